@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE ONLY -- import the *reference* DiffSBDD modules from
+/root/reference inside this (GPU-less) container so that
+
+  * oracle/ (our CPU restatement) can be validated against the real thing, and
+  * tests/golden/make_golden.py can generate the committed golden vectors.
+
+/root/reference does not exist on the GPU box, so nothing in `-m gpu` tests,
+smoke() or bench.py may import this module.  It copies no reference source; it
+only provides stand-ins for third-party modules that are missing in this image
+(SURVEY.md §8c):
+
+  torch_scatter.scatter_add / scatter_mean   (en_diffusion.py:8, conditional_model.py:6)
+  rdkit, Bio, networkx, openbabel             (utils.py:6-9, import-time only)
+"""
+import os
+import sys
+import types
+
+import torch
+
+REF_ROOT = os.environ.get("DIFFSBDD_REFERENCE", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REF_ROOT, "equivariant_diffusion", "egnn_new.py"))
+
+
+def _scatter_add(src, index, dim=0, out=None, dim_size=None):
+    assert dim == 0
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
+    res = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    return res.index_add_(0, index, src)
+
+
+def _scatter_mean(src, index, dim=0, out=None, dim_size=None):
+    assert dim == 0
+    s = _scatter_add(src, index, dim=0, dim_size=dim_size)
+    cnt = torch.zeros(s.shape[0], dtype=src.dtype, device=src.device)
+    cnt.index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+    cnt = cnt.clamp(min=1)
+    return s / cnt.view((-1,) + (1,) * (s.dim() - 1))
+
+
+def _install_stubs():
+    if "torch_scatter" not in sys.modules:
+        m = types.ModuleType("torch_scatter")
+        m.scatter_add = _scatter_add
+        m.scatter_mean = _scatter_mean
+        sys.modules["torch_scatter"] = m
+
+    def stub(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        mod = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+        return mod
+
+    class _Dummy:  # placeholder for names imported at module import time
+        def __init__(self, *a, **k):
+            pass
+
+    rd = stub("rdkit")
+    chem = stub("rdkit.Chem", BondType=types.SimpleNamespace(
+        SINGLE=1, DOUBLE=2, TRIPLE=3, AROMATIC=4))
+    rd.Chem = chem
+    try:
+        import networkx  # noqa: F401  (present in this image via torch deps)
+        import networkx.algorithms  # noqa: F401
+    except Exception:
+        nx = stub("networkx")
+        alg = stub("networkx.algorithms", isomorphism=types.SimpleNamespace())
+        nx.algorithms = alg
+    bio = stub("Bio")
+    pdb = stub("Bio.PDB")
+    poly = stub("Bio.PDB.Polypeptide", is_aa=lambda *a, **k: True,
+                three_to_one=lambda x: x)
+    bio.PDB = pdb
+    pdb.Polypeptide = poly
+    pdb.PDBParser = _Dummy
+
+
+def import_reference():
+    """Returns (dynamics_mod, en_diffusion_mod, conditional_model_mod, egnn_mod)
+    of the reference.  Never writes into /root/reference (no bytecode)."""
+    if not reference_available():
+        raise RuntimeError(f"reference not found under {REF_ROOT}")
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    # The repo root contains a drop-in package with the same name
+    # (`equivariant_diffusion`).  Make sure the reference one wins here.
+    for name in [n for n in sys.modules if n == "equivariant_diffusion"
+                 or n.startswith("equivariant_diffusion.") or n == "utils"]:
+        del sys.modules[name]
+    sys.path.insert(0, REF_ROOT)
+    try:
+        import equivariant_diffusion.egnn_new as egnn_mod
+        import equivariant_diffusion.en_diffusion as en_mod
+        import equivariant_diffusion.dynamics as dyn_mod
+        import equivariant_diffusion.conditional_model as cond_mod
+    finally:
+        sys.path.remove(REF_ROOT)
+    # keep them importable under private names, free the public names again
+    mods = (dyn_mod, en_mod, cond_mod, egnn_mod)
+    for name in [n for n in sys.modules if n == "equivariant_diffusion"
+                 or n.startswith("equivariant_diffusion.") or n == "utils"]:
+        sys.modules["_ref_" + name] = sys.modules.pop(name)
+    return mods

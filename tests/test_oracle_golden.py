@@ -1,0 +1,175 @@
+"""CPU: the oracle (our restatement) must reproduce the golden vectors that
+tests/golden/make_golden.py generated from the REAL reference.  This is what
+pins the oracle (the reference itself has no tests)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddpm_oracle as do
+from oracle import egnn_oracle as eo
+from tests._golden import Case, DYN_CASES
+
+# the oracle replays the reference's op sequence on the same torch build, so
+# agreement is at (or near) bit level; the tolerance only allows for BLAS
+# thread-count dependent summation order.
+TOL = 2e-6
+
+
+@pytest.mark.parametrize("name", DYN_CASES)
+def test_dynamics_forward_matches_golden(name):
+    c = Case(name)
+    sd = c.state_dict()
+    edges = c.t("edges", torch.int64)
+    trace = []
+    e_l, e_p, e_used = eo.dynamics_forward(
+        sd, c.cfg, c.t("xh_lig"), c.t("xh_pocket"), c.t("t"), c.t("mask_lig"),
+        c.t("mask_pocket"), edges=edges, trace=trace)
+    assert (e_l - c.t("eps_lig")).abs().max() < TOL
+    assert (e_p - c.t("eps_pocket")).abs().max() < TOL
+    for i, (h, x) in enumerate(trace):
+        if c.has(f"trace_x_{i}"):
+            assert (x - c.t(f"trace_x_{i}")).abs().max() < TOL
+        if c.has(f"trace_h_{i}"):
+            assert (h - c.t(f"trace_h_{i}")).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("name", DYN_CASES)
+def test_edge_builder_matches_golden(name):
+    """dynamics.py:169-187.  exact=False uses torch.cdist like the reference ->
+    identical list; exact=True may differ only inside the ambiguity band."""
+    c = Case(name)
+    xl, xp = c.t("xh_lig")[:, :3], c.t("xh_pocket")[:, :3]
+    ml, mp = c.t("mask_lig"), c.t("mask_pocket")
+    cuts = (c.cfg["edge_cutoff_ligand"], c.cfg["edge_cutoff_pocket"],
+            c.cfg["edge_cutoff_interaction"])
+    ref = c.t("edges", torch.int64)
+    e = eo.get_edges(ml, mp, xl, xp, *cuts, exact=False)
+    assert torch.equal(e, ref)
+    e2 = eo.get_edges(ml, mp, xl, xp, *cuts, exact=True)
+    n = len(ml) + len(mp)
+    a = torch.zeros(n, n, dtype=torch.bool); a[ref[0], ref[1]] = True
+    b = torch.zeros(n, n, dtype=torch.bool); b[e2[0], e2[1]] = True
+    band = eo.edge_ambiguity_band(ml, mp, xl, xp, *cuts, tol=1e-3)
+    assert not ((a ^ b) & ~band).any()
+    # sorted by (row, col), self loops present, same-sample only
+    key = ref[0] * n + ref[1]
+    assert torch.all(key[1:] > key[:-1])
+    m = torch.cat([ml, mp])
+    assert torch.all(m[ref[0]] == m[ref[1]])
+    assert a.diagonal().all()
+
+
+def test_schedule_known_answers():
+    z = np.load(__import__("os").path.join(__import__("tests._golden", fromlist=["GOLDEN_DIR"]).GOLDEN_DIR,
+                                            "schedule.npz"))
+    for tag, (sched, T, prec) in {
+        "poly2_T500_p5e-4": ("polynomial_2", 500, 5e-4),
+        "poly2_T500_p1e-5": ("polynomial_2", 500, 1e-5),
+        "poly2_T20_p5e-4": ("polynomial_2", 20, 5e-4),
+        "cosine_T20_p1e-4": ("cosine", 20, 1e-4),
+        "cosine_T1000_p1e-4": ("cosine", 1000, 1e-4),
+    }.items():
+        g = do.gamma_table(sched, T, prec).numpy()
+        assert g.shape == (T + 1,)
+        np.testing.assert_array_equal(g, z["gamma_" + tag])
+    # the SURVEY.md §8(a) known answers
+    g = do.gamma_table("polynomial_2", 500, 5e-4)
+    for idx, val in {0: -7.600402, 1: -7.584537, 250: -0.2510605, 499: 7.568981, 500: 7.600370}.items():
+        assert abs(float(g[idx]) - val) < 2e-6
+    g = do.gamma_table("polynomial_2", 500, 1e-5)
+    for idx, val in {0: -11.512916, 250: -0.2513093, 500: 11.511320}.items():
+        assert abs(float(g[idx]) - val) < 2e-6
+    for rec in json.loads(str(z["repaint_json"])):
+        s = do.repaint_schedule(rec["resamplings"], rec["jump_length"], rec["timesteps"])
+        assert s == rec["schedule"]
+    # total inner iterations
+    assert sum(do.repaint_schedule(1, 1, 500)) == 500
+    assert sum(do.repaint_schedule(2, 1, 500)) == 999
+    assert sum(do.repaint_schedule(10, 1, 500)) == 4991
+    assert sum(do.repaint_schedule(10, 10, 500)) == 4910
+
+
+def _model(c, simple=False):
+    cfg, dd = c.cfg, c.ddpm
+    return do.OracleModel(c.state_dict(), cfg, cfg["atom_nf"], cfg["residue_nf"],
+                          dd["timesteps"], dd["noise_schedule"], dd["noise_precision"],
+                          norm_values=dd["norm_values"], conditional=dd["conditional"])
+
+
+@pytest.mark.parametrize("name", ["ddpm_small_cond", "ddpm_small_variant"])
+def test_cond_sampling_loop_matches_golden(name):
+    c = Case(name)
+    m = _model(c)
+    trace = []
+    out_l, out_p, lm, pm = do.cond_sample_given_pocket(
+        m, c.pocket(), c.t("num_nodes_lig"), do.NoiseReplay(c.noise()),
+        timesteps=int(c.z["timesteps"]), trace=trace)
+    steps = c.steps()
+    assert len(trace) == len(steps) == int(c.z["timesteps"])
+    for (zt, pt, zs, ps), g in zip(trace, steps):
+        assert (zt - g["zt"]).abs().max() < 1e-5
+        assert (zs - g["zs"]).abs().max() < 1e-5
+        assert (ps - g["ps"]).abs().max() < 1e-5
+    assert (out_l[:, :3] - c.t("out_lig")[:, :3]).abs().max() < 1e-4
+    assert torch.equal(out_l[:, 3:].long(), c.t("out_lig")[:, 3:].long())
+    assert (out_p - c.t("out_pocket")).abs().max() < 1e-4
+    assert m.n_dynamics_calls == int(c.z["timesteps"]) + 1
+
+
+def test_cond_teacher_forced_steps_match_golden():
+    """Per-step parity the way the GPU tests do it: feed the golden z_t."""
+    c = Case("ddpm_small_cond")
+    m = _model(c)
+    noise = c.noise()
+    lm = torch.repeat_interleave(torch.arange(len(c.t("num_nodes_lig"))), c.t("num_nodes_lig"))
+    pm = c.t("pocket_mask")
+    for i, g in enumerate(c.steps()):
+        zs, ps = do.cond_sample_p_zs_given_zt(m, g["s"], g["t"], g["zt"], g["pt"], lm, pm,
+                                              do.NoiseReplay([noise[1 + i]]))
+        assert (zs - g["zs"]).abs().max() < 2e-6
+        assert (ps - g["ps"]).abs().max() < 2e-6
+
+
+def test_cond_inpaint_and_diversify_match_golden():
+    c = Case("ddpm_small_cond_inpaint")
+    m = _model(c)
+    ligand = c.pocket("ligand_")
+    out_l, out_p, _, _ = do.cond_inpaint(
+        m, ligand, c.pocket(), c.t("lig_fixed"), do.NoiseReplay(c.noise()),
+        resamplings=int(c.z["resamplings"]), timesteps=int(c.z["timesteps"]))
+    assert (out_l[:, :3] - c.t("out_lig")[:, :3]).abs().max() < 1e-4
+    assert torch.equal(out_l[:, 3:].long(), c.t("out_lig")[:, 3:].long())
+    assert (out_p - c.t("out_pocket")).abs().max() < 1e-4
+    m2 = _model(c)
+    d_l, d_p, _, _ = do.cond_diversify(m2, ligand, c.pocket(), int(c.z["div_steps"]),
+                                       do.NoiseReplay(c.noise("divnoise_", "n_draws_div")))
+    assert (d_l[:, :3] - c.t("div_lig")[:, :3]).abs().max() < 1e-4
+    assert torch.equal(d_l[:, 3:].long(), c.t("div_lig")[:, 3:].long())
+
+
+def test_joint_sampling_and_inpaint_match_golden():
+    c = Case("ddpm_small_joint")
+    m = _model(c)
+    out_l, out_p, lm, pm = do.joint_sample(
+        m, len(c.t("num_nodes_lig")), c.t("num_nodes_lig"), c.t("num_nodes_pocket"),
+        do.NoiseReplay(c.noise()), timesteps=int(c.z["timesteps"]))
+    assert (out_l[:, :3] - c.t("out_lig")[:, :3]).abs().max() < 1e-4
+    assert torch.equal(out_l[:, 3:].long(), c.t("out_lig")[:, 3:].long())
+    assert (out_p[:, :3] - c.t("out_pocket")[:, :3]).abs().max() < 1e-4
+    assert torch.equal(out_p[:, 3:].long(), c.t("out_pocket")[:, 3:].long())
+    # RePaint with the joint model
+    m2 = _model(c)
+    n_lig = c.t("num_nodes_lig")
+    lmask = torch.repeat_interleave(torch.arange(len(n_lig)), n_lig)
+    ligand = {"x": torch.zeros(len(lmask), 3), "one_hot": torch.zeros(len(lmask), c.cfg["atom_nf"]),
+              "size": n_lig, "mask": lmask}
+    pocket = c.pocket("inp_pocket_")
+    o_l, o_p, _, _ = do.joint_inpaint(
+        m2, ligand, pocket, torch.zeros(len(lmask)), torch.ones(len(pocket["mask"])),
+        do.NoiseReplay(c.noise("inpnoise_", "n_draws_inp")),
+        resamplings=int(c.z["inp_resamplings"]), jump_length=1, timesteps=int(c.z["inp_timesteps"]))
+    assert (o_l[:, :3] - c.t("inp_out_lig")[:, :3]).abs().max() < 1e-4
+    assert torch.equal(o_l[:, 3:].long(), c.t("inp_out_lig")[:, 3:].long())
+    assert (o_p[:, :3] - c.t("inp_out_pocket")[:, :3]).abs().max() < 1e-4
