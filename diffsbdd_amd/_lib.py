@@ -1,0 +1,118 @@
+"""ctypes binding of libdiffsbdd_hip.so (include/diffsbdd_hip.h).
+
+The library is built in-tree by `diffsbdd_amd.build.build()` (hipcc,
+--offload-arch=gfx950).  There is NO fallback: if the shared object is missing
+or does not export the expected ABI, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffsbdd_hip.so")
+ABI_VERSION = 1
+
+# error / status codes (include/diffsbdd_hip.h)
+OK, ERR_ARG, ERR_STATE, ERR_CAPACITY, ERR_LAUNCH = 0, -1, -2, -3, -4
+STATUS_NAN, STATUS_EDGE_OVERFLOW = 1, 2
+
+# weight-slot enums
+G_NAMES = ["ATOM_ENC_W0T", "ATOM_ENC_B0", "ATOM_ENC_W1T", "ATOM_ENC_B1",
+           "RES_ENC_W0T", "RES_ENC_B0", "RES_ENC_W1T", "RES_ENC_B1",
+           "ATOM_DEC_W0T", "ATOM_DEC_B0", "ATOM_DEC_W1T", "ATOM_DEC_B1",
+           "RES_DEC_W0T", "RES_DEC_B0", "RES_DEC_W1T", "RES_DEC_B1",
+           "EMB_WT", "EMB_B", "EMBOUT_WT", "EMBOUT_B"]
+GCL_NAMES = ["E1_WT", "E1_WD", "E1_WD0", "E1_TAB", "E2_WT", "E2_B", "ATT_W", "ATT_B",
+             "N1_WT", "N1_B", "N2_WT", "N2_B"]
+EQ_NAMES = ["C1_WT", "C_WD", "C_WD0", "C_TAB", "C_W2T", "C_B2",
+            "X_WD", "X_WD0", "X_TAB", "X_W2T", "X_B2", "W3"]
+BUF_EDGE_ROW, BUF_EDGE_COL, BUF_EDGE_D0, BUF_ROW_PTR, BUF_H, BUF_X, BUF_NODE_BATCH = range(7)
+
+
+class Config(C.Structure):
+    """struct dsbdd_config"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "atom_nf", "residue_nf", "joint_nf", "hidden_nf", "n_layers", "inv_sublayers",
+        "attention", "use_tanh", "update_pocket_coords", "reflection_equivariant",
+        "edge_embedding_dim", "has_cutoff_ligand", "has_cutoff_pocket",
+        "has_cutoff_interaction")] + [(n, C.c_float) for n in (
+            "cutoff_ligand", "cutoff_pocket", "cutoff_interaction",
+            "norm_constant", "normalization_factor", "coords_range")]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_F = C.c_float
+
+# name -> (restype, argtypes); every symbol include/diffsbdd_hip.h declares
+SIGNATURES = {
+    "dsbdd_abi_version": (C.c_int, []),
+    "dsbdd_last_error": (C.c_char_p, []),
+    "dsbdd_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "dsbdd_engine_destroy": (None, [_P]),
+    "dsbdd_engine_weight_slots": (C.c_int, [_P]),
+    "dsbdd_engine_set_weights": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
+    "dsbdd_engine_workspace_bytes": (C.c_size_t, [_P, _I64, _I64, _I64, _I64]),
+    "dsbdd_engine_bind_workspace": (C.c_int, [_P, _P, C.c_size_t, _I64, _I64, _I64, _I64]),
+    "dsbdd_engine_set_trace": (C.c_int, [_P, _P, _P]),
+    "dsbdd_dynamics_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64,
+                                         _P, _P, _I64, _P, _P, _P]),
+    "dsbdd_engine_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "dsbdd_engine_profile": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dsbdd_engine_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "dsbdd_cond_reverse_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
+                                            _I32, _I32, _F, _F, _F, _I32]),
+    "dsbdd_joint_reverse_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
+                                             _I32, _I32, _F, _F, _F]),
+    "dsbdd_randn_keyed": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, C.c_uint64, C.c_uint64,
+                                    C.c_uint32]),
+    "dsbdd_node_linear": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _P, _P, _I32,
+                                    _P, _I32, _I64, _I32, _I32]),
+    "dsbdd_build_edges": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, C.POINTER(Config),
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdiffsbdd_hip.so and bind every declared symbol.  Raises
+    HipLibraryError if the library is missing or incompatible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for the product path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.dsbdd_abi_version()
+    if ver != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {ver}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc == OK:
+        return
+    msg = load().dsbdd_last_error()
+    msg = msg.decode() if msg else ""
+    raise HipLibraryError(f"{what} failed with code {rc}: {msg}")

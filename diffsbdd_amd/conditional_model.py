@@ -1,0 +1,300 @@
+"""`ConditionalDDPM` / `SimpleConditionalDDPM` -- drop-in for the sampling API of
+/root/reference/equivariant_diffusion/conditional_model.py:12-746 (pocket fixed,
+ligand diffused): `sample_given_pocket`, `inpaint`, `diversify`,
+`sample_p_zs_given_zt`, `sample_p_zt_given_zs`, `sample_p_xh_given_z0`.
+
+The reverse loop (conditional_model.py:518-526) is the benchmark's hot path:
+per step one `EGNNDynamics.forward_async` (gfx950 kernels), one noise draw and
+one fused update kernel (`dsbdd_cond_reverse_update`: posterior mean, noise,
+ligand-COM removal from ligand and pocket), all enqueued on one stream with no
+host synchronisation.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .en_diffusion import EnVariationalDiffusion, num_nodes_to_batch_mask, seg_mean, seg_sum
+
+__all__ = ["ConditionalDDPM", "SimpleConditionalDDPM"]
+
+
+class ConditionalDDPM(EnVariationalDiffusion):
+    """Conditional diffusion module."""
+
+    _remove_com = 1   # SimpleConditionalDDPM switches the COM projection off
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert not self.dynamics.update_pocket_coords
+
+    # ---- COM handling (conditional_model.py:688-696) ------------------------------
+    @classmethod
+    def remove_mean_batch(cls, x_lig, x_pocket, lig_indices, pocket_indices):
+        """Subtract the LIGAND centre of mass from ligand and pocket."""
+        n = int(max(lig_indices.max(), pocket_indices.max())) + 1
+        mean = seg_mean(x_lig, lig_indices, n)
+        return x_lig - mean[lig_indices], x_pocket - mean[pocket_indices]
+
+    def _remove_lig_com(self, x_lig, x_pocket, lig_mask, pocket_mask, batch):
+        if not self._remove_com:
+            return x_lig, x_pocket
+        mean = seg_mean(x_lig, lig_mask, batch)
+        return x_lig - mean[lig_mask], x_pocket - mean[pocket_mask]
+
+    # ---- Gaussian draws around a mean (conditional_model.py:140-160) ------------------
+    def sample_normal(self, *args):
+        raise NotImplementedError("Has been replaced by sample_normal_zero_com()")
+
+    def sample_normal_zero_com(self, mu_lig, xh0_pocket, sigma, lig_mask, pocket_mask, fix_noise=False):
+        if fix_noise:
+            raise NotImplementedError("fix_noise option isn't implemented yet")
+        batch = sigma.shape[0]
+        nd = self.n_dims
+        eps = self._randn(lig_mask, nd + self.atom_nf, batch)
+        out = mu_lig + sigma[lig_mask] * eps
+        xl, xp = self._remove_lig_com(out[:, :nd], xh0_pocket[:, :nd], lig_mask, pocket_mask, batch)
+        return (torch.cat([xl, out[:, nd:]], dim=1).contiguous(),
+                torch.cat([xp, xh0_pocket[:, nd:]], dim=1).contiguous())
+
+    def noised_representation(self, xh_lig, xh0_pocket, lig_mask, pocket_mask, gamma_t):
+        batch = gamma_t.shape[0]
+        nd = self.n_dims
+        alpha_t, sigma_t = self.alpha(gamma_t, xh_lig), self.sigma(gamma_t, xh_lig)
+        eps = self._randn(lig_mask, nd + self.atom_nf, batch)
+        z = alpha_t[lig_mask] * xh_lig + sigma_t[lig_mask] * eps
+        xl, xp = self._remove_lig_com(z[:, :nd], xh0_pocket[:, :nd], lig_mask, pocket_mask, batch)
+        return (torch.cat([xl, z[:, nd:]], dim=1).contiguous(),
+                torch.cat([xp, xh0_pocket[:, nd:]], dim=1).contiguous(), eps)
+
+    def sample_combined_position_feature_noise(self, lig_indices, xh0_pocket, pocket_indices):
+        raise NotImplementedError("Use sample_normal_zero_com() instead.")
+
+    def sample(self, *args):
+        raise NotImplementedError("Conditional model does not support sampling without given pocket.")
+
+    # ---- one reverse step (conditional_model.py:432-464) ------------------------------------
+    def _cond_step(self, s, co, z_lig, xh_pocket, lig_mask, pocket_mask, batch, status):
+        """In place: z_lig (level s+1 -> s) and the pocket translation."""
+        eps, _, _ = self._dyn(z_lig, xh_pocket, co.t_value[s + 1], lig_mask, pocket_mask, batch, status,
+                              False)
+        noise = self._randn(lig_mask, self.n_dims + self.atom_nf, batch)
+        lib = _lib.load()
+        _lib.check(lib.dsbdd_cond_reverse_update(
+            torch.cuda.current_stream(z_lig.device).cuda_stream, z_lig.data_ptr(), xh_pocket.data_ptr(),
+            eps.data_ptr(), noise.data_ptr(), lig_mask.data_ptr(), pocket_mask.data_ptr(),
+            lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf, self.residue_nf,
+            float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s]), self._remove_com),
+            "dsbdd_cond_reverse_update")
+
+    def _step_impl(self, s_int, co, z_l, z_p, lig_mask, pocket_mask, batch, status):
+        self._cond_step(s_int, co, z_l, z_p, lig_mask, pocket_mask, batch, status)
+
+    def sample_p_zt_given_zs(self, zs_lig, xh0_pocket, ligand_mask, pocket_mask, gamma_t, gamma_s,
+                             fix_noise=False):
+        _, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, zs_lig)
+        mu = alpha_ts[ligand_mask] * zs_lig
+        return self.sample_normal_zero_com(mu, xh0_pocket, sigma_ts, ligand_mask, pocket_mask, fix_noise)
+
+    # ---- p(x, h | z_0) (conditional_model.py:112-135) ---------------------------------------------
+    def sample_p_xh_given_z0(self, z0_lig, xh0_pocket, lig_mask, pocket_mask, batch_size, fix_noise=False):
+        dev = z0_lig.device
+        nd = self.n_dims
+        t0 = torch.zeros((batch_size, 1), device=dev)
+        gamma_0 = self.gamma(t0)
+        sigma_x = self.SNR(-0.5 * gamma_0)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        net, _, _ = self._dyn(z0_lig.contiguous(), xh0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
+                              batch_size, status, False)
+        self._check_status(status)
+        mu = self.compute_x_pred(net, z0_lig, gamma_0, lig_mask)
+        xh_lig, xh_pocket = self.sample_normal_zero_com(mu, xh0_pocket, sigma_x, lig_mask, pocket_mask,
+                                                        fix_noise)
+        x_lig, h_lig = self.unnormalize(xh_lig[:, :nd], z0_lig[:, nd:])
+        x_pocket, h_pocket = self.unnormalize(xh_pocket[:, :nd], xh_pocket[:, nd:])
+        h_lig = F.one_hot(torch.argmax(h_lig, dim=1), self.atom_nf)
+        return x_lig, h_lig, x_pocket, h_pocket
+
+    # ---- sampling (conditional_model.py:478-555) -----------------------------------------------------
+    def _prepare_pocket(self, pocket, dev):
+        for k in ('x', 'one_hot', 'size', 'mask'):
+            pocket[k] = pocket[k].to(dev)
+        pocket['mask'] = pocket['mask'].to(torch.int64).contiguous()
+        return pocket
+
+    @torch.no_grad()
+    def sample_given_pocket(self, pocket, num_nodes_lig, return_frames=1, timesteps=None):
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps
+        assert timesteps % return_frames == 0
+        dev = self._hip_device(None)
+        pocket = self._prepare_pocket(pocket, dev)
+        n = len(pocket['size'])
+        nd = self.n_dims
+        _, pocket = self.normalize(pocket=pocket)
+        pm = pocket['mask']
+        xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+        lig_mask = num_nodes_to_batch_mask(n, num_nodes_lig, dev).contiguous()
+
+        # z_T ~ N(pocket COM, I), then ligand-COM-free (conditional_model.py:501-508)
+        mu_x = seg_mean(pocket['x'], pm, n)
+        mu = torch.cat((mu_x, torch.zeros((n, self.atom_nf), device=dev)), dim=1)[lig_mask]
+        sigma = torch.ones((n, 1), device=dev)
+        z_lig, xh_pocket = self.sample_normal_zero_com(mu, xh0_pocket, sigma, lig_mask, pm)
+
+        out_lig = torch.zeros((return_frames,) + z_lig.size(), device=dev)
+        out_pocket = torch.zeros((return_frames,) + xh_pocket.size(), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        co = self._coefs(timesteps)
+        for s in reversed(range(0, timesteps)):
+            self._cond_step(s, co, z_lig, xh_pocket, lig_mask, pm, n, status)
+            if (s * return_frames) % timesteps == 0:
+                idx = (s * return_frames) // timesteps
+                out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_lig, xh_pocket)
+        self._check_status(status)
+        if self._remove_com:
+            self.assert_mean_zero_with_mask(z_lig[:, :nd], lig_mask)
+
+        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lig_mask, pm, n)
+        if self._remove_com:
+            self.assert_mean_zero_with_mask(x_lig, lig_mask)
+        if return_frames == 1:                                              # :541-547
+            max_cog = seg_sum(x_lig, lig_mask, n).abs().max().item()
+            if max_cog > 5e-2:
+                print(f'Warning CoG drift with error {max_cog:.3f}. Projecting the positions down.')
+                x_lig, x_pocket = self.remove_mean_batch(x_lig, x_pocket, lig_mask, pm)
+        out_lig[0] = torch.cat([x_lig, h_lig], dim=1)
+        out_pocket[0] = torch.cat([x_pocket, h_pocket], dim=1)
+        return out_lig.squeeze(0), out_pocket.squeeze(0), lig_mask, pm
+
+    # ---- RePaint-style inpainting (conditional_model.py:557-686) ---------------------------------------
+    @torch.no_grad()
+    def inpaint(self, ligand, pocket, lig_fixed, resamplings=1, return_frames=1, timesteps=None,
+                center='ligand'):
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps
+        assert timesteps % return_frames == 0
+        if len(lig_fixed.size()) == 1:
+            lig_fixed = lig_fixed.unsqueeze(1)
+        dev = self._hip_device(None)
+        pocket = self._prepare_pocket(pocket, dev)
+        ligand = self._prepare_pocket(ligand, dev)
+        lig_fixed = lig_fixed.to(dev).float()
+        fixed = lig_fixed.bool().view(-1)
+        n = len(ligand['size'])
+        nd = self.n_dims
+        ligand, pocket = self.normalize(ligand, pocket)
+        lm, pm = ligand['mask'], pocket['mask']
+
+        xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+        com_pocket_0 = seg_mean(pocket['x'], pm, n)
+        xh_ligand = torch.cat([ligand['x'], ligand['one_hot']], dim=1).clone()
+        if center == 'ligand':
+            mean_known = seg_mean(ligand['x'][fixed], lm[fixed], n)
+        elif center == 'pocket':
+            mean_known = seg_mean(pocket['x'], pm, n)
+        else:
+            raise NotImplementedError(f"Centering option {center} not implemented")
+        mu = torch.cat((mean_known, torch.zeros((n, self.atom_nf), device=dev)), dim=1)[lm]
+        z_lig, xh_pocket = self.sample_normal_zero_com(mu, xh0_pocket, torch.ones((n, 1), device=dev), lm, pm)
+
+        out_lig = torch.zeros((return_frames,) + z_lig.size(), device=dev)
+        out_pocket = torch.zeros((return_frames,) + xh_pocket.size(), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        co = self._coefs(timesteps)
+        for s in reversed(range(0, timesteps)):
+            g_s = co.gamma[s].view(1, 1).expand(n, 1).to(dev)
+            g_t = co.gamma[s + 1].view(1, 1).expand(n, 1).to(dev)
+            for u in range(resamplings):
+                # unknown part: one reverse step (updates the pocket translation too)
+                z_unknown = z_lig.clone()
+                self._cond_step(s, co, z_unknown, xh_pocket, lm, pm, n, status)
+                # known part: move the input ligand with the pocket, noise it to level s
+                com_pocket = seg_mean(xh_pocket[:, :nd], pm, n)
+                xh_ligand[:, :nd] = ligand['x'] + (com_pocket - com_pocket_0)[lm]
+                z_known, xh_pocket, _ = self.noised_representation(xh_ligand, xh_pocket, lm, pm, g_s)
+                # align the COM of the fixed atoms of both parts, then blend
+                com_noised = seg_mean(z_known[fixed][:, :nd], lm[fixed], n)
+                com_denoised = seg_mean(z_unknown[fixed][:, :nd], lm[fixed], n)
+                dx = com_denoised - com_noised
+                z_known[:, :nd] = z_known[:, :nd] + dx[lm]
+                xh_pocket[:, :nd] = xh_pocket[:, :nd] + dx[pm]
+                z_lig = (z_known * lig_fixed + z_unknown * (1 - lig_fixed)).contiguous()
+                if u < resamplings - 1:
+                    z_lig, xh_pocket = self.sample_p_zt_given_zs(z_lig, xh_pocket, lm, pm, g_t, g_s)
+                if u == resamplings - 1 and (s * return_frames) % timesteps == 0:
+                    idx = (s * return_frames) // timesteps
+                    out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_lig, xh_pocket)
+        self._check_status(status)
+        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n)
+        out_lig[0] = torch.cat([x_lig, h_lig], dim=1)
+        out_pocket[0] = torch.cat([x_pocket, h_pocket], dim=1)
+        return out_lig.squeeze(0), out_pocket.squeeze(0), lm, pm
+
+    # ---- diversification (conditional_model.py:332-409) ---------------------------------------------------
+    def partially_noised_ligand(self, ligand, pocket, noising_steps):
+        n = ligand['size'].size(0)
+        nd = self.n_dims
+        dev = ligand['x'].device
+        t = torch.ones((n, 1), device=dev).float() * noising_steps / self.T
+        gamma_t = self.inflate_batch_array(self.gamma(t), ligand['x'])
+        xh0_lig = torch.cat([ligand['x'], ligand['one_hot']], dim=1)
+        xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+        xl, xp = self._remove_lig_com(xh0_lig[:, :nd], xh0_pocket[:, :nd], ligand['mask'], pocket['mask'], n)
+        xh0_lig = torch.cat([xl, xh0_lig[:, nd:]], dim=1)
+        xh0_pocket = torch.cat([xp, xh0_pocket[:, nd:]], dim=1)
+        return self.noised_representation(xh0_lig, xh0_pocket, ligand['mask'], pocket['mask'], gamma_t)
+
+    @torch.no_grad()
+    def diversify(self, ligand, pocket, noising_steps):
+        dev = self._hip_device(None)
+        pocket = self._prepare_pocket(pocket, dev)
+        ligand = self._prepare_pocket(ligand, dev)
+        ligand, pocket = self.normalize(ligand, pocket)
+        z_lig, xh_pocket, _ = self.partially_noised_ligand(ligand, pocket, noising_steps)
+        n = len(pocket['size'])
+        lm, pm = ligand['mask'], pocket['mask']
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        co = self._coefs(self.T)
+        for s in reversed(range(0, noising_steps)):
+            self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
+        self._check_status(status)
+        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n)
+        if self._remove_com:
+            self.assert_mean_zero_with_mask(x_lig, lm)
+        return torch.cat([x_lig, h_lig], dim=1), torch.cat([x_pocket, h_pocket], dim=1), lm, pm
+
+    # ---- training-only API: out of scope ----------------------------------------------------------------
+    def forward(self, ligand, pocket, return_info=False):
+        raise NotImplementedError(
+            "the training loss (conditional_model.py:202-330) is outside the MI355X sampling hot path "
+            "(SURVEY.md §2 row 4)")
+
+    def log_pN(self, N_lig, N_pocket):
+        return self.size_distribution.log_prob_n1_given_n2(N_lig, N_pocket)
+
+
+class SimpleConditionalDDPM(ConditionalDDPM):
+    """The same model without the subspace trick (conditional_model.py:702-746):
+    no COM projection; the pocket is centred once before sampling."""
+
+    _remove_com = 0
+
+    def subspace_dimensionality(self, input_size):
+        return input_size * self.n_dims
+
+    @classmethod
+    def remove_mean_batch(cls, x_lig, x_pocket, lig_indices, pocket_indices):
+        return x_lig, x_pocket
+
+    @staticmethod
+    def assert_mean_zero_with_mask(x, node_mask, eps=1e-10):
+        return
+
+    @torch.no_grad()
+    def sample_given_pocket(self, pocket, num_nodes_lig, return_frames=1, timesteps=None):
+        n = len(pocket['size'])
+        com = seg_mean(pocket['x'], pocket['mask'], n)
+        pocket['x'] = pocket['x'] - com[pocket['mask']]
+        return super().sample_given_pocket(pocket, num_nodes_lig, return_frames, timesteps)

@@ -1,0 +1,49 @@
+// Common device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsbdd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;  // 4 waves of 64 lanes per workgroup
+
+// SiLU(x) = x * sigmoid(x)  (nn.SiLU; egnn_new.py:8,16-19).  v_exp_f32 + v_rcp
+// based: ~2 ulp, saturates correctly at both ends (x -> -inf gives -0).
+__device__ __forceinline__ float silu(float x) {
+  return __fdividef(x, 1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+  return __fdividef(1.0f, 1.0f + __expf(-x));
+}
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32 (one fmaf
+// chain per output).  Lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; D register r of lane l is
+// D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int mfma_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// Bijective XCD-aware remap of a linear work index: workgroup b runs on XCD
+// b % 8 (observed dispatch order; speed only), so give every XCD a contiguous
+// chunk of the index space -> neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  constexpr int X = 8;
+  int q = n / X, r = n % X;
+  int xcd = b % X, k = b / X;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+
+}  // namespace dsbdd

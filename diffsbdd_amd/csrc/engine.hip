@@ -1,0 +1,518 @@
+// libdiffsbdd_hip.so -- C-ABI implementation (see include/diffsbdd_hip.h).
+// Host-side orchestration of one EGNNDynamics.forward call
+// (/root/reference/equivariant_diffusion/dynamics.py:87-167) as a fixed sequence
+// of asynchronous launches on the caller's stream: no allocation, no host sync.
+#include "../../include/diffsbdd_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "ddpm.h"
+#include "edge_mlp.h"
+#include "graph.h"
+#include "node_linear.h"
+
+using namespace dsbdd;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return fail(DSBDD_ERR_LAUNCH, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+static inline int pad4(int v) { return (v + 3) & ~3; }
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct dsbdd_engine {
+  dsbdd_config cfg;
+  std::vector<const float*> slots;
+  bool has_weights = false;
+  // workspace
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int64_t cap_lig = 0, cap_poc = 0, cap_batch = 0, cap_edges = 0;
+  int *node_batch, *lig_off, *poc_off, *deg, *row_ptr, *erow, *ecol;
+  float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *hout;
+  float *trace_h = nullptr, *trace_x = nullptr;
+  int n_cu = 256;
+  int edge_bm = 128;
+  // optional timing of the dominant kernel (GCL edge stage) with HIP events
+  bool profile = false;
+  std::vector<hipEvent_t> ev;   // pairs: start, stop
+  size_t ev_used = 0;
+  ~dsbdd_engine() {
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+  }
+};
+
+static int n_slots(const dsbdd_config& c) {
+  return DSBDD_G_COUNT + c.n_layers * (c.inv_sublayers * DSBDD_GCL_COUNT + DSBDD_EQ_COUNT);
+}
+static int gcl_slot(const dsbdd_config& c, int block, int sub, int which) {
+  return DSBDD_G_COUNT + block * (c.inv_sublayers * DSBDD_GCL_COUNT + DSBDD_EQ_COUNT) +
+         sub * DSBDD_GCL_COUNT + which;
+}
+static int eq_slot(const dsbdd_config& c, int block, int which) {
+  return DSBDD_G_COUNT + block * (c.inv_sublayers * DSBDD_GCL_COUNT + DSBDD_EQ_COUNT) +
+         c.inv_sublayers * DSBDD_GCL_COUNT + which;
+}
+
+struct WsLayout {
+  size_t off[32];
+  size_t total;
+};
+
+static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, int64_t E) {
+  const int64_t N = nl + np;
+  const int H = c.hidden_nf, JP = pad4(c.joint_nf + 1);
+  const int LE = pad4(2 * (c.atom_nf > c.residue_nf ? c.atom_nf : c.residue_nf));
+  const int PQ = (c.reflection_equivariant ? 2 : 4) * H;
+  size_t sizes[] = {
+      (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4, (size_t)(N + 1) * 4,  // 0-4
+      (size_t)E * 4, (size_t)E * 4, (size_t)E * 4,                                                  // 5-7 erow ecol ed0
+      (size_t)N * 12, (size_t)N * 12, (size_t)N * 12, (size_t)B * 12,                               // 8-11 x x_in xagg mean
+      (size_t)N * JP * 4, (size_t)N * LE * 4,                                                       // 12 h0, 13 enc_tmp
+      (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * PQ * 4,                  // 14 h 15 t1 16 agg 17 pq
+      (size_t)N * JP * 4};                                                                          // 18 hout
+  WsLayout L;
+  size_t o = 0;
+  const int n = sizeof(sizes) / sizeof(sizes[0]);
+  for (int i = 0; i < n; ++i) { L.off[i] = o; o += al256(sizes[i] + 16); }
+  L.total = o;
+  return L;
+}
+
+extern "C" {
+
+int dsbdd_abi_version(void) { return DSBDD_ABI_VERSION; }
+const char* dsbdd_last_error(void) { return g_err.c_str(); }
+
+int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
+  if (!cfg || !out) return fail(DSBDD_ERR_ARG, "null argument");
+  const int H = cfg->hidden_nf;
+  if (!(H == 64 || H == 128 || H == 192 || H == 256))
+    return fail(DSBDD_ERR_ARG, "hidden_nf must be one of 64, 128, 192, 256");
+  if (cfg->n_layers < 1 || cfg->inv_sublayers < 1 || cfg->atom_nf < 1 || cfg->residue_nf < 1 ||
+      cfg->joint_nf < 1 || cfg->edge_embedding_dim < 0)
+    return fail(DSBDD_ERR_ARG, "bad layer/feature counts");
+  if (!(cfg->normalization_factor > 0.f)) return fail(DSBDD_ERR_ARG, "normalization_factor must be > 0");
+  dsbdd_engine* e = new dsbdd_engine();
+  e->cfg = *cfg;
+  e->slots.assign(n_slots(*cfg), nullptr);
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+      prop.multiProcessorCount > 0)
+    e->n_cu = prop.multiProcessorCount;
+  const char* bm = getenv("DSBDD_EDGE_TILE");
+  if (bm && atoi(bm) == 64) e->edge_bm = 64;
+  *out = e;
+  return DSBDD_OK;
+}
+
+void dsbdd_engine_destroy(dsbdd_engine* e) { delete e; }
+
+int dsbdd_engine_weight_slots(const dsbdd_engine* e) { return e ? n_slots(e->cfg) : DSBDD_ERR_ARG; }
+
+int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, int n) {
+  if (!e || !slots_host) return fail(DSBDD_ERR_ARG, "null argument");
+  if (n != n_slots(e->cfg)) return fail(DSBDD_ERR_ARG, "wrong number of weight slots");
+  const dsbdd_config& c = e->cfg;
+  for (int i = 0; i < n; ++i) {
+    const float* ptr = slots_host[i];
+    bool optional = false;
+    // slots that may legitimately be absent
+    const int per = c.inv_sublayers * DSBDD_GCL_COUNT + DSBDD_EQ_COUNT;
+    if (i >= DSBDD_G_COUNT) {
+      const int r = (i - DSBDD_G_COUNT) % per;
+      if (r < c.inv_sublayers * DSBDD_GCL_COUNT) {
+        const int wch = r % DSBDD_GCL_COUNT;
+        if (!c.attention && (wch == DSBDD_GCL_ATT_W || wch == DSBDD_GCL_ATT_B)) optional = true;
+      } else {
+        const int wch = r - c.inv_sublayers * DSBDD_GCL_COUNT;
+        if (c.reflection_equivariant && wch >= DSBDD_EQ_X_WD && wch <= DSBDD_EQ_X_B2) optional = true;
+      }
+    }
+    if (!ptr && !optional) return fail(DSBDD_ERR_ARG, "null weight slot " + std::to_string(i));
+    if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15))
+      return fail(DSBDD_ERR_ARG, "weight slot " + std::to_string(i) + " not 16-byte aligned");
+    e->slots[i] = ptr;
+  }
+  e->has_weights = true;
+  return DSBDD_OK;
+}
+
+size_t dsbdd_engine_workspace_bytes(const dsbdd_engine* e, int64_t nl, int64_t np, int64_t B,
+                                    int64_t E) {
+  if (!e || nl < 0 || np < 0 || B < 1 || E < 0) return 0;
+  return carve(e->cfg, nl, np, B, E).total;
+}
+
+int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t nl, int64_t np,
+                                int64_t B, int64_t E) {
+  if (!e || !ws) return fail(DSBDD_ERR_ARG, "null argument");
+  if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(DSBDD_ERR_ARG, "workspace must be 256-byte aligned");
+  if ((nl + np) >= (1ll << 30) || E >= (1ll << 31) - 256) return fail(DSBDD_ERR_ARG, "problem too large for int32 indices");
+  WsLayout L = carve(e->cfg, nl, np, B, E);
+  if (bytes < L.total) return fail(DSBDD_ERR_CAPACITY, "workspace too small");
+  char* b = static_cast<char*>(ws);
+  e->ws = b; e->ws_bytes = bytes;
+  e->cap_lig = nl; e->cap_poc = np; e->cap_batch = B; e->cap_edges = E;
+  e->node_batch = (int*)(b + L.off[0]); e->lig_off = (int*)(b + L.off[1]); e->poc_off = (int*)(b + L.off[2]);
+  e->deg = (int*)(b + L.off[3]); e->row_ptr = (int*)(b + L.off[4]);
+  e->erow = (int*)(b + L.off[5]); e->ecol = (int*)(b + L.off[6]); e->ed0 = (float*)(b + L.off[7]);
+  e->x = (float*)(b + L.off[8]); e->x_in = (float*)(b + L.off[9]); e->xagg = (float*)(b + L.off[10]);
+  e->mean = (float*)(b + L.off[11]); e->h0 = (float*)(b + L.off[12]); e->enc_tmp = (float*)(b + L.off[13]);
+  e->h = (float*)(b + L.off[14]); e->t1 = (float*)(b + L.off[15]); e->agg = (float*)(b + L.off[16]);
+  e->pq = (float*)(b + L.off[17]); e->hout = (float*)(b + L.off[18]);
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_set_trace(dsbdd_engine* e, float* th, float* tx) {
+  if (!e) return DSBDD_ERR_ARG;
+  e->trace_h = th; e->trace_x = tx;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_profile(dsbdd_engine* e, int enable, int max_launches) {
+  if (!e || max_launches < 0) return fail(DSBDD_ERR_ARG, "bad argument");
+  e->profile = enable != 0;
+  e->ev_used = 0;
+  while (e->profile && e->ev.size() < (size_t)2 * max_launches) {
+    hipEvent_t a;
+    HIP_TRY(hipEventCreate(&a));
+    e->ev.push_back(a);
+  }
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_profile_read(dsbdd_engine* e, double* total_ms, int64_t* launches) {
+  if (!e || !total_ms || !launches) return fail(DSBDD_ERR_ARG, "null argument");
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(e->ev[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)(e->ev_used / 2);
+  e->ev_used = 0;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** out) {
+  if (!e || !out || !e->ws) return fail(DSBDD_ERR_STATE, "no workspace bound");
+  switch (which) {
+    case DSBDD_BUF_EDGE_ROW: *out = e->erow; break;
+    case DSBDD_BUF_EDGE_COL: *out = e->ecol; break;
+    case DSBDD_BUF_EDGE_D0: *out = e->ed0; break;
+    case DSBDD_BUF_ROW_PTR: *out = e->row_ptr; break;
+    case DSBDD_BUF_H: *out = e->h; break;
+    case DSBDD_BUF_X: *out = e->x; break;
+    case DSBDD_BUF_NODE_BATCH: *out = e->node_batch; break;
+    default: return fail(DSBDD_ERR_ARG, "unknown buffer id");
+  }
+  return DSBDD_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+static hipError_t nl(hipStream_t s, const float* A1, int lda1, int K1, const float* A2, int lda2, int K2,
+                     const float* WT, int ldw, const float* bias, const float* R, int ldr, float* C,
+                     int ldc, int64_t M, int N, int act) {
+  NodeLinearArgs a{A1, lda1, K1, A2, lda2, K2, WT, ldw, bias, R, ldr, C, ldc, (int)M, N, act};
+  return launch_node_linear(s, a);
+}
+
+template <int H, int BM, int BK>
+static hipError_t launch_edge_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+  if (mode == MODE_GCL)
+    hipLaunchKernelGGL((edge_mlp_kernel<H, BM, BK, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL((edge_mlp_kernel<H, BM, BK, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
+  return hipGetLastError();
+}
+
+static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
+                              int64_t edge_bound) {
+  const int H = e->cfg.hidden_nf;
+  const int bm = e->edge_bm;
+  int64_t tiles = (edge_bound + bm - 1) / bm;
+  int64_t resident = (int64_t)e->n_cu * (bm == 64 ? 2 : 1);
+  int64_t g = tiles < resident ? tiles : resident;
+  int grid = (int)((g + 7) / 8 * 8);
+  if (grid < 8) grid = 8;
+#define DSBDD_EDGE_CASE(HH)                                                        \
+  case HH:                                                                         \
+    return bm == 64 ? launch_edge_t<HH, 64, 16>(s, mode, a, grid)                  \
+                    : launch_edge_t<HH, 128, 32>(s, mode, a, grid);
+  switch (H) {
+    DSBDD_EDGE_CASE(64)
+    DSBDD_EDGE_CASE(128)
+    DSBDD_EDGE_CASE(192)
+    DSBDD_EDGE_CASE(256)
+  }
+#undef DSBDD_EDGE_CASE
+  return hipErrorInvalidValue;
+}
+
+static Cutoffs cutoffs_of(const dsbdd_config& c) {
+  return Cutoffs{c.has_cutoff_ligand, c.has_cutoff_pocket, c.has_cutoff_interaction,
+                 c.cutoff_ligand, c.cutoff_pocket, c.cutoff_interaction};
+}
+
+static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int B, const dsbdd_config& c,
+                            const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
+                            int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status) {
+  const int waves_per_block = kThreads / 64;
+  int blocks = (N + waves_per_block - 1) / waves_per_block;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  const Cutoffs cut = cutoffs_of(c);
+  hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
+                     poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
+                     (float*)nullptr, 0, status);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
+                     poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+extern "C" {
+
+int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, const float* xh_pocket,
+                           const float* t, int64_t t_count, const int64_t* mask_lig,
+                           const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                           const int32_t* ext_row, const int32_t* ext_col, int64_t ext_n_edges,
+                           float* eps_lig, float* eps_pocket, int32_t* status) {
+  if (!e || !xh_lig || !xh_pocket || !t || !mask_lig || !mask_pocket || !eps_lig || !status)
+    return fail(DSBDD_ERR_ARG, "null argument");
+  if (!e->has_weights) return fail(DSBDD_ERR_STATE, "weights not set");
+  if (!e->ws) return fail(DSBDD_ERR_STATE, "workspace not bound");
+  if (n_lig > e->cap_lig || n_pocket > e->cap_poc || batch > e->cap_batch || n_lig < 0 || n_pocket < 0 ||
+      batch < 1)
+    return fail(DSBDD_ERR_CAPACITY, "sizes exceed the bound workspace");
+  if (t_count != 1 && t_count != batch) return fail(DSBDD_ERR_ARG, "t must have 1 or batch entries");
+  const bool ext = ext_row != nullptr;
+  if (ext && (!ext_col || ext_n_edges < 0 || ext_n_edges > e->cap_edges))
+    return fail(DSBDD_ERR_CAPACITY, "external edge list exceeds edge capacity");
+
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dsbdd_config& c = e->cfg;
+  const int H = c.hidden_nf, J = c.joint_nf, JP = pad4(J + 1);
+  const int a = c.atom_nf, r = c.residue_nf, dl = 3 + a, dp = 3 + r;
+  const int LE = pad4(2 * (a > r ? a : r));
+  const int nlig = (int)n_lig, N = (int)(n_lig + n_pocket), B = (int)batch;
+  const int n_mlp = c.reflection_equivariant ? 1 : 2;
+  const int PQ = (c.reflection_equivariant ? 2 : 4) * H;
+  const float* const* W = e->slots.data();
+  if (N == 0) return DSBDD_OK;
+
+  // ---- masks -> offsets, split inputs ---------------------------------------
+  {
+    const int work = N > B + 1 ? N : B + 1;
+    hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
+                       (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(assemble_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xh_lig, dl, xh_pocket, dp,
+                       nlig, N, (const int*)e->node_batch, t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
+    HIP_TRY(hipGetLastError());
+  }
+  // ---- encoders (dynamics.py:96-97) -> h0[:, 0:J] ----------------------------
+  HIP_TRY(nl(s, xh_lig + 3, dl, a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0],
+             nullptr, 0, e->enc_tmp, LE, n_lig, 2 * a, 1));
+  HIP_TRY(nl(s, e->enc_tmp, LE, pad4(2 * a) <= LE ? 2 * a : 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W1T], pad4(J),
+             W[DSBDD_G_ATOM_ENC_B1], nullptr, 0, e->h0, JP, n_lig, J, 0));
+  {
+    float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
+    HIP_TRY(nl(s, xh_pocket + 3, dp, r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0],
+               nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
+    HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1],
+               nullptr, 0, e->h0 + (size_t)n_lig * JP, JP, n_pocket, J, 0));
+  }
+  // ---- edges (dynamics.py:114, 169-187) ---------------------------------------
+  int64_t edge_bound = e->cap_edges;
+  if (ext) {
+    HIP_TRY(hipMemsetAsync(e->deg, 0, (size_t)N * 4, s));
+    if (ext_n_edges > 0) {
+      hipLaunchKernelGGL(ext_edges_kernel, dim3((int)((ext_n_edges + 255) / 256)), dim3(256), 0, s, ext_row,
+                         ext_col, (int)ext_n_edges, (const float*)e->x, e->erow, e->ecol, e->ed0, e->deg);
+      HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->deg, e->row_ptr, N);
+    HIP_TRY(hipGetLastError());
+    edge_bound = ext_n_edges > 0 ? ext_n_edges : 1;
+  } else {
+    int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
+                              e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status);
+    if (rc) return rc;
+  }
+  // ---- embedding (egnn_new.py:233) ---------------------------------------------
+  HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
+  HIP_TRY(hipMemsetAsync(e->xagg, 0, (size_t)N * 12, s));
+
+  const int n_upd = c.update_pocket_coords ? N : nlig;   // update_coords_mask, dynamics.py:130-132
+  const int* e_all = e->row_ptr + N;
+  const int* e_upd = e->row_ptr + n_upd;                 // edges are row-sorted: a prefix
+
+  for (int blk = 0; blk < c.n_layers; ++blk) {
+    if (n_mlp == 2) {   // coord2cross needs the per-sample mean of the block's input x
+      hipLaunchKernelGGL(sample_mean_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)e->x,
+                         (const int*)e->lig_off, (const int*)e->poc_off, nlig, e->mean);
+      HIP_TRY(hipGetLastError());
+    }
+    for (int sub = 0; sub < c.inv_sublayers; ++sub) {
+      auto G = [&](int which) { return W[gcl_slot(c, blk, sub, which)]; };
+      // P | Q projections of the edge MLP's first layer
+      HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, G(DSBDD_GCL_E1_WT), 2 * H, nullptr, nullptr, 0, e->pq, PQ, N, 2 * H, 0));
+      HIP_TRY(hipMemsetAsync(e->agg, 0, (size_t)N * H * 4, s));
+      EdgeArgs ea{};
+      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.x = e->x;
+      ea.n_lig = nlig; ea.ldpq = PQ;
+      ea.mlp[0] = EdgeMlpW{e->pq, e->pq + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
+                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B)};
+      ea.mlp[1] = ea.mlp[0];
+      ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
+      ea.agg = e->agg; ea.norm_factor = c.normalization_factor;
+      const bool timed = e->profile && e->ev_used + 2 <= e->ev.size();
+      if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
+      HIP_TRY(launch_edge(e, s, MODE_GCL, ea, edge_bound));
+      if (timed) {
+        HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
+        e->ev_used += 2;
+      }
+      // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
+      HIP_TRY(nl(s, e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H, N, H, 1));
+      HIP_TRY(nl(s, e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H, N, H, 0));
+    }
+    {
+      auto Q = [&](int which) { return W[eq_slot(c, blk, which)]; };
+      HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ, N, PQ, 0));
+      EdgeArgs ea{};
+      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.x = e->x;
+      ea.n_lig = nlig; ea.ldpq = PQ;
+      ea.mlp[0] = EdgeMlpW{e->pq, e->pq + H, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
+                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2)};
+      if (n_mlp == 2)
+        ea.mlp[1] = EdgeMlpW{e->pq + 2 * H, e->pq + 3 * H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
+                             Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2)};
+      else
+        ea.mlp[1] = ea.mlp[0];
+      ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
+      ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
+      ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.norm_factor = c.normalization_factor;
+      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, edge_bound));
+      hipLaunchKernelGGL(coord_update_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, s, e->x, e->xagg,
+                         3 * n_upd, 3 * N);
+      HIP_TRY(hipGetLastError());
+    }
+    if (e->trace_h)
+      HIP_TRY(hipMemcpyAsync(e->trace_h + (size_t)blk * N * H, e->h, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s));
+    if (e->trace_x)
+      HIP_TRY(hipMemcpyAsync(e->trace_x + (size_t)blk * N * 3, e->x, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
+  }
+  // ---- embedding_out, decoders (egnn_new.py:241, dynamics.py:147-153) --------
+  HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, W[DSBDD_G_EMBOUT_WT], JP, W[DSBDD_G_EMBOUT_B], nullptr, 0, e->hout, JP, N, JP, 0));
+  HIP_TRY(nl(s, e->hout, JP, J, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_DEC_B0], nullptr, 0,
+             e->enc_tmp, LE, n_lig, 2 * a, 1));
+  HIP_TRY(nl(s, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W1T], pad4(a), W[DSBDD_G_ATOM_DEC_B1], nullptr, 0,
+             eps_lig + 3, dl, n_lig, a, 0));
+  if (eps_pocket) {
+    float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
+    HIP_TRY(nl(s, e->hout + (size_t)n_lig * JP, JP, J, nullptr, 0, 0, W[DSBDD_G_RES_DEC_W0T], pad4(2 * r),
+               W[DSBDD_G_RES_DEC_B0], nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
+    HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_DEC_W1T], pad4(r), W[DSBDD_G_RES_DEC_B1], nullptr, 0,
+               eps_pocket + 3, dp, n_pocket, r, 0));
+  }
+  // ---- velocity, NaN guard, joint-mode COM removal (dynamics.py:136,155-164) --
+  hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)e->x, (const float*)e->x_in,
+                     (const int*)e->lig_off, (const int*)e->poc_off, nlig, c.update_pocket_coords, eps_lig, dl,
+                     eps_pocket, dp, status);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_cond_reverse_update(void* stream, float* z_lig, float* xh_pocket, const float* eps_lig,
+                              const float* noise, const int64_t* mask_lig, const int64_t* mask_pocket,
+                              int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
+                              int32_t residue_nf, float alpha_ts, float c_eps, float sigma, int32_t remove_com) {
+  if (!z_lig || !xh_pocket || !eps_lig || !noise || !mask_lig || !mask_pocket || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(cond_update_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     z_lig, xh_pocket, eps_lig, noise, mask_lig, (int)n_lig, mask_pocket, (int)n_pocket,
+                     3 + atom_nf, 3 + residue_nf, alpha_ts, c_eps, sigma, remove_com);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_joint_reverse_update(void* stream, float* z_lig, float* z_pocket, const float* eps_lig,
+                               const float* eps_pocket, const float* noise_lig, const float* noise_pocket,
+                               const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
+                               int64_t n_pocket, int64_t batch, int32_t atom_nf, int32_t residue_nf,
+                               float alpha_ts, float c_eps, float sigma) {
+  if (!z_lig || !z_pocket || !eps_lig || !eps_pocket || !noise_lig || !noise_pocket || !mask_lig ||
+      !mask_pocket || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(joint_update_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     z_lig, z_pocket, eps_lig, eps_pocket, noise_lig, noise_pocket, mask_lig, (int)n_lig,
+                     mask_pocket, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, alpha_ts, c_eps, sigma);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_randn_keyed(void* stream, float* out, const int64_t* mask, int64_t n_rows, int32_t n_cols,
+                      int64_t batch, int64_t sample_offset, uint64_t seed, uint64_t draw_index,
+                      uint32_t stream_id) {
+  (void)batch;
+  if (!out || !mask || n_rows < 0 || n_cols < 1) return fail(DSBDD_ERR_ARG, "bad argument");
+  const int64_t n = n_rows * n_cols;
+  if (n == 0) return DSBDD_OK;
+  hipLaunchKernelGGL(randn_keyed_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), out, mask, (int)n_rows, (int)n_cols, sample_offset, seed,
+                     draw_index, stream_id);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_node_linear(void* stream, const float* A1, int32_t lda1, int32_t K1, const float* A2, int32_t lda2,
+                      int32_t K2, const float* WT, int32_t ldw, const float* bias, const float* R, int32_t ldr,
+                      float* C, int32_t ldc, int64_t M, int32_t N, int32_t act) {
+  if (!A1 || !WT || !C || K1 < 1 || K2 < 0 || (K2 > 0 && !A2) || (ldw & 3) || N > ldw ||
+      (reinterpret_cast<uintptr_t>(WT) & 15))
+    return fail(DSBDD_ERR_ARG, "bad argument (WT must be 16-byte aligned with ldw % 4 == 0)");
+  HIP_TRY(nl(static_cast<hipStream_t>(stream), A1, lda1, K1, A2, lda2, K2, WT, ldw, bias, R, ldr, C, ldc, M, N, act));
+  return DSBDD_OK;
+}
+
+int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig, const int64_t* mask_pocket,
+                      int64_t n_lig, int64_t n_pocket, int64_t batch, const dsbdd_config* cfg,
+                      int32_t* node_batch, int32_t* lig_off, int32_t* poc_off, int32_t* deg, int32_t* row_ptr,
+                      int32_t* edge_row, int32_t* edge_col, float* edge_d0, int64_t edge_capacity,
+                      int32_t* status) {
+  if (!x || !mask_lig || !mask_pocket || !cfg || !node_batch || !lig_off || !poc_off || !deg || !row_ptr ||
+      !edge_row || !edge_col || !edge_d0 || !status || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = (int)(n_lig + n_pocket), B = (int)batch;
+  const int work = N > B + 1 ? N : B + 1;
+  hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, (int)n_lig, mask_pocket,
+                     (int)n_pocket, B, node_batch, lig_off, poc_off);
+  HIP_TRY(hipGetLastError());
+  return build_edges_impl(s, x, (int)n_lig, N, B, *cfg, node_batch, lig_off, poc_off, deg, row_ptr, edge_row,
+                          edge_col, edge_d0, edge_capacity, status);
+}
+
+}  // extern "C"

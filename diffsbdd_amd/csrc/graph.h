@@ -1,0 +1,220 @@
+// Graph construction and per-node geometry kernels of EGNNDynamics.forward:
+//   - sample offsets from the (sorted) batch masks
+//   - radius graph -> edge list sorted by (row, col)      dynamics.py:169-187
+//   - input assembly (split xh, time feature)             dynamics.py:89-111
+//   - per-sample mean of x for coord2cross                egnn_new.py:307-310
+//   - coordinate update, velocity / NaN guard / COM       dynamics.py:136,155-164
+// All of this is O(N * n_per_sample) integer/float byte work (HBM/latency
+// bound, microseconds); one wave per row, ballot-compaction keeps the
+// reference's (row, col) order without a sort.
+#pragma once
+#include "common.h"
+
+namespace dsbdd {
+
+struct Cutoffs {
+  int has_l, has_p, has_i;
+  float cl, cp, ci;
+};
+
+__device__ __forceinline__ int lower_bound_i64(const int64_t* a, int n, int64_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// node_batch[i] = sample id of node i ([ligand | pocket] numbering);
+// lig_off[b] / poc_off[b] = first ligand / pocket node of sample b (b = 0..B).
+__global__ void prep_kernel(const int64_t* mask_lig, int n_lig, const int64_t* mask_poc, int n_poc,
+                            int B, int* node_batch, int* lig_off, int* poc_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_lig) node_batch[i] = (int)mask_lig[i];
+  else if (i < n_lig + n_poc) node_batch[i] = (int)mask_poc[i - n_lig];
+  if (i <= B) {
+    lig_off[i] = lower_bound_i64(mask_lig, n_lig, i);
+    poc_off[i] = lower_bound_i64(mask_poc, n_poc, i);
+  }
+}
+
+// One wave per row node.  FILL=false counts neighbours (deg), FILL=true writes
+// them at row_ptr[row].  Candidates are visited in index order (ligand nodes of
+// the sample, then its pocket nodes) and compacted with ballot/popcount, so the
+// output is sorted by (row, col) like torch.where(adj) (dynamics.py:185).
+// Self loops are kept (distance 0 <= cutoff; dynamics.py never removes them).
+template <bool FILL>
+__global__ __launch_bounds__(kThreads) void edges_kernel(
+    const float* __restrict__ x, const int* __restrict__ node_batch,
+    const int* __restrict__ lig_off, const int* __restrict__ poc_off, int n_lig, int n_nodes,
+    Cutoffs cut, int* __restrict__ deg, const int* __restrict__ row_ptr, int* __restrict__ erow,
+    int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n_nodes; i += nwaves) {
+    const int b = node_batch[i];
+    const bool il = i < n_lig;
+    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+    const int base = FILL ? row_ptr[i] : 0;
+    int cnt = 0;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+      const int j_begin = seg == 0 ? lig_off[b] : n_lig + poc_off[b];
+      const int j_end = seg == 0 ? lig_off[b + 1] : n_lig + poc_off[b + 1];
+      const bool jl = seg == 0;
+      const int has = (il && jl) ? cut.has_l : ((!il && !jl) ? cut.has_p : cut.has_i);
+      const float c = (il && jl) ? cut.cl : ((!il && !jl) ? cut.cp : cut.ci);
+      for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < j_end;
+        float d2 = 0.f;
+        if (valid) {
+          const float dx = xi - x[3 * j], dy = yi - x[3 * j + 1], dz = zi - x[3 * j + 2];
+          d2 = dx * dx + dy * dy + dz * dz;
+        }
+        // torch.cdist(...) <= cutoff  (dynamics.py:174-181), on the exact distance
+        const bool pass = valid && (!has || __fsqrt_rn(d2) <= c);
+        const unsigned long long m = __ballot(pass);
+        if (FILL && pass) {
+          const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < e_cap) {
+            erow[pos] = i; ecol[pos] = j; ed0[pos] = d2;
+          }
+        }
+        cnt += __popcll(m);
+      }
+    }
+    if (!FILL && lane == 0) deg[i] = cnt;
+    if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
+  }
+}
+
+// Exclusive scan of deg[0..n) -> row_ptr[0..n], row_ptr[n] = total.  One
+// workgroup of 1024 threads (n is tens of thousands).
+__global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr, int n) {
+  __shared__ int s[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int b = t * chunk, e = min(b + chunk, n);
+  int local = 0;
+  for (int i = b; i < e; ++i) local += deg[i];
+  s[t] = local;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+    const int v = (t >= o) ? s[t - o] : 0;
+    __syncthreads();
+    s[t] += v;
+    __syncthreads();
+  }
+  int run = s[t] - local;
+  for (int i = b; i < e; ++i) { row_ptr[i] = run; run += deg[i]; }
+  if (t == 1023) row_ptr[n] = s[1023];
+}
+
+// Teacher-forced edge list: copy rows/cols, compute d0, build row_ptr counts.
+__global__ void ext_edges_kernel(const int* row, const int* col, int E, const float* x, int* erow,
+                                 int* ecol, float* ed0, int* deg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int r = row[e], c = col[e];
+  erow[e] = r; ecol[e] = c;
+  const float dx = x[3 * r] - x[3 * c], dy = x[3 * r + 1] - x[3 * c + 1], dz = x[3 * r + 2] - x[3 * c + 2];
+  ed0[e] = dx * dx + dy * dy + dz * dz;
+  atomicAdd(&deg[r], 1);
+}
+
+// x[N][3] <- coordinates of both node sets; h0[:, J] <- t[sample]; pad columns
+// of h0 (J+1..JP-1) <- 0.  dynamics.py:89-111.
+__global__ void assemble_kernel(const float* xh_lig, int dl, const float* xh_poc, int dp, int n_lig,
+                                int n_nodes, const int* node_batch, const float* t, int t_count,
+                                float* x, float* x_in, float* h0, int J, int JP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const float* src = i < n_lig ? xh_lig + (size_t)i * dl : xh_poc + (size_t)(i - n_lig) * dp;
+  const float a = src[0], b = src[1], c = src[2];
+  x[3 * i] = a; x[3 * i + 1] = b; x[3 * i + 2] = c;
+  x_in[3 * i] = a; x_in[3 * i + 1] = b; x_in[3 * i + 2] = c;
+  h0[(size_t)i * JP + J] = t[t_count == 1 ? 0 : node_batch[i]];
+  for (int k = J + 1; k < JP; ++k) h0[(size_t)i * JP + k] = 0.f;
+}
+
+// mean[b] = mean of x over ALL nodes of sample b (egnn_new.py:307-310); one
+// workgroup per sample.
+__global__ __launch_bounds__(kThreads) void sample_mean_kernel(const float* x, const int* lig_off,
+                                                               const int* poc_off, int n_lig,
+                                                               float* mean) {
+  __shared__ float red[3][kThreads];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = l0 + t; i < l1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+  for (int i = p0 + t; i < p1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+  red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
+    __syncthreads();
+  }
+  if (t < 3) {
+    int cnt = (l1 - l0) + (p1 - p0);
+    if (cnt == 0) cnt = 1;
+    mean[3 * b + t] = red[t][0] / (float)cnt;
+  }
+}
+
+// x[i] += xagg[i] for the nodes whose coordinates are updated
+// (update_coords_mask, egnn_new.py:118-121), and clear xagg for the next block.
+__global__ void coord_update_kernel(float* x, float* xagg, int n_upd3, int n_all3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_all3) return;
+  if (i < n_upd3) x[i] += xagg[i];
+  xagg[i] = 0.f;
+}
+
+// vel = x_final - x_in (dynamics.py:136), NaN guard (dynamics.py:155-159: flag
+// instead of a host sync), optional per-sample mean removal in joint mode
+// (dynamics.py:161-164), scatter into eps[:, 0:3].  One workgroup per sample.
+__global__ __launch_bounds__(kThreads) void finalize_kernel(
+    const float* x, const float* x_in, const int* lig_off, const int* poc_off, int n_lig,
+    int remove_mean, float* eps_lig, int dl, float* eps_poc, int dp, int* status) {
+  __shared__ float red[3][kThreads];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  bool nan = false;
+  if (remove_mean) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int seg = 0; seg < 2; ++seg) {
+      const int a = seg ? p0 : l0, e = seg ? p1 : l1;
+      for (int i = a + t; i < e; i += kThreads) {
+        s0 += x[3 * i] - x_in[3 * i]; s1 += x[3 * i + 1] - x_in[3 * i + 1]; s2 += x[3 * i + 2] - x_in[3 * i + 2];
+      }
+    }
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+      if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
+      __syncthreads();
+    }
+    int cnt = (l1 - l0) + (p1 - p0);
+    if (cnt == 0) cnt = 1;
+    m0 = red[0][0] / (float)cnt; m1 = red[1][0] / (float)cnt; m2 = red[2][0] / (float)cnt;
+  }
+  for (int seg = 0; seg < 2; ++seg) {
+    const int a = seg ? p0 : l0, e = seg ? p1 : l1;
+    for (int i = a + t; i < e; i += kThreads) {
+      const float v0 = x[3 * i] - x_in[3 * i], v1 = x[3 * i + 1] - x_in[3 * i + 1],
+                  v2 = x[3 * i + 2] - x_in[3 * i + 2];
+      nan = nan || (v0 != v0) || (v1 != v1) || (v2 != v2);
+      float* dst = nullptr;
+      if (seg == 0) dst = eps_lig + (size_t)i * dl;
+      else if (eps_poc) dst = eps_poc + (size_t)(i - n_lig) * dp;
+      if (dst) { dst[0] = v0 - m0; dst[1] = v1 - m1; dst[2] = v2 - m2; }
+    }
+  }
+  if (nan) atomicOr(status, 1);
+}
+
+}  // namespace dsbdd

@@ -1,0 +1,173 @@
+// Dense per-node linear layer on the fp32 matrix cores:
+//
+//     C[M][N] = act( [A1 | A2][M][K1+K2] @ WT[K1+K2][N] + bias ) (+ R)
+//
+// Used for every node-level Linear of the denoiser: encoders/decoders
+// (dynamics.py:27-49), embedding / embedding_out (egnn_new.py:212-213), the
+// node MLP of GCL (egnn_new.py:21-24,56-57, input cat[h, agg] = the two A
+// sources) and the per-node first-layer projections of the edge MLPs (the
+// factorised form of Linear(cat[h_i, h_j, e])).
+//
+// Tiling: workgroup = 256 threads = 4 waves as 2(M) x 2(N); block tile
+// BM x 128, K step 32; each wave owns (BM/2) x 64 outputs as RT x 2 MFMA
+// 32x32 tiles (v_mfma_f32_32x32x2_f32, exact fp32).  Both operands sit in LDS
+// k-major (sA[k][m], sB[k][n]) so that the 32 lanes of a half-wave read 32
+// consecutive words (conflict-free ds_read_b32); the A tile is transposed on
+// its way into LDS with row stride BM+1 (conflict-free ds_write_b32).
+#pragma once
+#include "common.h"
+
+namespace dsbdd {
+
+struct NodeLinearArgs {
+  const float* A1; int lda1; int K1;
+  const float* A2; int lda2; int K2;
+  const float* WT; int ldw;
+  const float* bias;
+  const float* R; int ldr;
+  float* C; int ldc;
+  int M; int N; int act;
+};
+
+template <int BM, bool VEC_A>
+__global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p) {
+  constexpr int BN = 128, BK = 32, LDA = BM + 1;
+  constexpr int RT = BM / 64;  // 32-row MFMA tiles per wave
+  constexpr int AI = BM / 32;  // float4 A loads per thread per K step
+  __shared__ float sA[BK * LDA];
+  __shared__ float sB[BK * BN];
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int K = p.K1 + p.K2;
+
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[AI], rb[4];
+  const int a_kq = (t & 7) * 4, a_m = t >> 3;   // A: 8 lanes cover 32 consecutive k of one row
+  const int b_n = (t & 31) * 4, b_k = t >> 5;   // B: 32 lanes cover 128 consecutive n of one k
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int m = m0 + a_m + 32 * i, k = k0 + a_kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M) {
+        if (VEC_A) {
+          if (k < K) {
+            const float* src = (k < p.K1) ? p.A1 + (size_t)m * p.lda1 + k
+                                          : p.A2 + (size_t)m * p.lda2 + (k - p.K1);
+            v = ld4(src);
+          }
+        } else {
+          float e[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int kk = k + c;
+            e[c] = 0.f;
+            if (kk < K)
+              e[c] = (kk < p.K1) ? p.A1[(size_t)m * p.lda1 + kk]
+                                 : p.A2[(size_t)m * p.lda2 + (kk - p.K1)];
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + b_k + 8 * i, n = n0 + b_n;
+      // WT rows are padded to ldw (multiple of 4) -> a float4 never leaves the row
+      rb[i] = (k < K && n < p.ldw) ? ld4(p.WT + (size_t)k * p.ldw + n)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int m = a_m + 32 * i;
+      sA[(a_kq + 0) * LDA + m] = ra[i].x;
+      sA[(a_kq + 1) * LDA + m] = ra[i].y;
+      sA[(a_kq + 2) * LDA + m] = ra[i].z;
+      sA[(a_kq + 3) * LDA + m] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(&sB[(b_k + 8 * i) * BN + b_n]) = rb[i];
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    sstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * BK);  // in flight during the MFMAs
+    const float* pa = sA + (lane >> 5) * LDA + wm * (BM / 2) + (lane & 31);
+    const float* pb = sB + (lane >> 5) * BN + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[RT], b[2];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) a[i] = pa[kk * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = pb[kk * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: bias, activation, residual, store (32 consecutive columns per half-wave)
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + mfma_row(r, lane);
+        if (row >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (p.act == 1) v = silu(v);
+        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+        p.C[(size_t)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Host-side launcher.  Returns hipError_t of the launch.
+inline hipError_t launch_node_linear(hipStream_t s, const NodeLinearArgs& a) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  const bool vec = aligned16(a.A1) && (a.lda1 % 4 == 0) && (a.K1 % 4 == 0) &&
+                   (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
+  const int ny = (a.N + 127) / 128;
+  const long tiles128 = (long)((a.M + 127) / 128) * ny;
+  const bool big = tiles128 >= 512;  // enough 128-row tiles to fill 256 CUs twice
+  const int bm = big ? 128 : 64;
+  dim3 grid((a.M + bm - 1) / bm, ny), block(kThreads);
+  if (big) {
+    if (vec) hipLaunchKernelGGL((node_linear_kernel<128, true>), grid, block, 0, s, a);
+    else     hipLaunchKernelGGL((node_linear_kernel<128, false>), grid, block, 0, s, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((node_linear_kernel<64, true>), grid, block, 0, s, a);
+    else     hipLaunchKernelGGL((node_linear_kernel<64, false>), grid, block, 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace dsbdd

@@ -1,0 +1,249 @@
+"""`EGNNDynamics` -- drop-in for
+/root/reference/equivariant_diffusion/dynamics.py:10-187 whose forward pass runs
+entirely in the hand-written gfx950 kernels of libdiffsbdd_hip.so.
+
+What is mirrored exactly: the constructor keyword arguments (dynamics.py:11-19),
+the public attributes other code reads (`update_pocket_coords`, `edge_cutoff_*`,
+`n_dims`, `device`, `mode`, `edge_nf`, `node_nf`, `condition_time`), the
+`forward(xh_atoms, xh_residues, t, mask_atoms, mask_residues)` signature and
+return tuple (dynamics.py:87-167), the `ValueError("NaN detected in EGNN
+output")` contract (dynamics.py:155-159), `get_edges` (dynamics.py:169-187) and
+the `state_dict` key names and shapes, so released checkpoints
+load with `strict=True`.
+
+What is different: the modules below are *parameter containers*; nothing calls
+their `forward`.  The arithmetic is the factorised algorithm described in
+csrc/edge_mlp.h.  There is no CPU / PyTorch fallback: tensors must live on a
+GPU and the HIP library must be built, otherwise the call raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import HipEngine, edge_capacity, make_config
+
+_SUPPORTED_H = (64, 128, 192, 256)
+
+
+def _mlp(*dims, act, last_bias=True):
+    """Sequential(Linear, act, Linear[, act, Linear]) with the reference's
+    child indices 0, 2, 4 (dynamics.py:27-49, egnn_new.py:15-24,80-92)."""
+    layers = []
+    for i in range(len(dims) - 1):
+        last = i == len(dims) - 2
+        layers.append(nn.Linear(dims[i], dims[i + 1], bias=(last_bias or not last)))
+        if not last:
+            layers.append(act)
+    return nn.Sequential(*layers)
+
+
+class _GCLParams(nn.Module):
+    """Parameters of egnn_new.GCL (egnn_new.py:7-29)."""
+
+    def __init__(self, H, edges_in_d, act, attention):
+        super().__init__()
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * H + edges_in_d, H), act, nn.Linear(H, H), act)
+        self.node_mlp = _mlp(2 * H, H, H, act=act)
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(H, 1), nn.Sigmoid())
+
+
+class _EquivUpdateParams(nn.Module):
+    """Parameters of egnn_new.EquivariantUpdate (egnn_new.py:70-94).  The last,
+    bias-free Linear is ONE Parameter shared by both MLPs (egnn_new.py:78,85,91),
+    so `cross_product_mlp.4.weight` aliases `coord_mlp.4.weight` in state_dict."""
+
+    def __init__(self, H, edges_in_d, act, reflection_equiv):
+        super().__init__()
+        last = nn.Linear(H, 1, bias=False)
+        nn.init.xavier_uniform_(last.weight, gain=0.001)
+        self.coord_mlp = nn.Sequential(nn.Linear(2 * H + edges_in_d, H), act, nn.Linear(H, H), act, last)
+        self.cross_product_mlp = None if reflection_equiv else nn.Sequential(
+            nn.Linear(2 * H + edges_in_d, H), act, nn.Linear(H, H), act, last)
+
+
+class _BlockParams(nn.Module):
+    """egnn_new.EquivariantBlock (egnn_new.py:136-161)."""
+
+    def __init__(self, H, edge_feat_nf, act, inv_sublayers, attention, reflection_equiv):
+        super().__init__()
+        for i in range(inv_sublayers):
+            self.add_module(f"gcl_{i}", _GCLParams(H, edge_feat_nf, act, attention))
+        self.add_module("gcl_equiv", _EquivUpdateParams(H, edge_feat_nf, nn.SiLU(), reflection_equiv))
+
+
+class _EGNNParams(nn.Module):
+    """egnn_new.EGNN (egnn_new.py:188-223)."""
+
+    def __init__(self, in_node_nf, in_edge_nf, H, act, n_layers, inv_sublayers, attention,
+                 reflection_equiv):
+        super().__init__()
+        edge_feat_nf = 2 + in_edge_nf          # [d_cur, d_0] + edge-type embedding
+        self.embedding = nn.Linear(in_node_nf, H)
+        self.embedding_out = nn.Linear(H, in_node_nf)
+        for i in range(n_layers):
+            self.add_module(f"e_block_{i}", _BlockParams(H, edge_feat_nf, act, inv_sublayers,
+                                                         attention, reflection_equiv))
+
+
+class EGNNDynamics(nn.Module):
+    def __init__(self, atom_nf, residue_nf,
+                 n_dims, joint_nf=16, hidden_nf=64, device='cpu',
+                 act_fn=torch.nn.SiLU(), n_layers=4, attention=False,
+                 condition_time=True, tanh=False, mode='egnn_dynamics',
+                 norm_constant=0, inv_sublayers=2, sin_embedding=False,
+                 normalization_factor=100, aggregation_method='sum',
+                 update_pocket_coords=True, edge_cutoff_ligand=None,
+                 edge_cutoff_pocket=None, edge_cutoff_interaction=None,
+                 reflection_equivariant=True, edge_embedding_dim=None):
+        super().__init__()
+        # configurations the gfx950 kernels do not implement fail here, loudly
+        if mode != 'egnn_dynamics':
+            raise NotImplementedError("only mode='egnn_dynamics' is implemented on the HIP path")
+        if not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError("only act_fn=SiLU is implemented on the HIP path")
+        if sin_embedding:
+            raise NotImplementedError("sin_embedding=True is not implemented on the HIP path")
+        if aggregation_method != 'sum':
+            raise NotImplementedError("only aggregation_method='sum' is implemented on the HIP path")
+        if not condition_time:
+            raise NotImplementedError("condition_time=False is not implemented on the HIP path")
+        if n_dims != 3:
+            raise NotImplementedError("n_dims must be 3")
+        if hidden_nf not in _SUPPORTED_H:
+            raise NotImplementedError(f"hidden_nf must be one of {_SUPPORTED_H} (got {hidden_nf})")
+
+        self.mode = mode
+        self.edge_cutoff_l = edge_cutoff_ligand
+        self.edge_cutoff_p = edge_cutoff_pocket
+        self.edge_cutoff_i = edge_cutoff_interaction
+        self.edge_nf = edge_embedding_dim
+
+        self.atom_encoder = _mlp(atom_nf, 2 * atom_nf, joint_nf, act=act_fn)
+        self.atom_decoder = _mlp(joint_nf, 2 * atom_nf, atom_nf, act=act_fn)
+        self.residue_encoder = _mlp(residue_nf, 2 * residue_nf, joint_nf, act=act_fn)
+        self.residue_decoder = _mlp(joint_nf, 2 * residue_nf, residue_nf, act=act_fn)
+        self.edge_embedding = nn.Embedding(3, self.edge_nf) if self.edge_nf is not None else None
+        self.edge_nf = 0 if self.edge_nf is None else self.edge_nf
+
+        dynamics_node_nf = joint_nf + 1
+        self.egnn = _EGNNParams(dynamics_node_nf, self.edge_nf, hidden_nf, act_fn, n_layers,
+                                inv_sublayers, attention, reflection_equivariant)
+        self.node_nf = dynamics_node_nf
+        self.update_pocket_coords = update_pocket_coords
+
+        self.device = device
+        self.n_dims = n_dims
+        self.condition_time = condition_time
+
+        self._hp = dict(atom_nf=atom_nf, residue_nf=residue_nf, joint_nf=joint_nf,
+                        hidden_nf=hidden_nf, n_layers=n_layers, inv_sublayers=inv_sublayers,
+                        attention=attention, tanh=tanh, update_pocket_coords=update_pocket_coords,
+                        reflection_equivariant=reflection_equivariant,
+                        edge_embedding_dim=edge_embedding_dim,
+                        edge_cutoff_ligand=edge_cutoff_ligand, edge_cutoff_pocket=edge_cutoff_pocket,
+                        edge_cutoff_interaction=edge_cutoff_interaction,
+                        norm_constant=norm_constant, normalization_factor=normalization_factor,
+                        coords_range=15.0)   # egnn_new.py:190,218: the un-divided range reaches the layer
+        self._engine = None
+        self._cap_key = None
+        self._cap_val = 0
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_engine())
+        self.to(device)
+
+    # ---- engine management -------------------------------------------------
+    def invalidate_engine(self):
+        """Call after changing parameters in place (load_state_dict and .to()
+        do it automatically): the packed kernel weights are rebuilt lazily."""
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._engine = None
+        return out
+
+    def engine(self) -> HipEngine:
+        p = self.egnn.embedding.weight
+        if self._engine is None or self._engine.device != p.device:
+            if p.device.type != 'cuda':
+                raise _lib.HipLibraryError(
+                    "EGNNDynamics runs on the HIP kernels only: move the module to a GPU "
+                    f"(parameters are on {p.device}); there is no CPU fallback")
+            self._engine = HipEngine(make_config(**self._hp), self.state_dict(), p.device)
+        return self._engine
+
+    def _edge_cap(self, mask_atoms, mask_residues, batch):
+        key = (mask_atoms.data_ptr(), mask_residues.data_ptr(), mask_atoms.numel(),
+               mask_residues.numel(), batch)
+        if key != self._cap_key:
+            self._cap_val = edge_capacity(mask_atoms, mask_residues, batch)
+            self._cap_key = key
+        return self._cap_val
+
+    # ---- the reference API -------------------------------------------------
+    @torch.no_grad()
+    def forward(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues):
+        """dynamics.py:87-167.  Inputs are not modified.  Raises ValueError on NaN
+        in the predicted velocity (eval-mode behaviour of the reference)."""
+        eps_l, eps_p, status = self.forward_async(xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+        st = int(status.item())
+        if st & _lib.STATUS_EDGE_OVERFLOW:
+            raise RuntimeError("edge capacity overflow in EGNNDynamics.forward")
+        if st & _lib.STATUS_NAN:
+            raise ValueError("NaN detected in EGNN output")
+        return eps_l, eps_p
+
+    @torch.no_grad()
+    def forward_async(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues, edges=None,
+                      status=None, want_pocket=True, eps_lig=None, batch=None):
+        """Same as forward() but without the host sync: returns
+        (eps_atoms, eps_residues, status) where `status` is an int32 device
+        word (bit 0: NaN, bit 1: edge overflow).  `edges` ([2,E]) teacher-forces
+        the edge list (parity tests)."""
+        eng = self.engine()
+        dev = eng.device
+        xh_atoms = xh_atoms.to(device=dev, dtype=torch.float32).contiguous()
+        xh_residues = xh_residues.to(device=dev, dtype=torch.float32).contiguous()
+        t = t.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+        mask_atoms = mask_atoms.to(device=dev, dtype=torch.int64).contiguous()
+        mask_residues = mask_residues.to(device=dev, dtype=torch.int64).contiguous()
+        if batch is None:
+            if t.numel() > 1:
+                batch = t.numel()
+            else:   # dynamics.py:105-107: a single t for the whole batch
+                batch = int(max(int(mask_atoms.max()) if mask_atoms.numel() else 0,
+                                int(mask_residues.max()) if mask_residues.numel() else 0)) + 1
+        cap = self._edge_cap(mask_atoms, mask_residues, batch) if edges is None else 0
+        return eng.forward_async(xh_atoms, xh_residues, t, mask_atoms, mask_residues, batch, cap,
+                                 ext_edges=edges, status=status, want_pocket=want_pocket,
+                                 eps_lig=eps_lig)
+
+    @torch.no_grad()
+    def get_edges(self, batch_mask_ligand, batch_mask_pocket, x_ligand, x_pocket):
+        """dynamics.py:169-187 on the GPU radius-graph kernel: int64 [2,E]
+        sorted by (row, col), self loops kept."""
+        eng = self.engine()
+        dev = eng.device
+        ml = batch_mask_ligand.to(device=dev, dtype=torch.int64).contiguous()
+        mp = batch_mask_pocket.to(device=dev, dtype=torch.int64).contiguous()
+        x = torch.cat((x_ligand, x_pocket), 0).to(device=dev, dtype=torch.float32).contiguous()
+        n_l, n_p = ml.numel(), mp.numel()
+        N = n_l + n_p
+        batch = int(max(int(ml.max()) if n_l else 0, int(mp.max()) if n_p else 0)) + 1
+        cap = max(edge_capacity(ml, mp, batch), 1)
+        i32 = dict(dtype=torch.int32, device=dev)
+        node_batch = torch.empty(N, **i32)
+        lig_off, poc_off = torch.empty(batch + 1, **i32), torch.empty(batch + 1, **i32)
+        deg, row_ptr = torch.empty(N, **i32), torch.empty(N + 1, **i32)
+        erow, ecol = torch.empty(cap, **i32), torch.empty(cap, **i32)
+        ed0 = torch.empty(cap, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, **i32)
+        _lib.check(eng.lib.dsbdd_build_edges(
+            torch.cuda.current_stream(dev).cuda_stream, x.data_ptr(), ml.data_ptr(), mp.data_ptr(),
+            n_l, n_p, batch, eng.cfg, node_batch.data_ptr(), lig_off.data_ptr(), poc_off.data_ptr(),
+            deg.data_ptr(), row_ptr.data_ptr(), erow.data_ptr(), ecol.data_ptr(), ed0.data_ptr(),
+            cap, status.data_ptr()), "dsbdd_build_edges")
+        E = int(row_ptr[-1].item())
+        return torch.stack((erow[:E].long(), ecol[:E].long()), 0)

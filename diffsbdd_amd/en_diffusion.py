@@ -1,0 +1,613 @@
+"""`EnVariationalDiffusion` -- drop-in for the *sampling* API of
+/root/reference/equivariant_diffusion/en_diffusion.py:13-955 (joint ligand+pocket
+diffusion): `sample`, `inpaint`, `sample_p_zs_given_zt`, `sample_p_zt_given_zs`,
+`sample_p_xh_given_z0`, the predefined noise schedule and the helpers callers
+use (`normalize`, `unnormalize`, `size_distribution`, `norm_values`, `T`, ...).
+
+Per reverse step the work is: one `EGNNDynamics.forward_async` (HIP kernels)
++ one fused posterior-update kernel (`dsbdd_joint_reverse_update`) + the noise
+draw; nothing in the loop synchronises with the host (the reference has >= 10
+syncs per step).  The COM / NaN invariants the reference asserts
+with `.item()` every step are checked once at the end of the chain from device
+flags.
+
+Out of scope: the training loss (`forward`, `kl_prior*`,
+`log_pxh_given_z0_without_constants`, the learned `GammaNetwork`).  They raise
+NotImplementedError here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+__all__ = ["EnVariationalDiffusion", "DistributionNodes", "PredefinedNoiseSchedule",
+           "num_nodes_to_batch_mask"]
+
+
+# ---------------------------------------------------------------------------
+# small host-side helpers (torch as plumbing; none of this is per-step hot)
+# ---------------------------------------------------------------------------
+def num_nodes_to_batch_mask(n_samples, num_nodes, device):
+    """utils.num_nodes_to_batch_mask (/root/reference/utils.py:146-154)."""
+    assert isinstance(num_nodes, int) or len(num_nodes) == n_samples
+    if isinstance(num_nodes, torch.Tensor):
+        num_nodes = num_nodes.to(device)
+    return torch.repeat_interleave(torch.arange(n_samples, device=device), num_nodes)
+
+
+def seg_sum(src, index, n):
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    return out.index_add_(0, index, src)
+
+
+def seg_mean(src, index, n):
+    """torch_scatter.scatter_mean semantics (count clamped to >= 1)."""
+    s = seg_sum(src, index, n)
+    cnt = torch.zeros(n, dtype=src.dtype, device=src.device)
+    cnt.index_add_(0, index, torch.ones(index.shape[0], dtype=src.dtype, device=src.device))
+    return s / cnt.clamp(min=1).view((-1,) + (1,) * (s.dim() - 1))
+
+
+# ---------------------------------------------------------------------------
+# noise schedule (en_diffusion.py:1105-1190)
+# ---------------------------------------------------------------------------
+def _clip_noise_schedule(alphas2, clip_value=0.001):
+    alphas2 = np.concatenate([np.ones(1), alphas2], axis=0)
+    steps = np.clip(alphas2[1:] / alphas2[:-1], a_min=clip_value, a_max=1.0)
+    return np.cumprod(steps, axis=0)
+
+
+def _polynomial_alphas2(timesteps, s, power):
+    n = timesteps + 1
+    x = np.linspace(0, n, n)
+    a2 = _clip_noise_schedule((1 - np.power(x / n, power)) ** 2, clip_value=0.001)
+    return (1 - 2 * s) * a2 + s
+
+
+def _cosine_alphas2(timesteps, s=0.008):
+    n = timesteps + 2
+    x = np.linspace(0, n, n)
+    ac = np.cos(((x / n) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
+    return np.cumprod(1.0 - betas, axis=0)
+
+
+class PredefinedNoiseSchedule(nn.Module):
+    """Lookup table gamma[0..T] = -(log alpha^2 - log sigma^2), built in fp64
+    numpy and stored as an fp32 Parameter named `gamma` (state_dict key
+    `gamma.gamma`), en_diffusion.py:1158-1190."""
+
+    def __init__(self, noise_schedule, timesteps, precision):
+        super().__init__()
+        self.timesteps = timesteps
+        if noise_schedule == 'cosine':
+            alphas2 = _cosine_alphas2(timesteps)
+        elif 'polynomial' in noise_schedule:
+            parts = noise_schedule.split('_')
+            assert len(parts) == 2
+            alphas2 = _polynomial_alphas2(timesteps, s=precision, power=float(parts[1]))
+        else:
+            raise ValueError(noise_schedule)
+        sigmas2 = 1 - alphas2
+        table = -(np.log(alphas2) - np.log(sigmas2))
+        self.gamma = nn.Parameter(torch.from_numpy(table).float(), requires_grad=False)
+
+    def forward(self, t):
+        return self.gamma[torch.round(t * self.timesteps).long()]
+
+
+class DistributionNodes:
+    """Joint categorical over (n_ligand_nodes, n_pocket_nodes) from a 2-D
+    histogram; host side, once per batch (en_diffusion.py:958-1028)."""
+
+    def __init__(self, histogram):
+        hist = torch.as_tensor(np.asarray(histogram)).float() + 1e-3
+        self.prob = hist / hist.sum()
+        n1, n2 = self.prob.shape
+        self.idx_to_n_nodes = torch.stack(torch.meshgrid(
+            torch.arange(n1), torch.arange(n2), indexing='ij'), -1).view(-1, 2)
+        self.n_nodes_to_idx = {(int(a), int(b)): i for i, (a, b) in enumerate(self.idx_to_n_nodes.tolist())}
+        self.m = torch.distributions.Categorical(self.prob.view(-1), validate_args=True)
+        self.n1_given_n2 = [torch.distributions.Categorical(self.prob[:, j], validate_args=True)
+                            for j in range(n2)]
+        self.n2_given_n1 = [torch.distributions.Categorical(self.prob[i, :], validate_args=True)
+                            for i in range(n1)]
+
+    def sample(self, n_samples=1):
+        idx = self.m.sample((n_samples,))
+        nl, npk = self.idx_to_n_nodes[idx].T
+        return nl, npk
+
+    def sample_conditional(self, n1=None, n2=None):
+        assert (n1 is None) ^ (n2 is None), "Exactly one input argument must be None"
+        dists = self.n1_given_n2 if n2 is not None else self.n2_given_n1
+        c = n2 if n2 is not None else n1
+        return torch.tensor([dists[int(i)].sample() for i in c], device=c.device)
+
+    def log_prob(self, batch_n_nodes_1, batch_n_nodes_2):
+        assert batch_n_nodes_1.dim() == 1 and batch_n_nodes_2.dim() == 1
+        idx = torch.tensor([self.n_nodes_to_idx[(a, b)] for a, b in
+                            zip(batch_n_nodes_1.tolist(), batch_n_nodes_2.tolist())])
+        return self.m.log_prob(idx).to(batch_n_nodes_1.device)
+
+    def log_prob_n1_given_n2(self, n1, n2):
+        assert n1.dim() == 1 and n2.dim() == 1
+        return torch.stack([self.n1_given_n2[int(c)].log_prob(i.cpu())
+                            for i, c in zip(n1, n2)]).to(n1.device)
+
+    def log_prob_n2_given_n1(self, n2, n1):
+        assert n1.dim() == 1 and n2.dim() == 1
+        return torch.stack([self.n2_given_n1[int(c)].log_prob(i.cpu())
+                            for i, c in zip(n2, n1)]).to(n2.device)
+
+
+# ---------------------------------------------------------------------------
+class StepCoefficients:
+    """Per-step scalars of the reverse process, computed once per chain on the
+    host with the same fp32 torch formulas the reference evaluates per step on
+    [B,1] tensors (en_diffusion.py:83-107,865-873; conditional_model.py:435-456):
+
+        alpha_ts[s], c_eps[s] = sigma2_ts / alpha_ts / sigma_t, sigma[s] = sigma_ts sigma_s / sigma_t
+        and t_value[s] = (s+1)/timesteps as the reference's int-tensor division gives it.
+    """
+
+    def __init__(self, gamma_table, T, timesteps):
+        g = gamma_table.detach().float().cpu()
+        idx = torch.arange(0, timesteps + 1, dtype=torch.int64)
+        tv = idx / timesteps                                    # float32, as s_array / timesteps
+        gam = g[torch.round(tv * T).long()]
+        g_s, g_t = gam[:-1], gam[1:]
+        sigma2 = -torch.expm1(F.softplus(g_s) - F.softplus(g_t))
+        alpha_ts = torch.exp(0.5 * (F.logsigmoid(-g_t) - F.logsigmoid(-g_s)))
+        sigma_ts = torch.sqrt(sigma2)
+        sig_s, sig_t = torch.sqrt(torch.sigmoid(g_s)), torch.sqrt(torch.sigmoid(g_t))
+        self.t_value = tv                                       # [timesteps+1]
+        self.gamma = gam
+        self.alpha_ts = alpha_ts
+        self.sigma_ts = sigma_ts
+        self.c_eps = sigma2 / alpha_ts / sig_t
+        self.sigma = sigma_ts * sig_s / sig_t
+        self.alpha = torch.sqrt(torch.sigmoid(-gam))            # alpha_t per index
+        self.sigma_t = torch.sqrt(torch.sigmoid(gam))
+
+
+class EnVariationalDiffusion(nn.Module):
+    """The E(n) diffusion module (joint ligand + pocket)."""
+
+    def __init__(
+            self,
+            dynamics: nn.Module, atom_nf: int, residue_nf: int,
+            n_dims: int, size_histogram: Dict,
+            timesteps: int = 1000, parametrization='eps',
+            noise_schedule='learned', noise_precision=1e-4,
+            loss_type='vlb', norm_values=(1., 1.), norm_biases=(None, 0.),
+            virtual_node_idx=None):
+        super().__init__()
+        assert loss_type in {'vlb', 'l2'}
+        assert parametrization == 'eps'
+        self.loss_type = loss_type
+        if noise_schedule == 'learned':
+            raise NotImplementedError(
+                "noise_schedule='learned' (GammaNetwork) is a training-time feature and is not "
+                "part of the MI355X sampling path; the shipped configs use 'polynomial_2'")
+        self.gamma = PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps,
+                                             precision=noise_precision)
+        self.dynamics = dynamics
+        self.atom_nf = atom_nf
+        self.residue_nf = residue_nf
+        self.n_dims = n_dims
+        self.num_classes = self.atom_nf
+        self.T = timesteps
+        self.parametrization = parametrization
+        self.norm_values = norm_values
+        self.norm_biases = norm_biases
+        self.register_buffer('buffer', torch.zeros(1))
+        self.size_distribution = DistributionNodes(size_histogram)
+        self.vnode_idx = virtual_node_idx
+        self.check_issues_norm_values()
+        # noise: None -> sharding-invariant keyed Philox on the GPU; a callable
+        # (shape) -> tensor injects external noise (parity tests)
+        self.noise_source = None
+        self._seed = 0
+        self._sample_offset = 0
+        self._draw = 0
+        self._coef_cache = {}
+
+    # ---- noise -----------------------------------------------------------------
+    def set_noise_source(self, fn):
+        self.noise_source = fn
+
+    def seed(self, seed, sample_offset=0):
+        """Seed the keyed generator.  `sample_offset` = global index of this
+        shard's first sample, so a chain's noise is independent of sharding."""
+        self._seed, self._sample_offset, self._draw = int(seed), int(sample_offset), 0
+
+    def _randn(self, mask, n_cols, batch, stream_id=0):
+        n = mask.numel()
+        if self.noise_source is not None:
+            return self.noise_source((n, n_cols)).to(device=mask.device, dtype=torch.float32).contiguous()
+        out = torch.empty((n, n_cols), dtype=torch.float32, device=mask.device)
+        lib = _lib.load()
+        _lib.check(lib.dsbdd_randn_keyed(
+            torch.cuda.current_stream(mask.device).cuda_stream, out.data_ptr(), mask.data_ptr(), n,
+            n_cols, batch, self._sample_offset, C.c_uint64(self._seed & (2 ** 64 - 1)),
+            C.c_uint64(self._draw), stream_id), "dsbdd_randn_keyed")
+        self._draw += 1
+        return out
+
+    @staticmethod
+    def sample_gaussian(size, device):
+        return torch.randn(size, device=device)
+
+    # ---- schedule helpers (same names as the reference) --------------------------
+    def check_issues_norm_values(self, num_stdevs=8):
+        gamma_0 = self.gamma(torch.zeros((1, 1)))
+        sigma_0 = self.sigma(gamma_0, target_tensor=torch.zeros((1, 1))).item()
+        norm_value = self.norm_values[1]
+        if sigma_0 * num_stdevs > 1. / norm_value:
+            raise ValueError(
+                f'Value for normalization value {norm_value} probably too large with sigma_0 '
+                f'{sigma_0:.5f} and 1 / norm_value = {1. / norm_value}')
+
+    @staticmethod
+    def inflate_batch_array(array, target):
+        return array.view((array.size(0),) + (1,) * (len(target.size()) - 1))
+
+    def sigma(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(gamma)), target_tensor)
+
+    def alpha(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(-gamma)), target_tensor)
+
+    @staticmethod
+    def SNR(gamma):
+        return torch.exp(-gamma)
+
+    def sigma_and_alpha_t_given_s(self, gamma_t, gamma_s, target_tensor):
+        sigma2 = self.inflate_batch_array(
+            -torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t)), target_tensor)
+        alpha_ts = self.inflate_batch_array(
+            torch.exp(0.5 * (F.logsigmoid(-gamma_t) - F.logsigmoid(-gamma_s))), target_tensor)
+        return sigma2, torch.sqrt(sigma2), alpha_ts
+
+    def subspace_dimensionality(self, input_size):
+        return (input_size - 1) * self.n_dims
+
+    def _coefs(self, timesteps) -> StepCoefficients:
+        key = (timesteps, self.gamma.gamma.data_ptr(), self.gamma.gamma._version)
+        if key not in self._coef_cache:
+            self._coef_cache = {key: StepCoefficients(self.gamma.gamma, self.T, timesteps)}
+        return self._coef_cache[key]
+
+    # ---- normalisation (en_diffusion.py:880-912; in place on the dicts) ---------
+    def normalize(self, ligand=None, pocket=None):
+        for d in (ligand, pocket):
+            if d is not None:
+                d['x'] = d['x'] / self.norm_values[0]
+                d['one_hot'] = (d['one_hot'].float() - self.norm_biases[1]) / self.norm_values[1]
+        return ligand, pocket
+
+    def unnormalize(self, x, h_cat):
+        return x * self.norm_values[0], h_cat * self.norm_values[1] + self.norm_biases[1]
+
+    def unnormalize_z(self, z_lig, z_pocket):
+        nd = self.n_dims
+        x_l, h_l = self.unnormalize(z_lig[:, :nd], z_lig[:, nd:])
+        x_p, h_p = self.unnormalize(z_pocket[:, :nd], z_pocket[:, nd:])
+        return torch.cat([x_l, h_l], dim=1), torch.cat([x_p, h_p], dim=1)
+
+    @staticmethod
+    def remove_mean_batch(x, indices):
+        n = int(indices.max()) + 1 if indices.numel() else 0
+        return x - seg_mean(x, indices, n)[indices]
+
+    @staticmethod
+    def assert_mean_zero_with_mask(x, node_mask, eps=1e-10):
+        largest = x.abs().max().item()
+        n = int(node_mask.max()) + 1
+        err = seg_sum(x, node_mask, n).abs().max().item()
+        rel = err / (largest + eps)
+        assert rel < 1e-2, f'Mean is not zero, relative_error {rel}'
+
+    @staticmethod
+    def sample_center_gravity_zero_gaussian_batch(size, lig_indices, pocket_indices):
+        assert len(size) == 2
+        x = torch.randn(size, device=lig_indices.device)
+        return EnVariationalDiffusion.remove_mean_batch(x, torch.cat((lig_indices, pocket_indices)))
+
+    # ---- training-only API: out of scope ------------------------------------------
+    def forward(self, ligand, pocket, return_info=False):
+        raise NotImplementedError(
+            "the training loss (en_diffusion.py:336-469) is outside the MI355X sampling hot path "
+            "(SURVEY.md §2 row 3)")
+
+    # ---- dynamics call ---------------------------------------------------------------
+    def _check_status(self, status):
+        st = int(status.item())
+        if st & _lib.STATUS_EDGE_OVERFLOW:
+            raise RuntimeError("edge capacity overflow in the EGNN kernels")
+        if st & _lib.STATUS_NAN:
+            raise ValueError("NaN detected in EGNN output")
+
+    def _dyn(self, z_lig, z_pocket, t_value, lig_mask, pocket_mask, batch, status, want_pocket):
+        t = torch.full((batch,), float(t_value), dtype=torch.float32, device=z_lig.device)
+        return self.dynamics.forward_async(z_lig, z_pocket, t, lig_mask, pocket_mask, status=status,
+                                           want_pocket=want_pocket, batch=batch)
+
+    # ---- joint noise (en_diffusion.py:559-578) ------------------------------------------
+    def sample_combined_position_feature_noise(self, lig_indices, pocket_indices):
+        batch = int(max(lig_indices.max(), pocket_indices.max())) + 1
+        return self._joint_noise(lig_indices, pocket_indices, batch)
+
+    def _joint_noise(self, lig_mask, pocket_mask, batch):
+        nl = lig_mask.numel()
+        comb = torch.cat((lig_mask, pocket_mask))
+        if self.noise_source is not None:
+            zx = self._randn(comb, self.n_dims, batch)
+        else:
+            zx = torch.cat((self._randn(lig_mask, self.n_dims, batch, stream_id=1),
+                            self._randn(pocket_mask, self.n_dims, batch, stream_id=2)))
+        zx = zx - seg_mean(zx, comb, batch)[comb]
+        zh_l = self._randn(lig_mask, self.atom_nf, batch, stream_id=3)
+        zh_p = self._randn(pocket_mask, self.residue_nf, batch, stream_id=4)
+        return torch.cat([zx[:nl], zh_l], dim=1), torch.cat([zx[nl:], zh_p], dim=1)
+
+    # ---- one reverse step, joint model (en_diffusion.py:503-557) ---------------------------
+    def _joint_step(self, s, co, z_lig, z_pocket, lig_mask, pocket_mask, batch, status):
+        """In place: z_* at level s+1 -> level s."""
+        eps_l, eps_p, _ = self._dyn(z_lig, z_pocket, co.t_value[s + 1], lig_mask, pocket_mask, batch,
+                                    status, True)
+        n_l, n_p = self._joint_noise(lig_mask, pocket_mask, batch)
+        lib = _lib.load()
+        _lib.check(lib.dsbdd_joint_reverse_update(
+            torch.cuda.current_stream(z_lig.device).cuda_stream, z_lig.data_ptr(), z_pocket.data_ptr(),
+            eps_l.data_ptr(), eps_p.data_ptr(), n_l.data_ptr(), n_p.data_ptr(), lig_mask.data_ptr(),
+            pocket_mask.data_ptr(), lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf,
+            self.residue_nf, float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s])),
+            "dsbdd_joint_reverse_update")
+
+    def sample_p_zs_given_zt(self, s, t, zt_lig, zt_pocket, ligand_mask, pocket_mask, fix_noise=False):
+        """Functional form with the reference's signature: s, t are [B,1]
+        tensors (all entries equal, as every caller passes them)."""
+        if fix_noise:
+            raise NotImplementedError("fix_noise option isn't implemented yet")
+        batch = s.shape[0]
+        timesteps, s_int = self._infer_step(s, t)
+        co = self._coefs(timesteps)
+        z_l, z_p = zt_lig.clone().contiguous(), zt_pocket.clone().contiguous()
+        status = torch.zeros(1, dtype=torch.int32, device=z_l.device)
+        self._step_impl(s_int, co, z_l, z_p, ligand_mask, pocket_mask, batch, status)
+        self._check_status(status)
+        return z_l, z_p
+
+    def _step_impl(self, s_int, co, z_l, z_p, lig_mask, pocket_mask, batch, status):
+        self._joint_step(s_int, co, z_l, z_p, lig_mask, pocket_mask, batch, status)
+
+    def _infer_step(self, s, t):
+        """Recover (timesteps, s) from the [B,1] float tensors s = s_int/timesteps,
+        t = (s_int+1)/timesteps the reference API passes."""
+        s0, t0 = float(s.reshape(-1)[0]), float(t.reshape(-1)[0])
+        timesteps = int(round(1.0 / (t0 - s0)))
+        return timesteps, int(round(s0 * timesteps))
+
+    # ---- q(z_t | z_s) and q(z_t | x) (en_diffusion.py:479-501, 302-317) ----------------------
+    def sample_p_zt_given_zs(self, zs_lig, zs_pocket, ligand_mask, pocket_mask, gamma_t, gamma_s,
+                             fix_noise=False):
+        if fix_noise:
+            raise NotImplementedError("fix_noise option isn't implemented yet")
+        batch = gamma_t.shape[0]
+        _, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, zs_lig)
+        n_l, n_p = self._joint_noise(ligand_mask, pocket_mask, batch)
+        zt_l = alpha_ts[ligand_mask] * zs_lig + sigma_ts[ligand_mask] * n_l
+        zt_p = alpha_ts[pocket_mask] * zs_pocket + sigma_ts[pocket_mask] * n_p
+        return self._remove_joint_com(zt_l, zt_p, ligand_mask, pocket_mask, batch)
+
+    def _remove_joint_com(self, z_l, z_p, lig_mask, pocket_mask, batch):
+        nd, nl = self.n_dims, lig_mask.numel()
+        comb = torch.cat((lig_mask, pocket_mask))
+        zx = torch.cat((z_l[:, :nd], z_p[:, :nd]), dim=0)
+        zx = zx - seg_mean(zx, comb, batch)[comb]
+        return torch.cat((zx[:nl], z_l[:, nd:]), dim=1), torch.cat((zx[nl:], z_p[:, nd:]), dim=1)
+
+    def noised_representation(self, xh_lig, xh_pocket, lig_mask, pocket_mask, gamma_t):
+        batch = gamma_t.shape[0]
+        alpha_t, sigma_t = self.alpha(gamma_t, xh_lig), self.sigma(gamma_t, xh_lig)
+        eps_l, eps_p = self._joint_noise(lig_mask, pocket_mask, batch)
+        z_l = alpha_t[lig_mask] * xh_lig + sigma_t[lig_mask] * eps_l
+        z_p = alpha_t[pocket_mask] * xh_pocket + sigma_t[pocket_mask] * eps_p
+        return z_l, z_p, eps_l, eps_p
+
+    # ---- p(x, h | z_0) (en_diffusion.py:263-288, 157-169) ------------------------------------------
+    def compute_x_pred(self, net_out, zt, gamma_t, batch_mask):
+        sigma_t = self.sigma(gamma_t, target_tensor=net_out)
+        alpha_t = self.alpha(gamma_t, target_tensor=net_out)
+        return 1. / alpha_t[batch_mask] * (zt - sigma_t[batch_mask] * net_out)
+
+    def sample_p_xh_given_z0(self, z0_lig, z0_pocket, lig_mask, pocket_mask, batch_size, fix_noise=False):
+        if fix_noise:
+            raise NotImplementedError("fix_noise option isn't implemented yet")
+        dev = z0_lig.device
+        t0 = torch.zeros((batch_size, 1), device=dev)
+        gamma_0 = self.gamma(t0)
+        sigma_x = self.SNR(-0.5 * gamma_0)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        e_l, e_p, _ = self._dyn(z0_lig.contiguous(), z0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
+                                batch_size, status, True)
+        self._check_status(status)
+        mu_l = self.compute_x_pred(e_l, z0_lig, gamma_0, lig_mask)
+        mu_p = self.compute_x_pred(e_p, z0_pocket, gamma_0, pocket_mask)
+        n_l, n_p = self._joint_noise(lig_mask, pocket_mask, batch_size)
+        xh_l = mu_l + sigma_x[lig_mask] * n_l
+        xh_p = mu_p + sigma_x[pocket_mask] * n_p
+        nd = self.n_dims
+        x_l, h_l = self.unnormalize(xh_l[:, :nd], z0_lig[:, nd:])
+        x_p, h_p = self.unnormalize(xh_p[:, :nd], z0_pocket[:, nd:])
+        h_l = F.one_hot(torch.argmax(h_l, dim=1), self.atom_nf)
+        h_p = F.one_hot(torch.argmax(h_p, dim=1), self.residue_nf)
+        return x_l, h_l, x_p, h_p
+
+    def _finish_joint(self, z_l, z_p, lig_mask, pocket_mask, n, return_frames, out_lig, out_pocket):
+        x_l, h_l, x_p, h_p = self.sample_p_xh_given_z0(z_l, z_p, lig_mask, pocket_mask, n)
+        comb = torch.cat((lig_mask, pocket_mask))
+        self.assert_mean_zero_with_mask(torch.cat((x_l, x_p), dim=0), comb)
+        if return_frames == 1:                                         # en_diffusion.py:636-644
+            x = torch.cat((x_l, x_p))
+            max_cog = seg_sum(x, comb, n).abs().max().item()
+            if max_cog > 5e-2:
+                print(f'Warning CoG drift with error {max_cog:.3f}. Projecting the positions down.')
+                x = self.remove_mean_batch(x, comb)
+                x_l, x_p = x[:len(x_l)], x[len(x_l):]
+        out_lig[0] = torch.cat([x_l, h_l], dim=1)
+        out_pocket[0] = torch.cat([x_p, h_p], dim=1)
+        return out_lig.squeeze(0), out_pocket.squeeze(0), lig_mask, pocket_mask
+
+    # ---- sampling (en_diffusion.py:580-651) --------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, n_samples, num_nodes_lig, num_nodes_pocket, return_frames=1, timesteps=None,
+               device='cpu'):
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps
+        assert timesteps % return_frames == 0
+        device = self._hip_device(device)
+        lig_mask = num_nodes_to_batch_mask(n_samples, num_nodes_lig, device).contiguous()
+        pocket_mask = num_nodes_to_batch_mask(n_samples, num_nodes_pocket, device).contiguous()
+        co = self._coefs(timesteps)
+        z_l, z_p = self._joint_noise(lig_mask, pocket_mask, n_samples)
+        z_l, z_p = z_l.contiguous(), z_p.contiguous()
+        out_lig = torch.zeros((return_frames,) + z_l.size(), device=device)
+        out_pocket = torch.zeros((return_frames,) + z_p.size(), device=device)
+        status = torch.zeros(1, dtype=torch.int32, device=device)
+        for s in reversed(range(0, timesteps)):
+            self._joint_step(s, co, z_l, z_p, lig_mask, pocket_mask, n_samples, status)
+            if (s * return_frames) % timesteps == 0:
+                idx = (s * return_frames) // timesteps
+                out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_l, z_p)
+        self._check_status(status)
+        return self._finish_joint(z_l, z_p, lig_mask, pocket_mask, n_samples, return_frames,
+                                  out_lig, out_pocket)
+
+    def _hip_device(self, device):
+        """The sampling state lives where the dynamics' parameters live."""
+        p = next(self.dynamics.parameters())
+        if p.device.type != 'cuda':
+            raise _lib.HipLibraryError(
+                "sampling runs on the HIP kernels only: move the model to a GPU "
+                f"(parameters are on {p.device}); there is no CPU fallback")
+        return p.device
+
+    # ---- RePaint (en_diffusion.py:653-837) ------------------------------------------------------------
+    def get_repaint_schedule(self, resamplings, jump_length, timesteps):
+        """Number of denoising steps before each jump back, in execution order."""
+        sched, cur = [], 0
+        while cur < timesteps:
+            step = jump_length if cur + jump_length < timesteps else timesteps - cur
+            last = cur + jump_length >= timesteps
+            if sched:
+                sched[-1] += step
+                if not last:
+                    sched.extend([jump_length] * (resamplings - 1))
+            else:
+                sched.extend([step] * (1 if last else resamplings))
+            cur += step
+        return sched[::-1]
+
+    @torch.no_grad()
+    def inpaint(self, ligand, pocket, lig_fixed, pocket_fixed, resamplings=1, jump_length=1,
+                return_frames=1, timesteps=None):
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps
+        assert timesteps % return_frames == 0
+        assert jump_length == 1 or return_frames == 1, \
+            "Chain visualization is only implemented for jump_length=1"
+        if len(lig_fixed.size()) == 1:
+            lig_fixed = lig_fixed.unsqueeze(1)
+        if len(pocket_fixed.size()) == 1:
+            pocket_fixed = pocket_fixed.unsqueeze(1)
+        ligand, pocket = self.normalize(ligand, pocket)
+        dev = self._hip_device(None)
+        n = len(ligand['size'])
+        nd = self.n_dims
+        lm = ligand['mask'].to(dev).contiguous()
+        pm = pocket['mask'].to(dev).contiguous()
+        lig_fixed, pocket_fixed = lig_fixed.to(dev).float(), pocket_fixed.to(dev).float()
+        lfb, pfb = lig_fixed.bool().view(-1), pocket_fixed.bool().view(-1)
+        comb = torch.cat((lm, pm))
+        known_idx = torch.cat((lm[lfb], pm[pfb]))
+        xh0_l = torch.cat([ligand['x'], ligand['one_hot']], dim=1).to(dev)
+        xh0_p = torch.cat([pocket['x'], pocket['one_hot']], dim=1).to(dev)
+        mean_known = seg_mean(torch.cat((xh0_l[:, :nd][lfb], xh0_p[:, :nd][pfb])), known_idx, n)
+        xh0_l[:, :nd] = xh0_l[:, :nd] - mean_known[lm]
+        xh0_p[:, :nd] = xh0_p[:, :nd] - mean_known[pm]
+
+        co = self._coefs(timesteps)
+        z_l, z_p = self._joint_noise(lm, pm, n)
+        z_l, z_p = z_l.contiguous(), z_p.contiguous()
+        out_lig = torch.zeros((return_frames,) + z_l.size(), device=dev)
+        out_pocket = torch.zeros((return_frames,) + z_p.size(), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        schedule = self.get_repaint_schedule(resamplings, jump_length, timesteps)
+        s = timesteps - 1
+        for i, n_denoise_steps in enumerate(schedule):
+            for j in range(n_denoise_steps):
+                # known part: q(z_s | x) with fresh noise (en_diffusion.py:742-746)
+                a_s, sg_s = co.alpha[s], co.sigma_t[s]
+                eps_l, eps_p = self._joint_noise(lm, pm, n)
+                zk_l = a_s * xh0_l + sg_s * eps_l
+                zk_p = a_s * xh0_p + sg_s * eps_p
+                # unknown part: one reverse step of the current state
+                zu_l, zu_p = z_l.clone(), z_p.clone()
+                self._joint_step(s, co, zu_l, zu_p, lm, pm, n, status)
+                # align COMs of the known nodes (en_diffusion.py:752-772)
+                com_n = seg_mean(torch.cat((zk_l[:, :nd][lfb], zk_p[:, :nd][pfb])), known_idx, n)
+                com_d = seg_mean(torch.cat((zu_l[:, :nd][lfb], zu_p[:, :nd][pfb])), known_idx, n)
+                dx = com_d - com_n
+                zk_l[:, :nd] = zk_l[:, :nd] + dx[lm]
+                zk_p[:, :nd] = zk_p[:, :nd] + dx[pm]
+                z_l = (zk_l * lig_fixed + zu_l * (1 - lig_fixed)).contiguous()
+                z_p = (zk_p * pocket_fixed + zu_p * (1 - pocket_fixed)).contiguous()
+                if n_denoise_steps > jump_length or i == len(schedule) - 1:
+                    if (s * return_frames) % timesteps == 0:
+                        idx = (s * return_frames) // timesteps
+                        out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_l, z_p)
+                if j == n_denoise_steps - 1 and i < len(schedule) - 1:
+                    # jump back jump_length steps: q(z_t | z_s) (en_diffusion.py:793-809)
+                    t = s + jump_length
+                    g_s = co.gamma[s].view(1, 1).expand(n, 1).to(dev)
+                    g_t = co.gamma[t].view(1, 1).expand(n, 1).to(dev)
+                    z_l, z_p = self.sample_p_zt_given_zs(z_l, z_p, lm, pm, g_t, g_s)
+                    z_l, z_p = z_l.contiguous(), z_p.contiguous()
+                    s = t
+                s -= 1
+        self._check_status(status)
+        self.assert_mean_zero_with_mask(torch.cat((z_l[:, :nd], z_p[:, :nd]), dim=0), comb)
+        return self._finish_joint(z_l, z_p, lm, pm, n, return_frames, out_lig, out_pocket)
+
+    # ---- misc API kept for callers -------------------------------------------------------------
+    def xh_given_zt_and_epsilon(self, z_t, epsilon, gamma_t, batch_mask):
+        alpha_t, sigma_t = self.alpha(gamma_t, z_t), self.sigma(gamma_t, z_t)
+        return z_t / alpha_t[batch_mask] - epsilon * sigma_t[batch_mask] / alpha_t[batch_mask]
+
+    def log_pN(self, N_lig, N_pocket):
+        return self.size_distribution.log_prob(N_lig, N_pocket)
+
+    def delta_log_px(self, num_nodes):
+        return -self.subspace_dimensionality(num_nodes) * np.log(self.norm_values[0])
+
+    @staticmethod
+    def sum_except_batch(x, indices):
+        n = int(indices.max()) + 1
+        return seg_sum(x.sum(-1), indices, n)
+
+    @staticmethod
+    def cdf_standard_gaussian(x):
+        return 0.5 * (1. + torch.erf(x / math.sqrt(2)))

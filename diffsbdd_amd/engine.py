@@ -1,0 +1,268 @@
+"""Host-side handle on the HIP engine: packs an EGNNDynamics `state_dict` into
+the kernel weight layout (include/diffsbdd_hip.h "weight slots"), owns the
+device workspace (a torch uint8 tensor, i.e. torch's caching allocator owns the
+memory), and enqueues `dsbdd_dynamics_forward` on torch's current stream.
+
+PyTorch is plumbing here: tensors, streams, allocation.  All arithmetic of the
+hot path runs in libdiffsbdd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _pad4(v):
+    return (v + 3) & ~3
+
+
+def make_config(atom_nf, residue_nf, joint_nf, hidden_nf, n_layers, inv_sublayers, attention,
+                tanh, update_pocket_coords, reflection_equivariant, edge_embedding_dim,
+                edge_cutoff_ligand, edge_cutoff_pocket, edge_cutoff_interaction, norm_constant,
+                normalization_factor, coords_range=15.0):
+    cfg = _lib.Config()
+    cfg.atom_nf, cfg.residue_nf, cfg.joint_nf, cfg.hidden_nf = atom_nf, residue_nf, joint_nf, hidden_nf
+    cfg.n_layers, cfg.inv_sublayers = n_layers, inv_sublayers
+    cfg.attention, cfg.use_tanh = int(bool(attention)), int(bool(tanh))
+    cfg.update_pocket_coords = int(bool(update_pocket_coords))
+    cfg.reflection_equivariant = int(bool(reflection_equivariant))
+    cfg.edge_embedding_dim = int(edge_embedding_dim or 0)
+    for name, v in (("ligand", edge_cutoff_ligand), ("pocket", edge_cutoff_pocket),
+                    ("interaction", edge_cutoff_interaction)):
+        setattr(cfg, "has_cutoff_" + name, int(v is not None))
+        setattr(cfg, "cutoff_" + name, float(v) if v is not None else 0.0)
+    cfg.norm_constant = float(norm_constant)
+    cfg.normalization_factor = float(normalization_factor)
+    cfg.coords_range = float(coords_range)
+    return cfg
+
+
+def pack_weights(sd, cfg, device):
+    """state_dict (reference key names) -> list of device tensors
+    in slot order.  Pure layout work: transposes, splits of the first edge-MLP
+    layer into its row / col / distance / edge-type parts (the exact
+    factorisation of Linear(cat[h_i, h_j, e]), egnn_new.py:15,35,99), padding."""
+    H, J = cfg.hidden_nf, cfg.joint_nf
+    JP = _pad4(J + 1)
+    enf = cfg.edge_embedding_dim
+    f32 = dict(dtype=torch.float32, device=device)
+
+    def g(name):
+        return sd[name].detach().to(**f32)
+
+    def wt(name, rows_to=None, cols_to=None):
+        w = g(name).t().contiguous()              # [in][out]
+        k, n = w.shape
+        rows, cols = (rows_to or k), (cols_to or _pad4(n))
+        out = torch.zeros((rows, cols), **f32)
+        out[:k, :n] = w
+        return out
+
+    def vec(name, to=None):
+        v = g(name).reshape(-1)
+        if to is not None and to != v.numel():
+            out = torch.zeros(to, **f32)
+            out[:v.numel()] = v
+            return out
+        return v.contiguous()
+
+    emb = g("edge_embedding.weight") if enf else None   # [3][enf]
+
+    def first_layer(prefix):
+        """edge MLP layer 0: weight [H][2H + 2 + enf], bias [H]."""
+        w, b = g(prefix + ".weight"), g(prefix + ".bias")
+        row_t = w[:, :H].t()
+        col_t = w[:, H:2 * H].t()
+        wd = w[:, 2 * H].contiguous()
+        wd0 = w[:, 2 * H + 1].contiguous()
+        tab = b.unsqueeze(0).repeat(3, 1)
+        if enf:
+            tab = tab + emb @ w[:, 2 * H + 2:].t()   # [3][enf] @ [enf][H]
+        return row_t, col_t, wd, wd0, tab.contiguous()
+
+    slots = []
+    for nm in ("atom_encoder", "residue_encoder", "atom_decoder", "residue_decoder"):
+        slots += [wt(nm + ".0.weight"), vec(nm + ".0.bias"), wt(nm + ".2.weight"), vec(nm + ".2.bias")]
+    slots += [wt("egnn.embedding.weight", rows_to=JP, cols_to=H), vec("egnn.embedding.bias"),
+              wt("egnn.embedding_out.weight", cols_to=JP), vec("egnn.embedding_out.bias", to=JP)]
+    assert len(slots) == len(_lib.G_NAMES)
+    for i in range(cfg.n_layers):
+        for s in range(cfg.inv_sublayers):
+            p = f"egnn.e_block_{i}.gcl_{s}"
+            row_t, col_t, wd, wd0, tab = first_layer(p + ".edge_mlp.0")
+            blk = [torch.cat([row_t, col_t], 1).contiguous(), wd, wd0, tab,
+                   wt(p + ".edge_mlp.2.weight"), vec(p + ".edge_mlp.2.bias")]
+            if cfg.attention:
+                blk += [vec(p + ".att_mlp.0.weight"), vec(p + ".att_mlp.0.bias")]
+            else:
+                blk += [None, None]
+            blk += [wt(p + ".node_mlp.0.weight"), vec(p + ".node_mlp.0.bias"),
+                    wt(p + ".node_mlp.2.weight"), vec(p + ".node_mlp.2.bias")]
+            assert len(blk) == len(_lib.GCL_NAMES)
+            slots += blk
+        p = f"egnn.e_block_{i}.gcl_equiv"
+        c_row, c_col, c_wd, c_wd0, c_tab = first_layer(p + ".coord_mlp.0")
+        if cfg.reflection_equivariant:
+            eq = [torch.cat([c_row, c_col], 1).contiguous(), c_wd, c_wd0, c_tab,
+                  wt(p + ".coord_mlp.2.weight"), vec(p + ".coord_mlp.2.bias"),
+                  None, None, None, None, None]
+        else:
+            x_row, x_col, x_wd, x_wd0, x_tab = first_layer(p + ".cross_product_mlp.0")
+            eq = [torch.cat([c_row, c_col, x_row, x_col], 1).contiguous(), c_wd, c_wd0, c_tab,
+                  wt(p + ".coord_mlp.2.weight"), vec(p + ".coord_mlp.2.bias"),
+                  x_wd, x_wd0, x_tab,
+                  wt(p + ".cross_product_mlp.2.weight"), vec(p + ".cross_product_mlp.2.bias")]
+        eq.append(vec(p + ".coord_mlp.4.weight"))
+        assert len(eq) == len(_lib.EQ_NAMES)
+        slots += eq
+    return slots
+
+
+def edge_capacity(mask_lig, mask_pocket, batch):
+    """Upper bound on the number of directed edges incl. self loops: the
+    complete graph inside every sample (dynamics.py:170-172).  One host sync;
+    callers cache it per chain."""
+    nl = torch.bincount(mask_lig, minlength=batch)
+    np_ = torch.bincount(mask_pocket, minlength=batch)
+    n = (nl + np_).to(torch.int64)
+    return int((n * n).sum().item())
+
+
+class HipEngine:
+    """One dsbdd_engine + its weights and workspace on one GPU."""
+
+    def __init__(self, cfg, state_dict, device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HipLibraryError(
+                "the HIP engine needs a GPU device (got %s); there is no CPU fallback" % device)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self.lib.dsbdd_engine_create(C.byref(cfg), C.byref(h)), "dsbdd_engine_create")
+        self.handle = h
+        self.workspace = None
+        self.caps = (0, 0, 0, 0)
+        self._trace = None
+        self.set_weights(state_dict)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.dsbdd_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def set_weights(self, state_dict):
+        self.slots = pack_weights(state_dict, self.cfg, self.device)
+        n = self.lib.dsbdd_engine_weight_slots(self.handle)
+        assert n == len(self.slots), (n, len(self.slots))
+        arr = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in self.slots])
+        _lib.check(self.lib.dsbdd_engine_set_weights(self.handle, arr, n), "dsbdd_engine_set_weights")
+
+    def ensure_workspace(self, n_lig, n_pocket, batch, edge_cap):
+        c = self.caps
+        if n_lig <= c[0] and n_pocket <= c[1] and batch <= c[2] and edge_cap <= c[3]:
+            return
+        caps = (max(n_lig, c[0]), max(n_pocket, c[1]), max(batch, c[2]), max(edge_cap, c[3], 1))
+        nbytes = self.lib.dsbdd_engine_workspace_bytes(self.handle, *caps)
+        if nbytes == 0:
+            raise _lib.HipLibraryError("dsbdd_engine_workspace_bytes rejected the sizes %r" % (caps,))
+        torch.cuda.synchronize(self.device)   # the old workspace may still be in use
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self.workspace.data_ptr() + 255) & ~255
+        _lib.check(self.lib.dsbdd_engine_bind_workspace(self.handle, base, nbytes, *caps),
+                   "dsbdd_engine_bind_workspace")
+        self.caps = caps
+
+    def set_trace(self, n_nodes):
+        """Allocate per-block trace buffers (debug / parity tests)."""
+        L, H = self.cfg.n_layers, self.cfg.hidden_nf
+        th = torch.zeros((L, n_nodes, H), dtype=torch.float32, device=self.device)
+        tx = torch.zeros((L, n_nodes, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dsbdd_engine_set_trace(self.handle, th.data_ptr(), tx.data_ptr()))
+        self._trace = (th, tx)
+        return th, tx
+
+    def clear_trace(self):
+        _lib.check(self.lib.dsbdd_engine_set_trace(self.handle, None, None))
+        self._trace = None
+
+    def forward_async(self, xh_lig, xh_pocket, t, mask_lig, mask_pocket, batch, edge_cap,
+                      ext_edges=None, eps_lig=None, eps_pocket=None, status=None,
+                      want_pocket=True):
+        """Enqueue EGNNDynamics.forward on the current stream; no host sync.
+        Inputs must be contiguous fp32 / int64 tensors on this engine's GPU."""
+        dev = self.device
+        for name, x, dt in (("xh_lig", xh_lig, torch.float32), ("xh_pocket", xh_pocket, torch.float32),
+                            ("t", t, torch.float32), ("mask_lig", mask_lig, torch.int64),
+                            ("mask_pocket", mask_pocket, torch.int64)):
+            if x.device != dev or x.dtype != dt or not x.is_contiguous():
+                raise ValueError(f"{name}: expected contiguous {dt} tensor on {dev}, got "
+                                 f"{x.dtype} on {x.device} (contiguous={x.is_contiguous()})")
+        n_lig, n_pocket = xh_lig.shape[0], xh_pocket.shape[0]
+        if ext_edges is not None:
+            er = ext_edges[0].to(device=dev, dtype=torch.int32).contiguous()
+            ec = ext_edges[1].to(device=dev, dtype=torch.int32).contiguous()
+            edge_cap = max(edge_cap, er.numel())
+        self.ensure_workspace(n_lig, n_pocket, batch, edge_cap)
+        if eps_lig is None:
+            eps_lig = torch.empty_like(xh_lig)
+        if eps_pocket is None and want_pocket:
+            eps_pocket = torch.empty_like(xh_pocket)
+        if status is None:
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.dsbdd_dynamics_forward(
+            self.handle, stream, xh_lig.data_ptr(), xh_pocket.data_ptr(), t.data_ptr(), t.numel(),
+            mask_lig.data_ptr(), mask_pocket.data_ptr(), n_lig, n_pocket, batch,
+            er.data_ptr() if ext_edges is not None else None,
+            ec.data_ptr() if ext_edges is not None else None,
+            er.numel() if ext_edges is not None else 0,
+            eps_lig.data_ptr(), eps_pocket.data_ptr() if eps_pocket is not None else None,
+            status.data_ptr())
+        _lib.check(rc, "dsbdd_dynamics_forward")
+        return eps_lig, eps_pocket, status
+
+    def profile(self, enable, max_launches=16384):
+        _lib.check(self.lib.dsbdd_engine_profile(self.handle, int(enable), int(max_launches)))
+
+    def profile_read(self):
+        """(total kernel ms, launches) of the timed GCL edge kernel since the last read."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        _lib.check(self.lib.dsbdd_engine_profile_read(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def edge_count(self, n_nodes):
+        """Number of edges of the last forward (syncs)."""
+        import numpy as np
+        torch.cuda.synchronize(self.device)
+        return int(self._read(self.buffer_ptr(_lib.BUF_ROW_PTR) + 4 * n_nodes, 1, np.int32)[0])
+
+    def buffer_ptr(self, which):
+        p = C.c_void_p()
+        _lib.check(self.lib.dsbdd_engine_buffer(self.handle, which, C.byref(p)))
+        return p.value
+
+    def last_edges(self, n_nodes):
+        """(row, col) of the last forward's edge list, as int64 CPU tensors
+        (debug / tests; syncs)."""
+        import numpy as np
+        torch.cuda.synchronize(self.device)
+        rp = self._read(self.buffer_ptr(_lib.BUF_ROW_PTR), n_nodes + 1, np.int32)
+        E = int(rp[-1])
+        row = self._read(self.buffer_ptr(_lib.BUF_EDGE_ROW), E, np.int32)
+        col = self._read(self.buffer_ptr(_lib.BUF_EDGE_COL), E, np.int32)
+        return torch.from_numpy(row.astype("int64")), torch.from_numpy(col.astype("int64"))
+
+    def _read(self, ptr, count, dtype):
+        import numpy as np
+        itemsize = np.dtype(dtype).itemsize
+        base = (self.workspace.data_ptr() + 255) & ~255
+        off = ptr - self.workspace.data_ptr()
+        raw = self.workspace[off:off + count * itemsize].cpu().numpy()
+        return raw.view(dtype).copy()

@@ -1,0 +1,218 @@
+/*
+ * diffsbdd_hip.h -- C-ABI of libdiffsbdd_hip.so: the MI355X (gfx950) kernels for
+ * DiffSBDD's DDPM denoising hot path.
+ *
+ * The reference (/root/reference) is pure Python/PyTorch and has no FFI; the
+ * interface replaced here is the Python call boundary of
+ *
+ *   EGNNDynamics.forward                 equivariant_diffusion/dynamics.py:87-167
+ *   EGNNDynamics.get_edges               equivariant_diffusion/dynamics.py:169-187
+ *   EGNN / EquivariantBlock / GCL /
+ *   EquivariantUpdate .forward           equivariant_diffusion/egnn_new.py:31-244
+ *   ConditionalDDPM.sample_p_zs_given_zt equivariant_diffusion/conditional_model.py:432-464
+ *   EnVariationalDiffusion
+ *     .sample_p_zs_given_zt              equivariant_diffusion/en_diffusion.py:503-557
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *     nothing is allocated, freed or owned by the library except the opaque
+ *     engine object (host memory); device workspaces are caller-provided.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued asynchronously, no entry point synchronises.
+ *   - all floating point is fp32, row-major; node masks are int64 as in the
+ *     reference (constants.py:8-9) and must be sorted ascending (the reference
+ *     builds them with repeat_interleave, utils.py:146-154).
+ *   - return value: 0 = ok, negative = DSBDD_ERR_*.  Device-side conditions
+ *     (NaN in the velocity, edge-capacity overflow) are reported through the
+ *     `status` word (bit mask DSBDD_STATUS_*), never by a host sync.
+ *
+ * The Python binding is diffsbdd_amd/_lib.py (ctypes); INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ */
+#ifndef DIFFSBDD_HIP_H
+#define DIFFSBDD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSBDD_ABI_VERSION 1
+
+enum {
+  DSBDD_OK = 0,
+  DSBDD_ERR_ARG = -1,         /* bad argument / unsupported configuration   */
+  DSBDD_ERR_STATE = -2,       /* weights or workspace not bound             */
+  DSBDD_ERR_CAPACITY = -3,    /* sizes exceed the bound workspace           */
+  DSBDD_ERR_LAUNCH = -4       /* hip launch error (see dsbdd_last_error)    */
+};
+
+enum {
+  DSBDD_STATUS_NAN = 1,            /* dynamics.py:155-159                   */
+  DSBDD_STATUS_EDGE_OVERFLOW = 2   /* more edges than edge_capacity         */
+};
+
+/* EGNNDynamics constructor arguments that reach the kernels
+ * (dynamics.py:11-19; lightning_modules.py:137-159). */
+typedef struct dsbdd_config {
+  int32_t atom_nf, residue_nf, joint_nf, hidden_nf;
+  int32_t n_layers, inv_sublayers;
+  int32_t attention, use_tanh, update_pocket_coords, reflection_equivariant;
+  int32_t edge_embedding_dim;         /* 0 = no edge-type embedding         */
+  int32_t has_cutoff_ligand, has_cutoff_pocket, has_cutoff_interaction;
+  float cutoff_ligand, cutoff_pocket, cutoff_interaction;
+  float norm_constant, normalization_factor, coords_range;
+} dsbdd_config;
+
+typedef struct dsbdd_engine dsbdd_engine;
+
+/* ---- weight slots --------------------------------------------------------
+ * Weights are passed as a table of device pointers in the order below.  All
+ * matrices are stored TRANSPOSED with respect to nn.Linear ([in][out], out
+ * contiguous) with the leading dimension padded up to a multiple of 4 floats;
+ * vectors are unpadded.  `JP` = round_up(joint_nf+1, 4), `H` = hidden_nf.
+ *
+ * global slots (DSBDD_G_*), then per block b = 0..n_layers-1:
+ *   inv_sublayers x DSBDD_GCL_* slots, then DSBDD_EQ_* slots.            */
+enum {
+  DSBDD_G_ATOM_ENC_W0T = 0, DSBDD_G_ATOM_ENC_B0, DSBDD_G_ATOM_ENC_W1T, DSBDD_G_ATOM_ENC_B1,
+  DSBDD_G_RES_ENC_W0T, DSBDD_G_RES_ENC_B0, DSBDD_G_RES_ENC_W1T, DSBDD_G_RES_ENC_B1,
+  DSBDD_G_ATOM_DEC_W0T, DSBDD_G_ATOM_DEC_B0, DSBDD_G_ATOM_DEC_W1T, DSBDD_G_ATOM_DEC_B1,
+  DSBDD_G_RES_DEC_W0T, DSBDD_G_RES_DEC_B0, DSBDD_G_RES_DEC_W1T, DSBDD_G_RES_DEC_B1,
+  DSBDD_G_EMB_WT,      /* [JP][H]   rows >= joint_nf+1 are zero                */
+  DSBDD_G_EMB_B,       /* [H]                                                  */
+  DSBDD_G_EMBOUT_WT,   /* [H][JP]   cols >= joint_nf+1 are zero                */
+  DSBDD_G_EMBOUT_B,    /* [JP]                                                 */
+  DSBDD_G_COUNT
+};
+enum {
+  DSBDD_GCL_E1_WT = 0, /* [H][2H]: edge_mlp.0.weight[:, :H]^T | [:, H:2H]^T     */
+  DSBDD_GCL_E1_WD,     /* [H]    : edge_mlp.0.weight[:, 2H]   (current |d|^2)   */
+  DSBDD_GCL_E1_WD0,    /* [H]    : edge_mlp.0.weight[:, 2H+1] (input   |d|^2)   */
+  DSBDD_GCL_E1_TAB,    /* [3][H] : bias + edge-type-embedding contribution      */
+  DSBDD_GCL_E2_WT,     /* [H][H] */
+  DSBDD_GCL_E2_B,      /* [H]    */
+  DSBDD_GCL_ATT_W,     /* [H]    (unused if !attention)                         */
+  DSBDD_GCL_ATT_B,     /* [1]    */
+  DSBDD_GCL_N1_WT,     /* [2H][H]: node_mlp.0.weight^T                          */
+  DSBDD_GCL_N1_B,      /* [H]    */
+  DSBDD_GCL_N2_WT,     /* [H][H] */
+  DSBDD_GCL_N2_B,      /* [H]    */
+  DSBDD_GCL_COUNT
+};
+enum {
+  DSBDD_EQ_C1_WT = 0,  /* [H][4H]: coord row | coord col | cross row | cross col
+                          ([H][2H] if reflection_equivariant)                   */
+  DSBDD_EQ_C_WD,       /* coord_mlp: same five slots as the GCL edge MLP        */
+  DSBDD_EQ_C_WD0, DSBDD_EQ_C_TAB, DSBDD_EQ_C_W2T, DSBDD_EQ_C_B2,
+  DSBDD_EQ_X_WD,       /* cross_product_mlp (ignored if reflection_equivariant) */
+  DSBDD_EQ_X_WD0, DSBDD_EQ_X_TAB, DSBDD_EQ_X_W2T, DSBDD_EQ_X_B2,
+  DSBDD_EQ_W3,         /* [H]: the shared bias-free output layer (egnn_new.py:78) */
+  DSBDD_EQ_COUNT
+};
+
+/* ---- engine ---------------------------------------------------------------*/
+int dsbdd_abi_version(void);
+const char* dsbdd_last_error(void);
+
+int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out);
+void dsbdd_engine_destroy(dsbdd_engine* e);
+int dsbdd_engine_weight_slots(const dsbdd_engine* e);
+int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, int n_slots);
+
+/* Workspace for up to (n_lig, n_pocket) nodes, `batch` samples and
+ * `edge_capacity` directed edges (self loops included). */
+size_t dsbdd_engine_workspace_bytes(const dsbdd_engine* e, int64_t n_lig, int64_t n_pocket,
+                                    int64_t batch, int64_t edge_capacity);
+int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* workspace, size_t bytes, int64_t n_lig,
+                                int64_t n_pocket, int64_t batch, int64_t edge_capacity);
+
+/* Optional per-block trace (debug / parity tests): after every EquivariantBlock
+ * the node features h [N][H] and coordinates x [N][3] are copied to
+ * trace_h + b*N*H / trace_x + b*N*3.  NULL disables. */
+int dsbdd_engine_set_trace(dsbdd_engine* e, float* trace_h, float* trace_x);
+
+/* EGNNDynamics.forward (dynamics.py:87-167).
+ *   xh_lig    [n_lig][3+atom_nf]       xh_pocket [n_pocket][3+residue_nf]
+ *   t         [t_count] with t_count == batch or 1 (dynamics.py:104-111)
+ *   ext_row/ext_col: optional teacher-forced edge list (int32, sorted by
+ *     (row,col), node numbering [ligand | pocket]); NULL -> radius graph is
+ *     built on device as dynamics.py:169-187 does.
+ *   eps_lig   [n_lig][3+atom_nf]       eps_pocket [n_pocket][3+residue_nf] (may be NULL)
+ *   status    int32 device word, OR-ed with DSBDD_STATUS_* (caller zeroes it) */
+int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig,
+                           const float* xh_pocket, const float* t, int64_t t_count,
+                           const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
+                           int64_t n_pocket, int64_t batch, const int32_t* ext_row,
+                           const int32_t* ext_col, int64_t ext_n_edges, float* eps_lig,
+                           float* eps_pocket, int32_t* status);
+
+/* Timing of the dominant kernel (the fused GCL edge stage): while enabled,
+ * every launch of that kernel inside dsbdd_dynamics_forward is bracketed by
+ * hipEventRecord on the caller's stream (up to max_launches launches between
+ * reads).  dsbdd_engine_profile_read waits for the recorded events, returns
+ * the summed kernel time and the number of timed launches, and resets. */
+int dsbdd_engine_profile(dsbdd_engine* e, int enable, int max_launches);
+int dsbdd_engine_profile_read(dsbdd_engine* e, double* total_ms, int64_t* launches);
+
+/* Introspection of the last forward (device pointers into the workspace). */
+enum {
+  DSBDD_BUF_EDGE_ROW = 0, DSBDD_BUF_EDGE_COL, DSBDD_BUF_EDGE_D0, DSBDD_BUF_ROW_PTR,
+  DSBDD_BUF_H, DSBDD_BUF_X, DSBDD_BUF_NODE_BATCH
+};
+int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** ptr_out);
+
+/* ---- DDPM reverse-step updates -------------------------------------------
+ * ConditionalDDPM.sample_p_zs_given_zt after the dynamics call
+ * (conditional_model.py:448-464): in place
+ *   z_lig <- z_lig/alpha_ts - c_eps*eps_lig + sigma*noise ; then the ligand
+ *   centre of mass of each sample is subtracted from its ligand AND pocket x.
+ * remove_com = 0 reproduces SimpleConditionalDDPM (conditional_model.py:717-721). */
+int dsbdd_cond_reverse_update(void* stream, float* z_lig, float* xh_pocket, const float* eps_lig,
+                              const float* noise, const int64_t* mask_lig,
+                              const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket,
+                              int64_t batch, int32_t atom_nf, int32_t residue_nf, float alpha_ts,
+                              float c_eps, float sigma, int32_t remove_com);
+
+/* EnVariationalDiffusion.sample_p_zs_given_zt after the dynamics call
+ * (en_diffusion.py:530-556): both node sets are updated, noise_* must already
+ * be COM-free in x (en_diffusion.py:932-942), and the joint COM is removed. */
+int dsbdd_joint_reverse_update(void* stream, float* z_lig, float* z_pocket, const float* eps_lig,
+                               const float* eps_pocket, const float* noise_lig,
+                               const float* noise_pocket, const int64_t* mask_lig,
+                               const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket,
+                               int64_t batch, int32_t atom_nf, int32_t residue_nf, float alpha_ts,
+                               float c_eps, float sigma);
+
+/* Counter-based Gaussian noise, keyed by (seed, global sample id, row within
+ * the sample, column, draw index) so that a chain's noise does not depend on
+ * how samples are sharded over GPUs.  out [n_rows][n_cols];
+ * sample id of row i = mask[i] + sample_offset.  center_x != 0 additionally
+ * removes the per-sample mean of the first 3 columns over (mask, mask2 rows)
+ * -- not applied here; see dsbdd_remove_mean. */
+int dsbdd_randn_keyed(void* stream, float* out, const int64_t* mask, int64_t n_rows,
+                      int32_t n_cols, int64_t batch, int64_t sample_offset, uint64_t seed,
+                      uint64_t draw_index, uint32_t stream_id);
+
+/* ---- individual kernels (unit tests, building blocks) --------------------*/
+/* C[M][N] = act([A1 | A2] @ WT + bias) (+ R);  WT is [K1+K2][ldw]. act: 0 none, 1 SiLU */
+int dsbdd_node_linear(void* stream, const float* A1, int32_t lda1, int32_t K1, const float* A2,
+                      int32_t lda2, int32_t K2, const float* WT, int32_t ldw, const float* bias,
+                      const float* R, int32_t ldr, float* C, int32_t ldc, int64_t M, int32_t N,
+                      int32_t act);
+
+/* Radius graph (dynamics.py:169-187) -> edge list sorted by (row, col).
+ * x [n_lig+n_pocket][3]; scratch: node_batch [N], lig_off/poc_off [batch+1],
+ * deg [N], row_ptr [N+1] (row_ptr[N] = number of edges). */
+int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig,
+                      const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                      const dsbdd_config* cfg, int32_t* node_batch, int32_t* lig_off,
+                      int32_t* poc_off, int32_t* deg, int32_t* row_ptr, int32_t* edge_row,
+                      int32_t* edge_col, float* edge_d0, int64_t edge_capacity, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSBDD_HIP_H */

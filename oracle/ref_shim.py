@@ -94,6 +94,12 @@ def import_reference():
     for name in [n for n in sys.modules if n == "equivariant_diffusion"
                  or n.startswith("equivariant_diffusion.") or n == "utils"]:
         del sys.modules[name]
+    # The reference's `equivariant_diffusion` directory has no __init__.py (a
+    # namespace package), so a regular package of the same name anywhere on
+    # sys.path (ours) would win.  Pin the package object to the reference dir.
+    pkg = types.ModuleType("equivariant_diffusion")
+    pkg.__path__ = [os.path.join(REF_ROOT, "equivariant_diffusion")]
+    sys.modules["equivariant_diffusion"] = pkg
     sys.path.insert(0, REF_ROOT)
     try:
         import equivariant_diffusion.egnn_new as egnn_mod

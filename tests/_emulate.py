@@ -1,0 +1,225 @@
+"""CPU emulation of what libdiffsbdd_hip.so computes, written against the PACKED
+weight slots and following diffsbdd_amd/csrc/engine.hip launch by launch.
+
+Purpose (host-logic tests, no GPU): prove that the weight packing
+(diffsbdd_amd/engine.pack_weights), the slot order, the paddings, the exact
+first-layer factorisation, the edge-prefix trick for update_coords_mask and the
+orchestration order reproduce the oracle -- so that a GPU mismatch can only be
+a kernel bug, not an algebra/plumbing bug.  Also emulates the MFMA 32x32x2
+lane mapping used by the kernels' LDS indexing.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from diffsbdd_amd import _lib
+
+
+def pad4(v):
+    return (v + 3) & ~3
+
+
+def node_linear(A1, K1, A2, K2, WT, bias, R, N, act):
+    """C = act([A1[:, :K1] | A2[:, :K2]] @ WT[:K1+K2, :N] + bias) + R"""
+    A = A1[:, :K1] if A2 is None else torch.cat([A1[:, :K1], A2[:, :K2]], 1)
+    C = A @ WT[:K1 + (K2 if A2 is not None else 0), :N]
+    if bias is not None:
+        C = C + bias[:N]
+    if act:
+        C = F.silu(C)
+    if R is not None:
+        C = C + R[:, :N]
+    return C
+
+
+def edge_mlp_first(P, Q, row, col, d, d0, typ, wd, wd0, tab):
+    pre = P[row] + Q[col] + d[:, None] * wd[None] + d0[:, None] * wd0[None] + tab[typ]
+    return F.silu(pre)
+
+
+def build_edges(x, mask_l, mask_p, cfg):
+    """graph.h edges_kernel semantics: exact distance, sqrt(d2) <= cutoff."""
+    nl = len(mask_l)
+    m = torch.cat([mask_l, mask_p])
+    d = x[:, None, :] - x[None, :, :]
+    d2 = (d * d).sum(-1)
+    dist = torch.sqrt(d2)
+    N = len(m)
+    is_l = torch.arange(N) < nl
+    ll = is_l[:, None] & is_l[None, :]
+    pp = (~is_l[:, None]) & (~is_l[None, :])
+    ok = torch.ones(N, N, dtype=torch.bool)
+    if cfg.has_cutoff_ligand:
+        ok[ll] = (dist <= cfg.cutoff_ligand)[ll]
+    if cfg.has_cutoff_pocket:
+        ok[pp] = (dist <= cfg.cutoff_pocket)[pp]
+    if cfg.has_cutoff_interaction:
+        lp = ~(ll | pp)
+        ok[lp] = (dist <= cfg.cutoff_interaction)[lp]
+    adj = ok & (m[:, None] == m[None, :])
+    row, col = torch.where(adj)
+    return row, col
+
+
+def forward(cfg, slots, xh_lig, xh_pocket, t, mask_l, mask_p, edges=None, trace=None):
+    """Mirror of dsbdd_dynamics_forward."""
+    c = cfg
+    H, J = c.hidden_nf, c.joint_nf
+    JP = pad4(J + 1)
+    a, r = c.atom_nf, c.residue_nf
+    nl, npk = xh_lig.shape[0], xh_pocket.shape[0]
+    N = nl + npk
+    n_mlp = 1 if c.reflection_equivariant else 2
+    G = {n: i for i, n in enumerate(_lib.G_NAMES)}
+    per = c.inv_sublayers * len(_lib.GCL_NAMES) + len(_lib.EQ_NAMES)
+
+    def gcl(b, s, name):
+        return slots[len(_lib.G_NAMES) + b * per + s * len(_lib.GCL_NAMES) + _lib.GCL_NAMES.index(name)]
+
+    def eq(b, name):
+        return slots[len(_lib.G_NAMES) + b * per + c.inv_sublayers * len(_lib.GCL_NAMES)
+                     + _lib.EQ_NAMES.index(name)]
+
+    node_batch = torch.cat([mask_l, mask_p])
+    B = int(node_batch.max()) + 1
+    x = torch.cat([xh_lig[:, :3], xh_pocket[:, :3]]).clone()
+    x_in = x.clone()
+    tt = t.reshape(-1)
+    h0 = torch.zeros(N, JP)
+    h0[:, J] = tt[0] if tt.numel() == 1 else tt[node_batch]
+    # encoders
+    e1 = node_linear(xh_lig[:, 3:], a, None, 0, slots[G["ATOM_ENC_W0T"]], slots[G["ATOM_ENC_B0"]], None, 2 * a, 1)
+    h0[:nl, :J] = node_linear(e1, 2 * a, None, 0, slots[G["ATOM_ENC_W1T"]], slots[G["ATOM_ENC_B1"]], None, J, 0)
+    e2 = node_linear(xh_pocket[:, 3:], r, None, 0, slots[G["RES_ENC_W0T"]], slots[G["RES_ENC_B0"]], None, 2 * r, 1)
+    h0[nl:, :J] = node_linear(e2, 2 * r, None, 0, slots[G["RES_ENC_W1T"]], slots[G["RES_ENC_B1"]], None, J, 0)
+    # edges
+    if edges is None:
+        row, col = build_edges(x, mask_l, mask_p, c)
+    else:
+        row, col = edges[0].long(), edges[1].long()
+    d0 = ((x[row] - x[col]) ** 2).sum(1)
+    rl, cl = row < nl, col < nl
+    typ = torch.zeros(len(row), dtype=torch.long)
+    typ[rl & cl] = 1
+    typ[(~rl) & (~cl)] = 2
+    # embedding
+    h = node_linear(h0, JP, None, 0, slots[G["EMB_WT"]], slots[G["EMB_B"]], None, H, 0)
+    n_upd = N if c.update_pocket_coords else nl
+    e_upd = int((row < n_upd).sum())       # = row_ptr[n_upd]: a prefix of the row-sorted list
+    assert bool((row[:e_upd] < n_upd).all())
+    for blk in range(c.n_layers):
+        if n_mlp == 2:
+            mean = torch.zeros(B, 3).index_add_(0, node_batch, x)
+            cnt = torch.zeros(B).index_add_(0, node_batch, torch.ones(N)).clamp(min=1)
+            mean = mean / cnt[:, None]
+        d = ((x[row] - x[col]) ** 2).sum(1)
+        for sub in range(c.inv_sublayers):
+            pq = node_linear(h, H, None, 0, gcl(blk, sub, "E1_WT"), None, None, 2 * H, 0)
+            a1 = edge_mlp_first(pq[:, :H], pq[:, H:2 * H], row, col, d, d0, typ,
+                                gcl(blk, sub, "E1_WD"), gcl(blk, sub, "E1_WD0"), gcl(blk, sub, "E1_TAB"))
+            m = F.silu(a1 @ gcl(blk, sub, "E2_WT")[:, :H] + gcl(blk, sub, "E2_B"))
+            if c.attention:
+                att = torch.sigmoid(m @ gcl(blk, sub, "ATT_W") + gcl(blk, sub, "ATT_B"))
+                m = m * att[:, None]
+            agg = torch.zeros(N, H).index_add_(0, row, m) / c.normalization_factor
+            t1 = node_linear(h, H, agg, H, gcl(blk, sub, "N1_WT"), gcl(blk, sub, "N1_B"), None, H, 1)
+            h = node_linear(t1, H, None, 0, gcl(blk, sub, "N2_WT"), gcl(blk, sub, "N2_B"), h, H, 0)
+        PQ = (2 if c.reflection_equivariant else 4) * H
+        pq = node_linear(h, H, None, 0, eq(blk, "C1_WT"), None, None, PQ, 0)
+        ru, cu, du, d0u, tu = row[:e_upd], col[:e_upd], d[:e_upd], d0[:e_upd], typ[:e_upd]
+        w3 = eq(blk, "W3")
+        a1 = edge_mlp_first(pq[:, :H], pq[:, H:2 * H], ru, cu, du, d0u, tu, eq(blk, "C_WD"), eq(blk, "C_WD0"),
+                            eq(blk, "C_TAB"))
+        phi = F.silu(a1 @ eq(blk, "C_W2T")[:, :H] + eq(blk, "C_B2")) @ w3
+        diff = x[ru] - x[cu]
+        u = diff / (torch.sqrt((diff * diff).sum(1, keepdim=True) + 1e-8) + c.norm_constant)
+        if c.use_tanh:
+            trans = u * torch.tanh(phi)[:, None] * c.coords_range
+        else:
+            trans = u * phi[:, None]
+        if n_mlp == 2:
+            a1 = edge_mlp_first(pq[:, 2 * H:3 * H], pq[:, 3 * H:4 * H], ru, cu, du, d0u, tu, eq(blk, "X_WD"),
+                                eq(blk, "X_WD0"), eq(blk, "X_TAB"))
+            phx = F.silu(a1 @ eq(blk, "X_W2T")[:, :H] + eq(blk, "X_B2")) @ w3
+            if c.use_tanh:
+                phx = torch.tanh(phx) * c.coords_range
+            aa = x[ru] - mean[node_batch[ru]]
+            bb = x[cu] - mean[node_batch[cu]]
+            cr = torch.linalg.cross(aa, bb, dim=1)
+            cr = cr / (torch.linalg.norm(cr, dim=1, keepdim=True) + c.norm_constant)
+            trans = trans + cr * phx[:, None]
+        xagg = torch.zeros(N, 3).index_add_(0, ru, trans) / c.normalization_factor
+        x = x.clone()
+        x[:n_upd] += xagg[:n_upd]
+        if trace is not None:
+            trace.append((h.clone(), x.clone()))
+    hout = node_linear(h, H, None, 0, slots[G["EMBOUT_WT"]], slots[G["EMBOUT_B"]], None, JP, 0)
+    d1 = node_linear(hout[:nl], J, None, 0, slots[G["ATOM_DEC_W0T"]], slots[G["ATOM_DEC_B0"]], None, 2 * a, 1)
+    eh_l = node_linear(d1, 2 * a, None, 0, slots[G["ATOM_DEC_W1T"]], slots[G["ATOM_DEC_B1"]], None, a, 0)
+    d2 = node_linear(hout[nl:], J, None, 0, slots[G["RES_DEC_W0T"]], slots[G["RES_DEC_B0"]], None, 2 * r, 1)
+    eh_p = node_linear(d2, 2 * r, None, 0, slots[G["RES_DEC_W1T"]], slots[G["RES_DEC_B1"]], None, r, 0)
+    vel = x - x_in
+    if c.update_pocket_coords:
+        mean = torch.zeros(B, 3).index_add_(0, node_batch, vel)
+        cnt = torch.zeros(B).index_add_(0, node_batch, torch.ones(N)).clamp(min=1)
+        vel = vel - (mean / cnt[:, None])[node_batch]
+    return torch.cat([vel[:nl], eh_l], 1), torch.cat([vel[nl:], eh_p], 1), torch.stack([row, col])
+
+
+# ---------------------------------------------------------------------------
+# MFMA lane-mapping emulation (csrc/common.h mfma32 / mfma_row and the k-major
+# LDS indexing of node_linear.h / edge_mlp.h)
+# ---------------------------------------------------------------------------
+def mfma_32x32x2(a_lane, b_lane, acc):
+    """a_lane, b_lane: [64] operands; acc: [64][16].  Lane l holds A[i=l&31][k=l>>5],
+    B[k=l>>5][j=l&31]; D reg r of lane l = D[(r&3)+8*(r>>2)+4*(l>>5)][l&31]."""
+    A = np.zeros((32, 2), np.float64)
+    Bm = np.zeros((2, 32), np.float64)
+    for l in range(64):
+        A[l & 31, l >> 5] = a_lane[l]
+        Bm[l >> 5, l & 31] = b_lane[l]
+    D = A @ Bm
+    out = acc.copy()
+    for l in range(64):
+        for r in range(16):
+            out[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return out
+
+
+def emulate_tile_gemm(Atile, Btile, BM, BN_half_tiles, wave_rows, lda):
+    """Emulates the kernels' main loop for ONE workgroup tile with 4 waves
+    (2 x 2): A tile [BM][K] and B tile [K][BN] are first laid out k-major in
+    'LDS' exactly as the kernels do (sA[k*LDA + m], sB[k*BN + n]); every wave
+    reads its operands with the kernels' pointer arithmetic.  Returns C [BM][BN]
+    reassembled from the accumulator registers via the epilogue's index math."""
+    K = Atile.shape[1]
+    BN = Btile.shape[1]
+    CT = BN_half_tiles           # 32-col tiles per wave
+    RT = wave_rows // 32
+    sA = np.zeros(K * lda)
+    sB = np.zeros(K * BN)
+    for k in range(K):
+        sA[k * lda:k * lda + BM] = Atile[:, k]
+        sB[k * BN:(k + 1) * BN] = Btile[k]
+    C = np.full((BM, BN), np.nan)
+    for w in range(4):
+        wm, wn = w >> 1, w & 1
+        acc = [[np.zeros((64, 16)) for _ in range(CT)] for _ in range(RT)]
+        lanes = np.arange(64)
+        pa = (lanes >> 5) * lda + wm * wave_rows + (lanes & 31)
+        pb = (lanes >> 5) * BN + wn * (BN // 2) + (lanes & 31)
+        for kk in range(0, K, 2):
+            for i in range(RT):
+                a = sA[pa + kk * lda + i * 32]
+                for j in range(CT):
+                    b = sB[pb + kk * BN + j * 32]
+                    acc[i][j] = mfma_32x32x2(a, b, acc[i][j])
+        for i in range(RT):
+            for j in range(CT):
+                for l in range(64):
+                    col = wn * (BN // 2) + j * 32 + (l & 31)
+                    for r in range(16):
+                        rowl = wm * wave_rows + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                        assert np.isnan(C[rowl, col])
+                        C[rowl, col] = acc[i][j][l, r]
+    return C

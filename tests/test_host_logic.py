@@ -1,0 +1,214 @@
+"""CPU tests of the host side: weight packing + launch orchestration (through
+the emulator that mirrors engine.hip), state_dict contract, schedule tables,
+RePaint schedule, C-ABI symbol export."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from diffsbdd_amd import _lib
+from diffsbdd_amd.dynamics import EGNNDynamics
+from diffsbdd_amd.engine import make_config, pack_weights
+from diffsbdd_amd.en_diffusion import (DistributionNodes, EnVariationalDiffusion,
+                                       PredefinedNoiseSchedule, StepCoefficients)
+from diffsbdd_amd.conditional_model import ConditionalDDPM, SimpleConditionalDDPM
+from oracle import ddpm_oracle as do
+from oracle import egnn_oracle as eo
+from oracle import weights as W
+from tests import _emulate as em
+from tests._golden import Case, DYN_CASES, GOLDEN_DIR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hp(cfg):
+    return dict(atom_nf=cfg["atom_nf"], residue_nf=cfg["residue_nf"], joint_nf=cfg["joint_nf"],
+                hidden_nf=cfg["hidden_nf"], n_layers=cfg["n_layers"], inv_sublayers=cfg["inv_sublayers"],
+                attention=cfg["attention"], tanh=cfg["tanh"],
+                update_pocket_coords=cfg["update_pocket_coords"],
+                reflection_equivariant=cfg["reflection_equivariant"],
+                edge_embedding_dim=cfg["edge_embedding_dim"],
+                edge_cutoff_ligand=cfg["edge_cutoff_ligand"], edge_cutoff_pocket=cfg["edge_cutoff_pocket"],
+                edge_cutoff_interaction=cfg["edge_cutoff_interaction"], norm_constant=cfg["norm_constant"],
+                normalization_factor=cfg["normalization_factor"])
+
+
+@pytest.mark.parametrize("name", DYN_CASES)
+def test_packed_weights_and_orchestration_reproduce_golden(name):
+    """Emulated engine (packed slots, factorised first layer, edge prefix) ==
+    reference golden, teacher-forced edges."""
+    c = Case(name)
+    cfg = make_config(**_hp(c.cfg))
+    slots = pack_weights(c.state_dict(), cfg, "cpu")
+    assert len(slots) == len(_lib.G_NAMES) + cfg.n_layers * (
+        cfg.inv_sublayers * len(_lib.GCL_NAMES) + len(_lib.EQ_NAMES))
+    trace = []
+    e_l, e_p, _ = em.forward(cfg, slots, c.t("xh_lig"), c.t("xh_pocket"), c.t("t"), c.t("mask_lig"),
+                             c.t("mask_pocket"), edges=c.t("edges", torch.int64), trace=trace)
+    assert (e_l - c.t("eps_lig")).abs().max() < 2e-5
+    assert (e_p - c.t("eps_pocket")).abs().max() < 2e-5
+    for i, (h, x) in enumerate(trace):
+        if c.has(f"trace_x_{i}"):
+            assert (x - c.t(f"trace_x_{i}")).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["dyn_small_cond", "dyn_small_joint", "dyn_small_variant"])
+def test_emulated_edge_builder_semantics(name):
+    """graph.h semantics (exact distance, sqrt(d2) <= cutoff, order) vs the
+    reference list, up to the cdist ambiguity band."""
+    c = Case(name)
+    cfg = make_config(**_hp(c.cfg))
+    x = torch.cat([c.t("xh_lig")[:, :3], c.t("xh_pocket")[:, :3]])
+    row, col = em.build_edges(x, c.t("mask_lig"), c.t("mask_pocket"), cfg)
+    ref = c.t("edges", torch.int64)
+    n = len(x)
+    a = torch.zeros(n, n, dtype=torch.bool); a[ref[0], ref[1]] = True
+    b = torch.zeros(n, n, dtype=torch.bool); b[row, col] = True
+    band = eo.edge_ambiguity_band(c.t("mask_lig"), c.t("mask_pocket"), x[:len(c.t("mask_lig"))],
+                                  x[len(c.t("mask_lig")):], c.cfg["edge_cutoff_ligand"],
+                                  c.cfg["edge_cutoff_pocket"], c.cfg["edge_cutoff_interaction"], tol=1e-3)
+    assert not ((a ^ b) & ~band).any()
+
+
+def test_mfma_lane_mapping_and_lds_indexing():
+    """The kernels' k-major LDS layout + MFMA 32x32x2 operand/accumulator
+    mapping reproduce A @ B (asymmetric operands: catches transposes)."""
+    rng = np.random.default_rng(0)
+    for BM, BN, wave_rows in ((128, 128, 64), (64, 128, 32), (128, 256, 64), (64, 192, 32), (64, 64, 32)):
+        K = 8
+        A = rng.standard_normal((BM, K))
+        B = rng.standard_normal((K, BN))
+        C = em.emulate_tile_gemm(A, B, BM, BN // 64, wave_rows, BM + 1)
+        assert not np.isnan(C).any()
+        np.testing.assert_allclose(C, A @ B, atol=1e-12)
+
+
+def test_state_dict_contract():
+    """Key names / shapes / order of SURVEY.md §8b incl. the aliased last layer."""
+    for arch in ("crossdock_ca_cond", "crossdock_fullatom_cond", "moad_fullatom_joint", "small_variant"):
+        cfg, dd = W.arch_cfg(arch)
+        model = EGNNDynamics(**cfg)
+        got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        want = W.dynamics_param_shapes(cfg)
+        assert list(got.items()) == [(k, tuple(v)) for k, v in want.items()]
+        if not cfg["reflection_equivariant"]:
+            eqp = model.egnn.e_block_0.gcl_equiv
+            assert eqp.coord_mlp[4].weight is eqp.cross_product_mlp[4].weight
+        model.load_state_dict(W.random_state_dict(cfg, 0), strict=True)
+        cls = ConditionalDDPM if dd["conditional"] else EnVariationalDiffusion
+        ddpm = cls(dynamics=model, atom_nf=cfg["atom_nf"], residue_nf=cfg["residue_nf"], n_dims=3,
+                   size_histogram=np.ones((6, 30)), timesteps=dd["timesteps"],
+                   noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
+                   loss_type="l2", norm_values=dd["norm_values"])
+        keys = list(ddpm.state_dict().keys())
+        assert keys[0] == "buffer" and keys[1] == "gamma.gamma"
+        assert all(k.startswith("dynamics.") for k in keys[2:])
+        assert len(keys) == 2 + len(want)
+    n_params = sum(p.numel() for p in EGNNDynamics(**W.arch_cfg("crossdock_fullatom_cond")[0]).parameters())
+    assert n_params == 4821003   # SURVEY.md §8a (4,821,504 incl. buffer + gamma table)
+
+
+def test_unsupported_configurations_fail_loudly():
+    cfg, _ = W.arch_cfg("small_cond")
+    for bad in (dict(hidden_nf=100), dict(mode="gnn_dynamics"), dict(sin_embedding=True),
+                dict(aggregation_method="mean"), dict(condition_time=False)):
+        kw = dict(cfg); kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            EGNNDynamics(**kw)
+    model = EGNNDynamics(**cfg)   # CPU module: construction is fine, running is not
+    with pytest.raises(_lib.HipLibraryError):
+        model(torch.zeros(2, 13), torch.zeros(3, 13), torch.zeros(1, 1), torch.zeros(2, dtype=torch.long),
+              torch.zeros(3, dtype=torch.long))
+    with pytest.raises(AssertionError):   # conditional_model.py:16-18
+        kw = dict(cfg); kw["update_pocket_coords"] = True
+        ConditionalDDPM(dynamics=EGNNDynamics(**kw), atom_nf=10, residue_nf=10, n_dims=3,
+                        size_histogram=np.ones((4, 8)), timesteps=20, noise_schedule="polynomial_2",
+                        noise_precision=5e-4, loss_type="l2", norm_values=(1., 4.))
+    with pytest.raises(ValueError):       # en_diffusion.py:68-81
+        ConditionalDDPM(dynamics=EGNNDynamics(**cfg), atom_nf=10, residue_nf=10, n_dims=3,
+                        size_histogram=np.ones((4, 8)), timesteps=20, noise_schedule="polynomial_2",
+                        noise_precision=5e-4, loss_type="l2", norm_values=(1., 40.))
+
+
+def test_schedule_tables_and_step_coefficients():
+    z = np.load(os.path.join(GOLDEN_DIR, "schedule.npz"))
+    for tag, (sched, T, prec) in {"poly2_T500_p5e-4": ("polynomial_2", 500, 5e-4),
+                                  "poly2_T500_p1e-5": ("polynomial_2", 500, 1e-5),
+                                  "cosine_T20_p1e-4": ("cosine", 20, 1e-4),
+                                  "cosine_T1000_p1e-4": ("cosine", 1000, 1e-4)}.items():
+        g = PredefinedNoiseSchedule(sched, T, prec)
+        np.testing.assert_array_equal(g.gamma.numpy(), z["gamma_" + tag])
+    # coefficients == what the oracle (== reference formulas) computes per step
+    g = PredefinedNoiseSchedule("polynomial_2", 500, 5e-4)
+    for timesteps in (500, 50):
+        co = StepCoefficients(g.gamma, 500, timesteps)
+        m = do.OracleModel({}, {}, 10, 10, 500, "polynomial_2", 5e-4)
+        for s in (0, 1, timesteps // 2, timesteps - 1):
+            s_arr = torch.full((1, 1), float(s)) / timesteps
+            t_arr = torch.full((1, 1), float(s + 1)) / timesteps
+            s2, s_ts, a_ts, sig_s, sig_t = do.cond_step_coeffs(m, s_arr, t_arr)
+            # torch's vectorised and scalar CPU kernels differ in the last ulp of
+            # expm1/softplus/logsigmoid (the reference itself evaluates these on
+            # [B,1] tensors, i.e. on either path depending on B): compare to 1e-6
+            rel = lambda a, b: abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
+            assert rel(co.alpha_ts[s], a_ts)
+            assert rel(co.c_eps[s], s2 / a_ts / sig_t)
+            assert rel(co.sigma[s], s_ts * sig_s / sig_t)
+            assert float(co.t_value[s + 1]) == float(t_arr)
+
+
+def test_repaint_schedule_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "schedule.npz"))
+    cfg, dd = W.arch_cfg("small_joint")
+    ddpm = EnVariationalDiffusion(dynamics=EGNNDynamics(**cfg), atom_nf=10, residue_nf=10, n_dims=3,
+                                  size_histogram=np.ones((4, 8)), timesteps=20, noise_schedule="polynomial_2",
+                                  noise_precision=1e-5, loss_type="l2", norm_values=(5., 5.))
+    for rec in json.loads(str(z["repaint_json"])):
+        assert ddpm.get_repaint_schedule(rec["resamplings"], rec["jump_length"], rec["timesteps"]) \
+            == rec["schedule"], rec
+    for r in range(1, 5):
+        for j in range(1, 6):
+            for T in (1, 2, 7, 10, 23):
+                assert ddpm.get_repaint_schedule(r, j, T) == do.repaint_schedule(r, j, T), (r, j, T)
+
+
+def test_distribution_nodes():
+    torch.manual_seed(0)
+    hist = np.zeros((5, 7)); hist[2, 3] = 10; hist[4, 3] = 30; hist[1, 6] = 5
+    d = DistributionNodes(hist)
+    nl, npk = d.sample(200)
+    assert set(zip(nl.tolist(), npk.tolist())) <= {(2, 3), (4, 3), (1, 6)}
+    n1 = d.sample_conditional(n2=torch.tensor([3, 3, 6, 3]))
+    assert n1[2] == 1 and set(n1[[0, 1, 3]].tolist()) <= {2, 4}
+    lp = d.log_prob(torch.tensor([4]), torch.tensor([3]))
+    assert abs(float(lp) - np.log((30 + 1e-3) / (45 + 35e-3))) < 1e-5
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/diffsbdd_hip.h <-> libdiffsbdd_hip.so <-> ctypes binding."""
+    hdr = open(os.path.join(ROOT, "include", "diffsbdd_hip.h")).read()
+    declared = set(re.findall(r"\b(dsbdd_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                      # loads without a GPU; no compute calls here
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dsbdd_abi_version() == 1
+    # enum sizes the binding mirrors
+    assert len(_lib.G_NAMES) == 20 and len(_lib.GCL_NAMES) == 12 and len(_lib.EQ_NAMES) == 12
+    for names, prefix in ((_lib.G_NAMES, "DSBDD_G_"), (_lib.GCL_NAMES, "DSBDD_GCL_"), (_lib.EQ_NAMES, "DSBDD_EQ_")):
+        pos = [hdr.index(prefix + n) for n in names]
+        assert pos == sorted(pos), prefix        # same order as the header enums
+    # engine bookkeeping entry points work on the host alone
+    cfg = make_config(**_hp(W.arch_cfg("crossdock_fullatom_cond")[0]))
+    h = ctypes.c_void_p()
+    assert lib.dsbdd_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    assert lib.dsbdd_engine_weight_slots(h) == 20 + 6 * 24
+    assert lib.dsbdd_engine_workspace_bytes(h, 1472, 18304, 64, 6_200_000) > 0
+    lib.dsbdd_engine_destroy(h)
+    bad = make_config(**{**_hp(W.arch_cfg("small_cond")[0]), "hidden_nf": 96})
+    assert lib.dsbdd_engine_create(ctypes.byref(bad), ctypes.byref(h)) == _lib.ERR_ARG
+    assert b"hidden_nf" in lib.dsbdd_last_error()
