@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark of the DDPM sampling hot path on MI355X (contract: see the task
+description / DESIGN.md §Measurement).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete sampling chain over one batch of synthetic pockets:
+`ConditionalDDPM.sample_given_pocket` on BASELINE.json configs[2]
+(crossdock_fullatom_cond, 64 pockets per GPU, 23 ligand atoms each, T = 500
+reverse steps + the final decode = 501 EGNN evaluations).  Inputs are resident
+in HBM before the timed region; weights are seeded random (no checkpoint is
+reachable), pockets are the 3rfm full-atom pocket fixture repeated.
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run;
+every rank runs its own 64 pockets (weak scaling, no data-path collective) and
+the finished ligands are gathered once per chain over RCCL.  value = ligands of
+all ranks / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fused GCL edge stage, csrc/edge_mlp.h) timed
+                 live with HIP events on its own stream; algorithmic FLOPs
+                 (E*(H^2 + (A+2)H) MAC per launch) / duration vs
+                 the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline : the CPU oracle (a port of the reference's PyTorch path) timed on
+                 this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from diffsbdd_amd import sharding, synthetic  # noqa: E402
+from diffsbdd_amd.pocket import prepare_pocket  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / fp32 vector peak
+HBM_PEAK_GBPS = 8000.0
+METRIC = "sampled ligands/sec (500-step DDPM, fullatom_cond) at 1/2/4/8 MI355X"
+
+WORKLOADS = {
+    # name: (arch, pocket key, default batch per GPU)
+    "crossdock_fullatom_cond": ("crossdock_fullatom_cond", "fa", 64),
+    "crossdock_ca_cond": ("crossdock_ca_cond", "ca", 32),
+}
+
+
+def load_pocket(key, batch, device):
+    z = np.load(os.path.join(ROOT, "diffsbdd_amd", "data", "pocket_3rfm.npz"))
+    n_types = 20 if key == "ca" else 10
+    return prepare_pocket(z[key + "_x"], z[key + "_types"], n_types, repeats=batch, device=device)
+
+
+def build_model(arch, device):
+    from diffsbdd_amd.conditional_model import ConditionalDDPM
+    from diffsbdd_amd.dynamics import EGNNDynamics
+    cfg, dd = synthetic.arch_cfg(arch)
+    dyn = EGNNDynamics(**cfg, device=device)
+    dyn.load_state_dict(synthetic.random_state_dict(cfg, seed=0))
+    model = ConditionalDDPM(dynamics=dyn, atom_nf=cfg["atom_nf"], residue_nf=cfg["residue_nf"], n_dims=3,
+                            size_histogram=np.ones((40, 400)), timesteps=dd["timesteps"],
+                            noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
+                            loss_type="l2", norm_values=dd["norm_values"]).to(device)
+    return cfg, dd, model
+
+
+def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
+    """The oracle (CPU port of the reference path) on this host's cores:
+    `steps` consecutive reverse steps after one warm-up at batch b_cpu,
+    extrapolated to a full chain (>= 98.6 % of a chain is the per-step dynamics
+    call)."""
+    from oracle import ddpm_oracle as do
+    # torch's intra-op pool stops scaling long before a 256-core host is full (measured on
+    # the GPU box: 256 threads -> 75 s/step at batch 16, i.e. 30x SLOWER than 8 threads on an
+    # 8-core machine); use at most `max_threads` and report the number actually used.
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    cfg, dd = synthetic.arch_cfg(arch)
+    sd = synthetic.random_state_dict(cfg, seed=0)
+    m = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
+                       dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
+    pocket = load_pocket(key, b_cpu, "cpu")
+    _, pocket = do.normalize(m, None, pocket)
+    xh_pocket = torch.cat([pocket["x"], pocket["one_hot"]], 1)
+    lig_mask = torch.repeat_interleave(torch.arange(b_cpu), n_lig)
+    tape = do.NoiseTape(1234)
+    mu = torch.cat((do._seg_mean(pocket["x"], pocket["mask"], b_cpu), torch.zeros(b_cpu, cfg["atom_nf"])), 1)[lig_mask]
+    z, xp = do.cond_sample_normal_zero_com(m, mu, xh_pocket, torch.ones(b_cpu, 1), lig_mask, pocket["mask"], tape, b_cpu)
+    T = dd["timesteps"]
+    times = []
+    with torch.no_grad():
+        for i, s in enumerate(range(T - 1, T - 2 - steps, -1)):
+            s_arr = torch.full((b_cpu, 1), float(s)) / T
+            t_arr = torch.full((b_cpu, 1), float(s + 1)) / T
+            t0 = time.perf_counter()
+            z, xp = do.cond_sample_p_zs_given_zt(m, s_arr, t_arr, z, xp, lig_mask, pocket["mask"], tape)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
+    t_step = float(np.mean(times))
+    return {"value": b_cpu / (t_step * n_calls), "unit": "ligands/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} reverse steps (EGNN call + posterior update) of {arch} at batch {b_cpu} after 1 "
+                      f"warm-up step, {t_step:.3f} s/step, extrapolated to {n_calls} EGNN calls per chain",
+            "torch_threads": torch.get_num_threads()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed sampling chains")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up chains")
+    ap.add_argument("--workload", default="crossdock_fullatom_cond", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="pockets per GPU")
+    ap.add_argument("--timesteps", type=int, default=None, help="DDPM steps (default: the config's 500)")
+    ap.add_argument("--n-lig", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    args = ap.parse_args()
+
+    rank, local_rank, world = sharding.init_distributed()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    arch, key, default_batch = WORKLOADS[args.workload]
+    B = args.batch or default_batch
+    cfg, dd, model = build_model(arch, device)
+    T = args.timesteps or dd["timesteps"]
+    n_calls = T + 1
+    pocket0 = load_pocket(key, B, device)
+    n_lig = torch.full((B,), args.n_lig, dtype=torch.int64)
+    lo = rank * B                                   # weak scaling: every rank owns B global samples
+    eng = model.dynamics.engine()
+
+    def chain(seed):
+        model.seed(seed, sample_offset=lo)
+        pocket = {k: v.clone() for k, v in pocket0.items()}
+        out_l, out_p, lm, pm = model.sample_given_pocket(pocket, n_lig, timesteps=T)
+        return sharding.gather_ligands(out_l, lm, lo)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize(device)
+
+    for w in range(args.warmup):
+        chain(100 + w)
+    sync()
+    eng.profile(True, max_launches=min(args.steps, 5) * n_calls * cfg["n_layers"] * cfg["inv_sublayers"] + 8)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        all_lig, all_mask = chain(200 + k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = eng.profile_read()
+    eng.profile(False, 0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    n_ligands_total = B * world * args.steps
+    assert all_lig.shape[0] == B * world * args.n_lig and torch.isfinite(all_lig).all()
+
+    if rank == 0:
+        N = B * args.n_lig + pocket0["x"].shape[0]
+        E = eng.edge_count(N)
+        H = cfg["hidden_nf"]
+        A = 2 + (cfg.get("edge_embedding_dim") or 0)
+        flops_per_launch = 2.0 * E * (H * H + (A + 2) * H)
+        avg_ms = kern_ms / max(kern_n, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
+        bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E + 3 * N + N * H)
+        roofline = {
+            "bound": "mfma", "kernel": "edge_mlp_kernel<MODE_GCL> (fused GCL edge stage)",
+            "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
+            "traffic": None,
+            "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E,
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "kernel_share_of_wall": (kern_ms * 1e-3 / elapsed) * (args.steps * n_calls * cfg["n_layers"]
+                                                                 * cfg["inv_sublayers"] / max(kern_n, 1)),
+            "hbm_algorithmic_gbps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None,
+            "hbm_frac_of_8TBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_n else None,
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, max_threads=args.cpu_threads)
+        value = n_ligands_total / elapsed
+        line = {
+            "metric": METRIC, "value": value, "unit": "ligands/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {B} pockets/GPU (3rfm {key} pocket, "
+                                   f"{pocket0['x'].shape[0] // B} nodes) x {args.n_lig} ligand atoms, "
+                                   f"T={T} reverse steps + final decode = {n_calls} EGNN calls per chain",
+                       "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
+                       "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
+                       "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
+            "host_cores": os.cpu_count(),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

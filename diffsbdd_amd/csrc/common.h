@@ -9,15 +9,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;  // 4 waves of 64 lanes per workgroup
 
-// SiLU(x) = x * sigmoid(x)  (nn.SiLU; egnn_new.py:8,16-19).  v_exp_f32 + v_rcp
-// based: ~2 ulp, saturates correctly at both ends (x -> -inf gives -0).
-__device__ __forceinline__ float silu(float x) {
-  return __fdividef(x, 1.0f + __expf(-x));
+// SiLU(x) = x * sigmoid(x)  (nn.SiLU; egnn_new.py:8,16-19) as v_exp_f32 +
+// v_rcp_f32 (~1 ulp each; `x / (1+e)` would expand to the 10-instruction IEEE
+// division sequence).  Saturates correctly: x << 0 -> exp = inf -> rcp = 0 -> -0.
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
-__device__ __forceinline__ float sigmoidf_fast(float x) {
-  return __fdividef(1.0f, 1.0f + __expf(-x));
-}
+__device__ __forceinline__ float silu(float x) { return x * sigmoidf_fast(x); }
 
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32 (one fmaf
 // chain per output).  Lane l supplies A[i = l&31][k = l>>5] and

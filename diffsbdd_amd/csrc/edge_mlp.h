@@ -81,7 +81,7 @@ struct EdgeLayout {
   static constexpr int VEC_OFF = REGION;
   static constexpr int VEC_PER = 7 * H;
   static constexpr int META_OFF = VEC_OFF + NV * VEC_PER;
-  static constexpr int META = 10 * BM;            // row,col,type | d,d0,att/phi0,phi1 | trans[3]
+  static constexpr int META = 15 * BM;            // 2 x (row,col,type,d,d0) | att/phi0, phi1 | trans[3]
   static constexpr int TOTAL = META_OFF + META;
 };
 
@@ -106,14 +106,13 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
   float* sA = smem;                         // [2][BK][LDA]
   float* sB = smem + 2 * L::A_BUF;          // [2][BK][H]
   float* sV = smem + L::VEC_OFF;            // per MLP: wd, wd0, tab0, tab1, tab2, b2, wout
-  int* s_row = reinterpret_cast<int*>(smem + L::META_OFF);
-  int* s_col = s_row + BM;
-  int* s_typ = s_row + 2 * BM;
-  float* s_d = smem + L::META_OFF + 3 * BM;
-  float* s_d0 = s_d + BM;
-  float* s_s0 = s_d + 2 * BM;               // GCL: attention; COORD: phi (coord)
-  float* s_s1 = s_d + 3 * BM;               // COORD: phi (cross)
-  float* s_tr = s_d + 4 * BM;               // COORD: trans [BM][3]
+  // tile metadata is double-buffered: the next tile's (row, col, type, d, d0) are
+  // fetched while the current tile is in its main loop (hides two dependent
+  // global-load latencies per tile)
+  float* s_meta = smem + L::META_OFF;       // [2][5][BM]
+  float* s_s0 = s_meta + 10 * BM;           // GCL: attention; COORD: phi (coord)
+  float* s_s1 = s_meta + 11 * BM;           // COORD: phi (cross)
+  float* s_tr = s_meta + 12 * BM;           // COORD: trans [BM][3]
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
@@ -146,26 +145,55 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
   // staging coordinates
   const int a_kq = (t % KQ) * 4, a_m = t / KQ;  // + (kThreads/KQ)*i
 
-  for (int li = kx; li < csize; li += gx) {
-    const int tile = cbase + li;
-    __syncthreads();  // previous tile's epilogue is done with LDS (also covers sV fill)
-
-    // ---- tile metadata: one thread per edge ----------------------------------
+  // one thread per edge: fetch (row, col, d0) / coordinates / write LDS
+  int nx_r = -1, nx_c = 0;
+  float nx_d0 = 0.f, nx_xr[3] = {0.f, 0.f, 0.f}, nx_xc[3] = {0.f, 0.f, 0.f};
+  auto meta_fetch_idx = [&](int tile_id) {
+    nx_r = -1; nx_c = 0; nx_d0 = 0.f;
+    const int e = tile_id * BM + t;
+    if (t < BM && e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
+  };
+  auto meta_fetch_x = [&]() {
+    if (t < BM && nx_r >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { nx_xr[k] = p.x[3 * nx_r + k]; nx_xc[k] = p.x[3 * nx_c + k]; }
+    }
+  };
+  auto meta_store = [&](int buf) {
     if (t < BM) {
-      const int e = tile * BM + t;
-      int r = -1, c = 0, ty = 0;
-      float d = 0.f, d0 = 0.f;
-      if (e < E) {
-        r = p.erow[e]; c = p.ecol[e]; d0 = p.ed0[e];
-        const float dx = p.x[3 * r] - p.x[3 * c], dy = p.x[3 * r + 1] - p.x[3 * c + 1],
-                    dz = p.x[3 * r + 2] - p.x[3 * c + 2];
+      float* mb = s_meta + buf * 5 * BM;
+      float d = 0.f;
+      int ty = 0;
+      if (nx_r >= 0) {
+        const float dx = nx_xr[0] - nx_xc[0], dy = nx_xr[1] - nx_xc[1], dz = nx_xr[2] - nx_xc[2];
         d = dx * dx + dy * dy + dz * dz;   // coord2diff radial, egnn_new.py:298-299
-        const bool rl = r < p.n_lig, cl = c < p.n_lig;
+        const bool rl = nx_r < p.n_lig, cl = nx_c < p.n_lig;
         ty = (rl && cl) ? 1 : ((!rl && !cl) ? 2 : 0);  // dynamics.py:119-124
       }
-      s_row[t] = r; s_col[t] = c; s_typ[t] = ty; s_d[t] = d; s_d0[t] = d0;
+      reinterpret_cast<int*>(mb)[t] = nx_r;
+      reinterpret_cast<int*>(mb)[BM + t] = nx_c;
+      reinterpret_cast<int*>(mb)[2 * BM + t] = ty;
+      mb[3 * BM + t] = d;
+      mb[4 * BM + t] = nx_d0;
     }
-    __syncthreads();
+  };
+
+  int mbuf = 0;
+  if (kx < csize) {   // first tile of this workgroup: synchronous
+    meta_fetch_idx(cbase + kx);
+    meta_fetch_x();
+    meta_store(0);
+  }
+
+  for (int li = kx; li < csize; li += gx, mbuf ^= 1) {
+    const bool has_next = li + gx < csize;
+    const int next_tile = cbase + li + gx;
+    const int* s_row = reinterpret_cast<const int*>(s_meta + mbuf * 5 * BM);
+    const int* s_col = s_row + BM;
+    const int* s_typ = s_row + 2 * BM;
+    const float* s_d = s_meta + mbuf * 5 * BM + 3 * BM;
+    const float* s_d0 = s_d + BM;
+    __syncthreads();  // previous tile's epilogue is done with LDS; metadata / sV visible
 
     for (int q = 0; q < n_pass; ++q) {
       const EdgeMlpW& mw = p.mlp[q];
@@ -227,6 +255,11 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
       __syncthreads();
 #pragma unroll 1
       for (int kt = 0; kt < NK; ++kt) {
+        if (q == 0 && has_next) {   // next tile's metadata, spread over the first K steps
+          if (kt == 0) meta_fetch_idx(next_tile);
+          if (kt == 1) meta_fetch_x();
+          if (kt == (NK > 2 ? 2 : NK - 1)) meta_store(mbuf ^ 1);
+        }
         if (kt + 1 < NK) gload((kt + 1) * BK);
         const float* pa = sA + (kt & 1) * L::A_BUF + (lane >> 5) * LDA + wm * (BM / 2) + (lane & 31);
         const float* pb = sB + (kt & 1) * L::B_BUF + (lane >> 5) * H + wn * (H / 2) + (lane & 31);
@@ -271,7 +304,12 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
             float dot = 0.f;
             const float* mrow = sM + el * LDM;
             const float* aw = vq + 6 * H;
-            for (int k = part; k < H; k += TPR) dot += mrow[k] * aw[k];
+            constexpr int CH = H / TPR;           // features per thread
+#pragma unroll 8
+            for (int i = 0; i < CH; ++i) {        // skewed start: conflict-free LDS banks
+              const int k = part * CH + (i + part * (32 / TPR)) % CH;
+              dot += mrow[k] * aw[k];
+            }
 #pragma unroll
             for (int o = 1; o < TPR; o <<= 1) dot += __shfl_xor(dot, o);
             att = sigmoidf_fast(dot + att_b);
@@ -280,17 +318,28 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
         }
         __syncthreads();
         // ---- segmented sum over the row-sorted edges, one thread per feature --
-        if (t < H) {
+        if (t < H) {   // whole waves only (H is a multiple of 64): the row id is wave-uniform
           int cur = -1;
           float sum = 0.f;
-          for (int el = 0; el < BM; ++el) {
-            const int r = s_row[el];
-            if (r != cur) {
-              if (cur >= 0) unsafeAtomicAdd(&p.agg[(size_t)cur * H + t], sum / p.norm_factor);
-              cur = r;
-              sum = 0.f;
+#pragma unroll 1
+          for (int e0 = 0; e0 < BM; e0 += 16) {
+            int rr[16];
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {          // 48 independent LDS reads in flight
+              rr[j] = s_row[e0 + j];
+              v[j] = sM[(e0 + j) * LDM + t] * s_s0[e0 + j];   // mij * att, egnn_new.py:40
             }
-            if (r >= 0) sum += sM[el * LDM + t] * s_s0[el];   // mij * att, egnn_new.py:40
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int r = __builtin_amdgcn_readfirstlane(rr[j]);   // scalar compare/branch
+              if (r != cur) {
+                if (cur >= 0) unsafeAtomicAdd(&p.agg[(size_t)cur * H + t], sum / p.norm_factor);
+                cur = r;
+                sum = 0.f;
+              }
+              sum += v[j];   // rows of padding edges (r = -1) are summed but never flushed
+            }
           }
           if (cur >= 0) unsafeAtomicAdd(&p.agg[(size_t)cur * H + t], sum / p.norm_factor);
         }
@@ -319,7 +368,9 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
         {
           const int el = t / TPR, part = t % TPR;
           float s = 0.f;
-          for (int k = part; k < 64; k += TPR) s += sR[el * 65 + k];
+          constexpr int CH = 64 / TPR;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) s += sR[el * 65 + part * CH + (i + part * (32 / TPR)) % CH];
 #pragma unroll
           for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
           if (part == 0) (q == 0 ? s_s0 : s_s1)[el] = s;
@@ -369,14 +420,22 @@ __global__ __launch_bounds__(kThreads) void edge_mlp_kernel(EdgeArgs p) {
       if (t < 3) {
         int cur = -1;
         float sum = 0.f;
-        for (int el = 0; el < BM; ++el) {
-          const int r = s_row[el];
-          if (r != cur) {
-            if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + t], sum / p.norm_factor);
-            cur = r;
-            sum = 0.f;
+#pragma unroll 1
+        for (int e0 = 0; e0 < BM; e0 += 16) {
+          int rr[16];
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { rr[j] = s_row[e0 + j]; v[j] = s_tr[3 * (e0 + j) + t]; }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int r = rr[j];
+            if (r != cur) {
+              if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + t], sum / p.norm_factor);
+              cur = r;
+              sum = 0.f;
+            }
+            sum += v[j];
           }
-          if (r >= 0) sum += s_tr[3 * el + t];
         }
         if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + t], sum / p.norm_factor);
       }

@@ -43,7 +43,7 @@ struct dsbdd_engine {
   float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *hout;
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
-  int edge_bm = 128;
+  int edge_bm = 64;    // 64-edge tiles, 2 workgroups per CU (measured faster than 128 / 1)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
   bool profile = false;
   std::vector<hipEvent_t> ev;   // pairs: start, stop
@@ -113,7 +113,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
       prop.multiProcessorCount > 0)
     e->n_cu = prop.multiProcessorCount;
   const char* bm = getenv("DSBDD_EDGE_TILE");
-  if (bm && atoi(bm) == 64) e->edge_bm = 64;
+  if (bm && atoi(bm) == 128) e->edge_bm = 128;
   *out = e;
   return DSBDD_OK;
 }

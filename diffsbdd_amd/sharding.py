@@ -1,0 +1,100 @@
+"""Pocket sharding across the GPUs of one node.
+
+Samples of a sampling batch are independent diffusion chains (the graph is
+block-diagonal per sample: /root/reference/equivariant_diffusion/dynamics.py:170-172),
+so the data-parallel scheme has NO collective on the data path:
+
+  * one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on
+    ROCm, "gloo" on CPU for tests);
+  * rank r owns the contiguous global sample range shard_range(n, W, r);
+  * noise is keyed by the GLOBAL sample index (dsbdd_randn_keyed), so a chain
+    does not depend on W;
+  * one exchange at the very end: all_gather of the per-rank row counts, then a
+    padded all_gather of the finished ligands (KB-scale: latency bound).
+
+The reference has no multi-GPU sampling path at all.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, world: int, rank: int):
+    """Contiguous block partition, ceil(n/W) per rank (the last ranks may get
+    fewer / zero samples)."""
+    per = (n_total + world - 1) // world
+    lo = min(rank * per, n_total)
+    hi = min(lo + per, n_total)
+    return lo, hi
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns
+    (rank, local_rank, world).  A single process (no env) is world 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        # dmabuf IPC is the only mode the host driver supports (see task notes)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int, group=None):
+    """Gather the finished ligands of every rank.
+
+    out_lig  [n_rows, D] this rank's ligand atoms (x | one-hot), lig_mask [n_rows]
+    LOCAL sample ids; sample_lo = global index of this rank's first sample.
+    Returns (all_lig [sum rows, D], all_mask with GLOBAL sample ids) on every
+    rank (all_gather; the payload is ~1 KB per molecule)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return out_lig, lig_mask + sample_lo
+    world = dist.get_world_size(group)
+    dev = out_lig.device
+    n_rows = torch.tensor([out_lig.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n_rows, group=group)
+    counts = [int(c.item()) for c in counts]
+    max_rows = max(max(counts), 1)
+    D = out_lig.shape[1]
+    # one padded payload: [max_rows, D + 1] with the global sample id as last column
+    payload = torch.zeros((max_rows, D + 1), dtype=torch.float64, device=dev)
+    payload[:out_lig.shape[0], :D] = out_lig.to(torch.float64)
+    payload[:out_lig.shape[0], D] = (lig_mask + sample_lo).to(torch.float64)
+    bufs = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(bufs, payload, group=group)
+    rows = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return rows[:, :D].to(out_lig.dtype), rows[:, D].round().to(torch.int64)
+
+
+def sample_sharded(sample_fn, n_total: int, group=None):
+    """Run `sample_fn(lo, hi) -> (out_lig, lig_mask_local)` on this rank's
+    shard and gather.  `sample_fn` must key its randomness by the global sample
+    index (e.g. model.seed(seed, sample_offset=lo))."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n_total, world, rank)
+    if hi > lo:
+        out_lig, mask = sample_fn(lo, hi)
+    else:
+        out_lig, mask = None, None
+    if out_lig is None:   # empty shard: still has to take part in the gather
+        probe_dev = torch.device("cuda", torch.cuda.current_device()) if (
+            dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
+        out_lig = torch.zeros((0, sample_sharded.feature_dim), device=probe_dev)
+        mask = torch.zeros((0,), dtype=torch.int64, device=probe_dev)
+    return gather_ligands(out_lig, mask, lo, group)
+
+
+sample_sharded.feature_dim = 13  # 3 + atom_nf of the shipped configs; set before use otherwise

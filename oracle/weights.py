@@ -1,136 +1,5 @@
-"""ORACLE support (test infrastructure): deterministic synthetic weights.
-
-No released checkpoint is reachable, so parity runs use seeded
-random weights.  To make them reproducible on the GPU box *without* the
-reference, the tensors are generated by name, in a fixed order, from a CPU
-`torch.Generator` -- independent of any module-construction order.  Scales
-follow nn.Linear's default init (U(+-1/sqrt(fan_in))); the final bias-free
-layer of the coordinate MLPs (xavier gain 0.001 in the reference,
-egnn_new.py:78-79, which makes untrained coordinate updates vanish and the
-test vacuous) is drawn at 0.75/sqrt(fan_in) instead.
-"""
-from __future__ import annotations
-
-import hashlib
-import math
-
-import torch
-
-
-def dynamics_param_shapes(cfg):
-    """Ordered {name: shape} of EGNNDynamics.state_dict() for `cfg`
-    (dynamics.py:27-85, egnn_new.py:15-29,78-92,151-160,212-222)."""
-    a, r = cfg["atom_nf"], cfg["residue_nf"]
-    J, H, L = cfg["joint_nf"], cfg["hidden_nf"], cfg["n_layers"]
-    enf = cfg.get("edge_embedding_dim") or 0
-    A = 2 + enf
-    D = J + 1  # condition_time=True
-    shapes = {}
-
-    def lin(name, fin, fout, bias=True):
-        shapes[name + ".weight"] = (fout, fin)
-        if bias:
-            shapes[name + ".bias"] = (fout,)
-
-    lin("atom_encoder.0", a, 2 * a); lin("atom_encoder.2", 2 * a, J)
-    lin("atom_decoder.0", J, 2 * a); lin("atom_decoder.2", 2 * a, a)
-    lin("residue_encoder.0", r, 2 * r); lin("residue_encoder.2", 2 * r, J)
-    lin("residue_decoder.0", J, 2 * r); lin("residue_decoder.2", 2 * r, r)
-    if enf:
-        shapes["edge_embedding.weight"] = (3, enf)
-    lin("egnn.embedding", D, H)
-    lin("egnn.embedding_out", H, D)
-    for i in range(L):
-        for s in range(cfg["inv_sublayers"]):
-            p = f"egnn.e_block_{i}.gcl_{s}"
-            lin(p + ".edge_mlp.0", 2 * H + A, H); lin(p + ".edge_mlp.2", H, H)
-            lin(p + ".node_mlp.0", 2 * H, H); lin(p + ".node_mlp.2", H, H)
-            if cfg["attention"]:
-                lin(p + ".att_mlp.0", H, 1)
-        p = f"egnn.e_block_{i}.gcl_equiv"
-        lin(p + ".coord_mlp.0", 2 * H + A, H); lin(p + ".coord_mlp.2", H, H)
-        lin(p + ".coord_mlp.4", H, 1, bias=False)
-        if not cfg["reflection_equivariant"]:
-            lin(p + ".cross_product_mlp.0", 2 * H + A, H)
-            lin(p + ".cross_product_mlp.2", H, H)
-            lin(p + ".cross_product_mlp.4", H, 1, bias=False)
-    return shapes
-
-
-def random_state_dict(cfg, seed=0, dtype=torch.float32):
-    gen = torch.Generator().manual_seed(seed)
-    shapes = dynamics_param_shapes(cfg)
-    sd = {}
-    for name, shape in shapes.items():
-        if name == "edge_embedding.weight":
-            sd[name] = torch.randn(shape, generator=gen)
-            continue
-        if name.endswith("cross_product_mlp.4.weight"):
-            # same Parameter object as coord_mlp.4 in the reference (egnn_new.py:78,85,91)
-            sd[name] = sd[name.replace("cross_product_mlp", "coord_mlp")]
-            continue
-        fan_in = shape[1] if len(shape) == 2 else \
-            shapes[name.replace(".bias", ".weight")][1]
-        bound = 1.0 / math.sqrt(fan_in)
-        if name.endswith("coord_mlp.4.weight"):
-            bound *= 0.75
-        sd[name] = (torch.rand(shape, generator=gen) * 2 - 1) * bound
-    return {k: v.to(dtype) for k, v in sd.items()}
-
-
-def state_dict_checksum(sd):
-    h = hashlib.sha256()
-    for k in sorted(sd):
-        h.update(k.encode())
-        h.update(sd[k].detach().cpu().float().contiguous().numpy().tobytes())
-    return h.hexdigest()[:16]
-
-
-# --- the architectures behind BASELINE.json's configs -------
-def arch_cfg(name):
-    base = dict(n_dims=3, attention=True, tanh=True, norm_constant=1, inv_sublayers=1,
-                sin_embedding=False, normalization_factor=100, aggregation_method="sum",
-                edge_cutoff_ligand=None, reflection_equivariant=False, condition_time=True)
-    if name == "crossdock_ca_cond":          # configs/crossdock_ca_cond.yml:30-52
-        base.update(atom_nf=10, residue_nf=20, joint_nf=128, hidden_nf=256, n_layers=6,
-                    edge_cutoff_pocket=5.0, edge_cutoff_interaction=5.0,
-                    update_pocket_coords=False, edge_embedding_dim=None)
-        ddpm = dict(timesteps=500, noise_schedule="polynomial_2", noise_precision=5e-4,
-                    norm_values=(1.0, 1.0), conditional=True)
-    elif name == "crossdock_fullatom_cond":  # configs/crossdock_fullatom_cond.yml:30-52
-        base.update(atom_nf=10, residue_nf=10, joint_nf=128, hidden_nf=256, n_layers=6,
-                    edge_cutoff_pocket=5.0, edge_cutoff_interaction=5.0,
-                    update_pocket_coords=False, edge_embedding_dim=None)
-        ddpm = dict(timesteps=500, noise_schedule="polynomial_2", noise_precision=5e-4,
-                    norm_values=(1.0, 4.0), conditional=True)
-    elif name == "moad_fullatom_joint":      # configs/moad_fullatom_joint.yml:31-53
-        base.update(atom_nf=10, residue_nf=10, joint_nf=128, hidden_nf=192, n_layers=6,
-                    edge_cutoff_pocket=0.8, edge_cutoff_interaction=1.4,
-                    update_pocket_coords=True, edge_embedding_dim=8)
-        ddpm = dict(timesteps=500, noise_schedule="polynomial_2", noise_precision=1e-5,
-                    norm_values=(5.0, 5.0), conditional=False)
-    elif name == "small_cond":
-        base.update(atom_nf=10, residue_nf=10, joint_nf=16, hidden_nf=64, n_layers=2,
-                    edge_cutoff_pocket=5.0, edge_cutoff_interaction=5.0,
-                    update_pocket_coords=False, edge_embedding_dim=None)
-        ddpm = dict(timesteps=20, noise_schedule="polynomial_2", noise_precision=5e-4,
-                    norm_values=(1.0, 4.0), conditional=True)
-    elif name == "small_joint":
-        base.update(atom_nf=10, residue_nf=10, joint_nf=16, hidden_nf=64, n_layers=2,
-                    edge_cutoff_pocket=0.8, edge_cutoff_interaction=1.4,
-                    update_pocket_coords=True, edge_embedding_dim=8)
-        ddpm = dict(timesteps=20, noise_schedule="polynomial_2", noise_precision=1e-5,
-                    norm_values=(5.0, 5.0), conditional=False)
-    elif name == "small_variant":
-        # exercises the non-default flags: no attention, no tanh, E(3) (no cross
-        # product MLP), two invariant sub-layers, ligand cutoff, norm_constant 0
-        base.update(atom_nf=10, residue_nf=20, joint_nf=16, hidden_nf=128, n_layers=2,
-                    attention=False, tanh=False, reflection_equivariant=True,
-                    inv_sublayers=2, norm_constant=0, edge_cutoff_ligand=6.0,
-                    edge_cutoff_pocket=5.0, edge_cutoff_interaction=5.0,
-                    update_pocket_coords=False, edge_embedding_dim=None)
-        ddpm = dict(timesteps=20, noise_schedule="cosine", noise_precision=1e-4,
-                    norm_values=(1.0, 1.0), conditional=True)
-    else:
-        raise KeyError(name)
-    return base, ddpm
+"""ORACLE support: the synthetic-weight generator lives in the package
+(diffsbdd_amd/synthetic.py -- plain data generation, no arithmetic of the hot
+path) so that bench.py's GPU leg does not import from oracle/."""
+from diffsbdd_amd.synthetic import (arch_cfg, dynamics_param_shapes, random_state_dict,  # noqa: F401
+                                    state_dict_checksum)
