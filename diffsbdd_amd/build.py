@@ -11,9 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "engine.hip")
 OUT = os.path.join(HERE, "libdiffsbdd_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("engine.hip", "common.h", "node_linear.h", "edge_mlp.h", "graph.h", "ddpm.h")] + \
-       [os.path.join(ROOT, "include", "diffsbdd_hip.h")]
+def deps():
+    """Every source the library is built from (all of csrc/ + the public header)."""
+    csrc = os.path.join(HERE, "csrc")
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))) + \
+        [os.path.join(ROOT, "include", "diffsbdd_hip.h")]
 
 
 def hipcc_path():
@@ -27,7 +29,7 @@ def up_to_date():
     if not os.path.isfile(OUT):
         return False
     t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(d) <= t for d in DEPS)
+    return all(os.path.getmtime(d) <= t for d in deps())
 
 
 def build(force=False, verbose=True, extra_flags=()):

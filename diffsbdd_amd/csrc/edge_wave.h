@@ -1,0 +1,372 @@
+// Third structure of the fused edge-MLP kernels (same math and arguments as
+// edge_mlp.h -- see there for the algorithm and the reference citations).
+//
+// What the hardware counters said about the LDS-tiled kernel (rocprofv3 --pmc,
+// profiles/): matrix pipe 52 % busy; every wave parked 28 % of its time at
+// barriers / waitcnt and issuing ~5 VALU + 2 LDS instructions per MFMA, most of
+// it to move the *A operand* (gather -> SiLU -> transposed LDS write -> LDS read)
+// and the tile metadata through LDS, with a workgroup barrier every 32 MFMAs.
+//
+// Here the MFMA A-operand layout is used the other way round:
+//
+//   * one wave owns 32 edges x ALL H features.  v_mfma_f32_32x32x2_f32 wants lane l
+//     to supply A[i = l & 31][k = l >> 5]: so lane l simply *is* edge (l & 31); it
+//     keeps that edge's P/Q row pointers, |d|^2, d0 and type in registers, loads
+//     float4 chunks of its own P and Q rows straight from L2 and evaluates
+//     a = SiLU(P + Q + d*wd + d0*wd0 + tab) in registers.  Half-wave h takes
+//     k in {8g + 4h .. 8g + 4h + 3} of every group of 8 (any k pairing is legal as
+//     long as B uses the same one).  No LDS, no transpose, no barrier for A.
+//   * only W2^T goes through LDS (K slices of 32, double buffered, a continuous
+//     stream across tiles): one workgroup barrier per 128 MFMAs per wave.
+//   * the epilogue is wave-private: attention dot by lane shuffles inside each
+//     half-wave (a half-wave holds complete rows), accumulators scaled in place,
+//     segmented row sums walk the rows in edge order with the running sum passed
+//     as a baton between the two half-waves (rows alternate between them in groups
+//     of 4 in the MFMA accumulator layout); one atomic per (row segment, feature).
+//
+// Workgroup = 4 waves = 128 edges; LDS = 2 x 32 x H x 4 B (64 KB at H = 256) +
+// vectors -> 2 workgroups per CU, which overlap each other's epilogues.
+#pragma once
+#include "common.h"
+#include "edge_mlp.h"
+
+namespace dsbdd {
+
+template <int H, int MODE>
+struct WaveLayout {
+  static constexpr int BK = 32;
+  static constexpr int B_BUF = BK * H;
+  static constexpr int NV = (MODE == MODE_GCL) ? 1 : 2;
+  static constexpr int VEC_PER = 7 * H;
+  static constexpr int VEC_OFF = 2 * B_BUF;
+  static constexpr int SCR_OFF = VEC_OFF + NV * VEC_PER;
+  static constexpr int SCR_PER = 32 + 32 * 3;              // per wave: phi[32], trans[32][3]
+  static constexpr int TOTAL = SCR_OFF + 4 * SCR_PER;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave complete in order; this only stops the compiler
+  // from moving the later reads above the earlier writes.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int H, int MODE>
+__global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
+  using L = WaveLayout<H, MODE>;
+  constexpr int BK = L::BK;
+  constexpr int CT = H / 32;            // 32-col MFMA tiles per wave (all features)
+  constexpr int NK = H / BK;            // K slices per unit
+  constexpr int NQ = H / 4;
+  constexpr int BI = BK * NQ / kThreads;   // float4 of a W2^T slice per thread
+  constexpr int BMW = 32, BMB = 128;    // edges per wave / per workgroup
+  static_assert(H % 64 == 0 && H <= 256, "hidden_nf must be 64,128,192 or 256");
+  static_assert((BK * NQ) % kThreads == 0, "B slice split");
+
+  __shared__ float smem[L::TOTAL];
+  float* sB = smem;                         // [2][BK][H]
+  float* sV = smem + L::VEC_OFF;            // per MLP: wd, wd0, tab0..2, b2, w-out
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, j = lane & 31;
+  float* s_phi = smem + L::SCR_OFF + w * L::SCR_PER;   // [32]
+  float* s_tr = s_phi + 32;                             // [32][3]
+  const int n_pass = (MODE == MODE_GCL) ? 1 : p.n_mlp;
+
+  for (int q = 0; q < n_pass; ++q) {
+    const EdgeMlpW& mw = p.mlp[q];
+    float* v = sV + q * L::VEC_PER;
+    for (int i = t; i < H; i += kThreads) {
+      v[i] = mw.wd[i];
+      v[H + i] = mw.wd0[i];
+      v[2 * H + i] = mw.table[i];
+      v[3 * H + i] = mw.table[H + i];
+      v[4 * H + i] = mw.table[2 * H + i];
+      v[5 * H + i] = mw.b2[i];
+      v[6 * H + i] = (MODE == MODE_GCL) ? (p.attention ? p.att_w[i] : 0.f) : p.w3[i];
+    }
+  }
+  const float att_b = (MODE == MODE_GCL && p.attention) ? p.att_b[0] : 0.f;
+  // aggregate / normalization_factor (egnn_new.py:328-329) as one multiply per flushed
+  // segment (<= 1 ulp from the reference's division)
+  const float inv_norm = 1.0f / p.norm_factor;
+
+  const int E = *p.e_count;
+  const int ntiles = (E + BMB - 1) / BMB;
+  const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3, gx = gridDim.x >> 3;
+  const int tq = ntiles / 8, tr = ntiles % 8;
+  const int csize = tq + (xcd < tr ? 1 : 0);
+  const int cbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  if (kx >= csize) return;
+
+  // ---- W2^T slice streaming: direct global -> LDS DMA (global_load_lds, 16 B per lane,
+  // LDS destination = wave-uniform base + lane*16), no staging registers.  The DMA is
+  // tracked by vmcnt; the __syncthreads() that ends a K step drains it (vmcnt(0)) and
+  // publishes the slice to the other waves.
+  auto streamB = [&](int q, int ks, int buf) {
+    const float* src = p.mlp[q].W2T + (size_t)ks * BK * H + t * 4;
+    float* dst = sB + buf * L::B_BUF + w * 256;          // wave-uniform
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + kThreads * 4 * i),
+          (__attribute__((address_space(3))) void*)(dst + kThreads * 4 * i), 16, 0, 0);
+  };
+
+  // ---- this lane's edge (current unit) and the prefetched one (next tile) ----------------
+  int my_r = -1, my_c = 0, my_ty = 0;
+  float my_d = 0.f, my_d0 = 0.f, xr[3] = {0.f, 0.f, 0.f}, xc[3] = {0.f, 0.f, 0.f};
+  int nx_r = -1, nx_c = 0;
+  float nx_d0 = 0.f, nxr[3] = {0.f, 0.f, 0.f}, nxc[3] = {0.f, 0.f, 0.f};
+  auto fetch_idx = [&](int tile) {
+    const int e = tile * BMB + w * BMW + j;
+    nx_r = -1; nx_c = 0; nx_d0 = 0.f;
+    if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
+  };
+  auto fetch_x = [&]() {
+    if (nx_r >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { nxr[k] = p.x[3 * nx_r + k]; nxc[k] = p.x[3 * nx_c + k]; }
+    }
+  };
+  auto commit_edge = [&]() {
+    my_r = nx_r; my_c = nx_c; my_d0 = nx_d0; my_d = 0.f; my_ty = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { xr[k] = nxr[k]; xc[k] = nxc[k]; }
+    if (my_r >= 0) {
+      const float dx = xr[0] - xc[0], dy = xr[1] - xc[1], dz = xr[2] - xc[2];
+      my_d = dx * dx + dy * dy + dz * dz;                  // coord2diff radial, egnn_new.py:298-299
+      const bool rl = my_r < p.n_lig, cl = my_c < p.n_lig;
+      my_ty = (rl && cl) ? 1 : ((!rl && !cl) ? 2 : 0);     // dynamics.py:119-124
+    }
+  };
+
+  // prologue: first W2^T slice, first edge, first P/Q chunk
+  streamB(0, 0, 0);
+  fetch_idx(cbase + kx);
+  fetch_x();
+  commit_edge();
+  __syncthreads();          // sV + slice 0 visible
+  int bslice = 0;           // running slice counter (buffer = bslice & 1)
+
+  const float* Pp = p.mlp[0].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + 4 * half;
+  const float* Qp = p.mlp[0].Q + (size_t)my_c * p.ldpq + 4 * half;
+  float4 pc = ld4(Pp), qc = ld4(Qp), pn = pc, qn4 = qc;
+  float phi0 = 0.f, phi1 = 0.f;
+
+  const int my_tiles = (csize - kx + gx - 1) / gx;
+  const int U = my_tiles * n_pass;
+  int li = kx, q = 0;
+#pragma unroll 1
+  for (int u = 0; u < U; ++u) {
+    const float* vq = sV + q * L::VEC_PER;
+    const bool last_unit = u + 1 == U;
+    const bool tile_ends = q == n_pass - 1;
+    const int qn = tile_ends ? 0 : q + 1;                  // MLP pass of the next unit
+    const bool prefetch_next_tile = tile_ends && !last_unit;
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < NK; ++kt) {
+      const bool more = kt + 1 < NK;
+      if (more) streamB(q, kt + 1, (bslice + 1) & 1);
+      else if (!last_unit) streamB(qn, 0, (bslice + 1) & 1);   // continuous stream across units
+      if (prefetch_next_tile) {                            // next tile's edge, two dependent loads
+        if (kt == 0) fetch_idx(cbase + li + gx);
+        if (kt == 1) fetch_x();
+      }
+      const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + j;
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
+        if (g + 1 < BK / 8 || more) {                      // prefetch the next group's P/Q chunk
+          pn = ld4(Pp + kb + 8);
+          qn4 = ld4(Qp + kb + 8);
+        }
+        const float4 wd4 = *reinterpret_cast<const float4*>(vq + kb + 4 * half);
+        const float4 wz4 = *reinterpret_cast<const float4*>(vq + H + kb + 4 * half);
+        const float4 tb4 = *reinterpret_cast<const float4*>(vq + (2 + my_ty) * H + kb + 4 * half);
+        float a[4];
+        a[0] = silu(pc.x + qc.x + my_d * wd4.x + my_d0 * wz4.x + tb4.x);
+        a[1] = silu(pc.y + qc.y + my_d * wd4.y + my_d0 * wz4.y + tb4.y);
+        a[2] = silu(pc.z + qc.z + my_d * wd4.z + my_d0 * wz4.z + tb4.z);
+        a[3] = silu(pc.w + qc.w + my_d * wd4.w + my_d0 * wz4.w + tb4.w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* brow = bcur + (8 * g + i) * H;
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
+        }
+        pc = pn; qc = qn4;
+      }
+      ++bslice;
+      __syncthreads();
+    }
+
+    // first P/Q chunk of the NEXT unit: in flight during the epilogue
+    if (!last_unit) {
+      const int r_n = tile_ends ? nx_r : my_r, c_n = tile_ends ? nx_c : my_c;
+      Pp = p.mlp[qn].P + (size_t)(r_n < 0 ? 0 : r_n) * p.ldpq + 4 * half;
+      Qp = p.mlp[qn].Q + (size_t)c_n * p.ldpq + 4 * half;
+      pc = ld4(Pp); qc = ld4(Qp);
+    }
+
+    // ================= wave-private epilogue =================
+    if (MODE == MODE_GCL) {
+      // messages m = SiLU(acc + b2)   (egnn_new.py:18-19)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float bv = vq[5 * H + c * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = silu(acc[c][r] + bv);
+      }
+      if (p.attention) {   // att = sigmoid(w_a . m + b_a); a half-wave holds complete rows
+        float part[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const float aw = vq[6 * H + c * 32 + j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[r] += acc[c][r] * aw;
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[r] += __shfl_xor(part[r], o);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = sigmoidf_fast(part[r] + att_b);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][r] *= part[r];       // mij * att, egnn_new.py:40
+      }
+      // segmented sums in edge order; accumulator register rr of half h is row
+      // 8*(rr>>2) + 4*h + (rr&3): rows alternate between the halves in groups of 4
+      // Walk the 32 rows once (row ids are wave-uniform scalars), carrying the CT
+      // column sums of this lane; sub-block gb (rows 4gb..4gb+3) lives in half gb&1.
+      float sum[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) sum[c] = 0.f;
+      int cur = -1;
+      auto flush = [&](int owner) {                        // the owning half holds the full sums
+        if (cur >= 0 && half == owner) {
+          float* dst = p.agg + (size_t)cur * H + j;
+#pragma unroll
+          for (int c = 0; c < CT; ++c) unsafeAtomicAdd(dst + c * 32, sum[c] * inv_norm);
+        }
+      };
+#pragma unroll
+      for (int gb = 0; gb < 8; ++gb) {
+        const int hh = gb & 1;
+        if (gb > 0) {                                      // baton: running sums move to the owning half
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            const float other = __shfl_xor(sum[c], 32);
+            if (half == hh) sum[c] = other;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rn = __builtin_amdgcn_readlane(my_r, 4 * gb + i);
+          if (rn != cur) {                                 // scalar compare / branch
+            flush(hh);
+            cur = rn;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) sum[c] = 0.f;
+          }
+          if (half == hh) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) sum[c] += acc[c][4 * (gb >> 1) + i];
+          }
+        }
+      }
+      flush(1);
+    } else {
+      // scalar head: phi = w3 . SiLU(acc + b2)   (egnn_new.py:80-92)
+      float part[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float bv = vq[5 * H + c * 32 + j], wv = vq[6 * H + c * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] += silu(acc[c][r] + bv) * wv;
+      }
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] += __shfl_xor(part[r], o);
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_phi[mfma_row(r, lane)] = part[r];
+      }
+      wave_lds_fence();
+      const float ph = s_phi[j];                            // this lane's edge
+      wave_lds_fence();
+      if (q == 0) phi0 = ph; else phi1 = ph;
+
+      if (tile_ends) {
+        // trans = u*phi + cross*phi_x   (egnn_new.py:100-109, 296-316); lane = edge
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (my_r >= 0) {
+          const float dx = xr[0] - xc[0], dy = xr[1] - xc[1], dz = xr[2] - xc[2];
+          const float den = sqrtf(my_d + 1e-8f) + p.norm_constant;
+          const float ux = dx / den, uy = dy / den, uz = dz / den;
+          if (p.use_tanh) {
+            const float th = tanhf(phi0);
+            tx = ux * th * p.coords_range; ty = uy * th * p.coords_range; tz = uz * th * p.coords_range;
+          } else {
+            tx = ux * phi0; ty = uy * phi0; tz = uz * phi0;
+          }
+          if (p.n_mlp == 2) {
+            const int b = p.node_batch[my_r];
+            const float m0 = p.mean[3 * b], m1 = p.mean[3 * b + 1], m2 = p.mean[3 * b + 2];
+            const float a0 = xr[0] - m0, a1 = xr[1] - m1, a2 = xr[2] - m2;
+            const float b0 = xc[0] - m0, b1 = xc[1] - m1, b2 = xc[2] - m2;
+            const float c0 = a1 * b2 - a2 * b1, c1 = a2 * b0 - a0 * b2, c2 = a0 * b1 - a1 * b0;
+            const float cden = sqrtf(c0 * c0 + c1 * c1 + c2 * c2) + p.norm_constant;
+            float phx = phi1;
+            if (p.use_tanh) phx = tanhf(phx) * p.coords_range;
+            tx += c0 / cden * phx; ty += c1 / cden * phx; tz += c2 / cden * phx;
+          }
+        }
+        if (half == 0) { s_tr[3 * j] = tx; s_tr[3 * j + 1] = ty; s_tr[3 * j + 2] = tz; }
+        wave_lds_fence();
+        if (lane < 3) {
+          int cur = -1;
+          float sum = 0.f;
+#pragma unroll
+          for (int e = 0; e < 32; ++e) {
+            const int rn = __builtin_amdgcn_readlane(my_r, e);
+            if (rn != cur) {
+              if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + lane], sum / p.norm_factor);
+              cur = rn;
+              sum = 0.f;
+            }
+            sum += s_tr[3 * e + lane];
+          }
+          if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + lane], sum / p.norm_factor);
+        }
+        wave_lds_fence();   // scratch is reused by the next tile
+      }
+    }
+
+    // advance to the next unit
+    if (tile_ends) {
+      if (!last_unit) commit_edge();
+      li += gx;
+      q = 0;
+    } else {
+      ++q;
+    }
+  }  // units
+}
+
+}  // namespace dsbdd

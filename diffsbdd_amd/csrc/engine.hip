@@ -13,6 +13,8 @@
 #include "common.h"
 #include "ddpm.h"
 #include "edge_mlp.h"
+#include "edge_pipe.h"
+#include "edge_wave.h"
 #include "graph.h"
 #include "node_linear.h"
 
@@ -40,10 +42,13 @@ struct dsbdd_engine {
   size_t ws_bytes = 0;
   int64_t cap_lig = 0, cap_poc = 0, cap_batch = 0, cap_edges = 0;
   int *node_batch, *lig_off, *poc_off, *deg, *row_ptr, *erow, *ecol;
+  int *act_flag, *act_ptr, *act_list;
   float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *hout;
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   int edge_bm = 64;    // 64-edge tiles, 2 workgroups per CU (measured faster than 128 / 1)
+  int edge_pipe = 0;   // 1 = wave-specialised pipelined variant (edge_pipe.h): correct, but measured slower
+  int edge_wave = 1;   // wave-owns-32-edges kernel with register-resident A operand (edge_wave.h)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
   bool profile = false;
   std::vector<hipEvent_t> ev;   // pairs: start, stop
@@ -81,7 +86,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * 12, (size_t)N * 12, (size_t)N * 12, (size_t)B * 12,                               // 8-11 x x_in xagg mean
       (size_t)N * JP * 4, (size_t)N * LE * 4,                                                       // 12 h0, 13 enc_tmp
       (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * PQ * 4,                  // 14 h 15 t1 16 agg 17 pq
-      (size_t)N * JP * 4};                                                                          // 18 hout
+      (size_t)N * JP * 4,                                                                           // 18 hout
+      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4};                                           // 19-21 act flag/ptr/list
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -114,6 +120,9 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
     e->n_cu = prop.multiProcessorCount;
   const char* bm = getenv("DSBDD_EDGE_TILE");
   if (bm && atoi(bm) == 128) e->edge_bm = 128;
+  const char* ek = getenv("DSBDD_EDGE_KERNEL");
+  if (ek && !strcmp(ek, "pipe")) { e->edge_pipe = 1; e->edge_wave = 0; }
+  if (ek && !strcmp(ek, "tiled")) { e->edge_pipe = 0; e->edge_wave = 0; }
   *out = e;
   return DSBDD_OK;
 }
@@ -173,6 +182,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->mean = (float*)(b + L.off[11]); e->h0 = (float*)(b + L.off[12]); e->enc_tmp = (float*)(b + L.off[13]);
   e->h = (float*)(b + L.off[14]); e->t1 = (float*)(b + L.off[15]); e->agg = (float*)(b + L.off[16]);
   e->pq = (float*)(b + L.off[17]); e->hout = (float*)(b + L.off[18]);
+  e->act_flag = (int*)(b + L.off[19]); e->act_ptr = (int*)(b + L.off[20]); e->act_list = (int*)(b + L.off[21]);
   return DSBDD_OK;
 }
 
@@ -230,7 +240,14 @@ int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** out) {
 static hipError_t nl(hipStream_t s, const float* A1, int lda1, int K1, const float* A2, int lda2, int K2,
                      const float* WT, int ldw, const float* bias, const float* R, int ldr, float* C,
                      int ldc, int64_t M, int N, int act) {
-  NodeLinearArgs a{A1, lda1, K1, A2, lda2, K2, WT, ldw, bias, R, ldr, C, ldc, (int)M, N, act};
+  NodeLinearArgs a{A1, lda1, K1, A2, lda2, K2, WT, ldw, bias, R, ldr, C, ldc, (int)M, N, act, nullptr, nullptr};
+  return launch_node_linear(s, a);
+}
+
+// same, over the gathered row subset row_idx[0 .. *m_count)
+static hipError_t nl_rows(hipStream_t s, const float* A1, int lda1, int K1, const float* WT, int ldw, float* C,
+                          int ldc, int64_t M_cap, int N, const int* row_idx, const int* m_count) {
+  NodeLinearArgs a{A1, lda1, K1, nullptr, 0, 0, WT, ldw, nullptr, nullptr, 0, C, ldc, (int)M_cap, N, 0, row_idx, m_count};
   return launch_node_linear(s, a);
 }
 
@@ -243,9 +260,54 @@ static hipError_t launch_edge_t(hipStream_t s, int mode, const EdgeArgs& a, int 
   return hipGetLastError();
 }
 
+template <int H>
+static hipError_t launch_pipe_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+  if (mode == MODE_GCL)
+    hipLaunchKernelGGL((edge_pipe_kernel<H, MODE_GCL>), dim3(grid), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((edge_pipe_kernel<H, MODE_COORD>), dim3(grid), dim3(512), 0, s, a);
+  return hipGetLastError();
+}
+
+template <int H>
+static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+  if (mode == MODE_GCL)
+    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
+  return hipGetLastError();
+}
+
 static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
                               int64_t edge_bound) {
   const int H = e->cfg.hidden_nf;
+  if (e->edge_wave) {   // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU
+    int64_t tiles = (edge_bound + 127) / 128;
+    int64_t resident = 2LL * e->n_cu;
+    int64_t g = tiles < resident ? tiles : resident;
+    int grid = (int)((g + 7) / 8 * 8);
+    if (grid < 8) grid = 8;
+    switch (H) {
+      case 64: return launch_wave_t<64>(s, mode, a, grid);
+      case 128: return launch_wave_t<128>(s, mode, a, grid);
+      case 192: return launch_wave_t<192>(s, mode, a, grid);
+      case 256: return launch_wave_t<256>(s, mode, a, grid);
+    }
+    return hipErrorInvalidValue;
+  }
+  if (e->edge_pipe) {   // 64-edge tiles, one 512-thread workgroup per CU
+    int64_t tiles = (edge_bound + 63) / 64;
+    int64_t g = tiles < e->n_cu ? tiles : e->n_cu;
+    int grid = (int)((g + 7) / 8 * 8);
+    if (grid < 8) grid = 8;
+    switch (H) {
+      case 64: return launch_pipe_t<64>(s, mode, a, grid);
+      case 128: return launch_pipe_t<128>(s, mode, a, grid);
+      case 192: return launch_pipe_t<192>(s, mode, a, grid);
+      case 256: return launch_pipe_t<256>(s, mode, a, grid);
+    }
+    return hipErrorInvalidValue;
+  }
   const int bm = e->edge_bm;
   int64_t tiles = (edge_bound + bm - 1) / bm;
   int64_t resident = (int64_t)e->n_cu * (bm == 64 ? 2 : 1);
@@ -273,7 +335,8 @@ static Cutoffs cutoffs_of(const dsbdd_config& c) {
 
 static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int B, const dsbdd_config& c,
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
-                            int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status) {
+                            int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
+                            int* act_flag = nullptr) {
   const int waves_per_block = kThreads / 64;
   int blocks = (N + waves_per_block - 1) / waves_per_block;
   if (blocks > 4096) blocks = 4096;
@@ -281,12 +344,13 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   const Cutoffs cut = cutoffs_of(c);
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status);
+                     (float*)nullptr, 0, status, act_flag);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
-                     poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status);
+                     poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
+                     (int*)nullptr);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -320,6 +384,9 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
   const int PQ = (c.reflection_equivariant ? 2 : 4) * H;
   const float* const* W = e->slots.data();
   if (N == 0) return DSBDD_OK;
+  // pocket-conditioning mode: the coordinate MLPs only touch edges whose row is a ligand
+  // node, so their first-layer projections are needed for a subset of the nodes only
+  const bool subset = !c.update_pocket_coords;
 
   // ---- masks -> offsets, split inputs ---------------------------------------
   {
@@ -355,10 +422,27 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->deg, e->row_ptr, N);
     HIP_TRY(hipGetLastError());
     edge_bound = ext_n_edges > 0 ? ext_n_edges : 1;
+    if (subset) {
+      hipLaunchKernelGGL(ext_flags_init_kernel, dim3((N + 255) / 256), dim3(256), 0, s, e->act_flag, nlig, N);
+      HIP_TRY(hipGetLastError());
+      if (ext_n_edges > 0) {
+        hipLaunchKernelGGL(ext_flags_kernel, dim3((int)((ext_n_edges + 255) / 256)), dim3(256), 0, s, ext_row,
+                           ext_col, (int)ext_n_edges, nlig, e->act_flag);
+        HIP_TRY(hipGetLastError());
+      }
+    }
   } else {
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
-                              e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status);
+                              e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
+                              subset ? e->act_flag : nullptr);
     if (rc) return rc;
+  }
+  if (subset) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(compact_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const int*)e->act_flag,
+                       (const int*)e->act_ptr, e->act_list, N);
+    HIP_TRY(hipGetLastError());
   }
   // ---- embedding (egnn_new.py:233) ---------------------------------------------
   HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
@@ -400,20 +484,29 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
     }
     {
       auto Q = [&](int which) { return W[eq_slot(c, blk, which)]; };
-      HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ, N, PQ, 0));
+      // first-layer projections, column order [Q_coord | Q_cross | P_coord | P_cross]
+      const int QW = n_mlp * H;   // width of the Q (column-node) part
+      if (subset) {
+        HIP_TRY(nl_rows(s, e->h, H, H, Q(DSBDD_EQ_C1_WT), PQ, e->pq, PQ, N, QW, e->act_list, e->act_ptr + N));
+        HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT) + QW, PQ, nullptr, nullptr, 0, e->pq + QW, PQ,
+                   n_lig, QW, 0));
+      } else {
+        HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ, N, PQ, 0));
+      }
       EdgeArgs ea{};
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = PQ;
-      ea.mlp[0] = EdgeMlpW{e->pq, e->pq + H, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
+      ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
                            Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2)};
       if (n_mlp == 2)
-        ea.mlp[1] = EdgeMlpW{e->pq + 2 * H, e->pq + 3 * H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
+        ea.mlp[1] = EdgeMlpW{e->pq + QW + H, e->pq + H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
                              Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2)};
       else
         ea.mlp[1] = ea.mlp[0];
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
       ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
       ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.norm_factor = c.normalization_factor;
+     
       HIP_TRY(launch_edge(e, s, MODE_COORD, ea, edge_bound));
       hipLaunchKernelGGL(coord_update_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, s, e->x, e->xagg,
                          3 * n_upd, 3 * N);

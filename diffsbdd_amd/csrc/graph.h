@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const float* __restrict__ x, const int* __restrict__ node_batch,
     const int* __restrict__ lig_off, const int* __restrict__ poc_off, int n_lig, int n_nodes,
     Cutoffs cut, int* __restrict__ deg, const int* __restrict__ row_ptr, int* __restrict__ erow,
-    int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status) {
+    int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status,
+    int* __restrict__ act_flag) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const bool il = i < n_lig;
     const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
     const int base = FILL ? row_ptr[i] : 0;
-    int cnt = 0;
+    int cnt = 0, cnt_lig = 0;
 #pragma unroll 1
     for (int seg = 0; seg < 2; ++seg) {
       const int j_begin = seg == 0 ? lig_off[b] : n_lig + poc_off[b];
@@ -85,8 +86,14 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
         }
         cnt += __popcll(m);
       }
+      if (seg == 0) cnt_lig = cnt;
     }
-    if (!FILL && lane == 0) deg[i] = cnt;
+    if (!FILL && lane == 0) {
+      deg[i] = cnt;
+      // "active" for the coordinate MLPs in pocket-conditioning mode: ligand nodes and
+      // pocket nodes that are a column of some ligand-row edge (graph is symmetric)
+      if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
+    }
     if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
   }
 }
@@ -123,6 +130,22 @@ __global__ void ext_edges_kernel(const int* row, const int* col, int E, const fl
   const float dx = x[3 * r] - x[3 * c], dy = x[3 * r + 1] - x[3 * c + 1], dz = x[3 * r + 2] - x[3 * c + 2];
   ed0[e] = dx * dx + dy * dy + dz * dz;
   atomicAdd(&deg[r], 1);
+}
+
+// Active-node flags for a teacher-forced edge list: ligand nodes, plus every column
+// of an edge whose row is a ligand node.
+__global__ void ext_flags_init_kernel(int* flag, int n_lig, int n_nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_nodes) flag[i] = i < n_lig ? 1 : 0;
+}
+__global__ void ext_flags_kernel(const int* row, const int* col, int E, int n_lig, int* flag) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E && row[e] < n_lig) flag[col[e]] = 1;   // benign race: all writers store 1
+}
+// list[ptr[i]] = i for flagged nodes (ptr = exclusive scan of flag): sorted node list.
+__global__ void compact_kernel(const int* flag, const int* ptr, int* list, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) list[ptr[i]] = i;
 }
 
 // x[N][3] <- coordinates of both node sets; h0[:, J] <- t[sample]; pad columns

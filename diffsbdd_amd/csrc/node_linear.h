@@ -27,6 +27,10 @@ struct NodeLinearArgs {
   const float* R; int ldr;
   float* C; int ldc;
   int M; int N; int act;
+  // optional row gather: logical row m -> physical row row_idx[m] of A1/A2/R/C, with
+  // the number of logical rows read from device memory (min(M, *m_count)); used for
+  // the active-node subset of the coordinate-MLP projections
+  const int* row_idx; const int* m_count;
 };
 
 template <int BM, bool VEC_A>
@@ -41,6 +45,8 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int K = p.K1 + p.K2;
+  const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
+  if (m0 >= M) return;   // uniform per workgroup
 
   f32x16 acc[RT][2];
 #pragma unroll
@@ -57,9 +63,10 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int m = m0 + a_m + 32 * i, k = k0 + a_kq;
+      const int ml = m0 + a_m + 32 * i, k = k0 + a_kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.M) {
+      if (ml < M) {
+        const int m = p.row_idx ? p.row_idx[ml] : ml;
         if (VEC_A) {
           if (k < K) {
             const float* src = (k < p.K1) ? p.A1 + (size_t)m * p.lda1 + k
@@ -137,8 +144,9 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
       const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + mfma_row(r, lane);
-        if (row >= p.M) continue;
+        const int rowl = m0 + wm * (BM / 2) + i * 32 + mfma_row(r, lane);
+        if (rowl >= M) continue;
+        const int row = p.row_idx ? p.row_idx[rowl] : rowl;
         float v = acc[i][j][r] + bv;
         if (p.act == 1) v = silu(v);
         if (p.R) v += p.R[(size_t)row * p.ldr + col];
@@ -157,7 +165,7 @@ inline hipError_t launch_node_linear(hipStream_t s, const NodeLinearArgs& a) {
                    (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
   const int ny = (a.N + 127) / 128;
   const long tiles128 = (long)((a.M + 127) / 128) * ny;
-  const bool big = tiles128 >= 512;  // enough 128-row tiles to fill 256 CUs twice
+  const bool big = tiles128 >= 512 && !a.row_idx;  // enough 128-row tiles to fill 256 CUs twice
   const int bm = big ? 128 : 64;
   dim3 grid((a.M + bm - 1) / bm, ny), block(kThreads);
   if (big) {

@@ -106,12 +106,12 @@ def pack_weights(sd, cfg, device):
         p = f"egnn.e_block_{i}.gcl_equiv"
         c_row, c_col, c_wd, c_wd0, c_tab = first_layer(p + ".coord_mlp.0")
         if cfg.reflection_equivariant:
-            eq = [torch.cat([c_row, c_col], 1).contiguous(), c_wd, c_wd0, c_tab,
+            eq = [torch.cat([c_col, c_row], 1).contiguous(), c_wd, c_wd0, c_tab,
                   wt(p + ".coord_mlp.2.weight"), vec(p + ".coord_mlp.2.bias"),
                   None, None, None, None, None]
         else:
             x_row, x_col, x_wd, x_wd0, x_tab = first_layer(p + ".cross_product_mlp.0")
-            eq = [torch.cat([c_row, c_col, x_row, x_col], 1).contiguous(), c_wd, c_wd0, c_tab,
+            eq = [torch.cat([c_col, x_col, c_row, x_row], 1).contiguous(), c_wd, c_wd0, c_tab,
                   wt(p + ".coord_mlp.2.weight"), vec(p + ".coord_mlp.2.bias"),
                   x_wd, x_wd0, x_tab,
                   wt(p + ".cross_product_mlp.2.weight"), vec(p + ".cross_product_mlp.2.bias")]

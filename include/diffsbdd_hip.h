@@ -103,8 +103,9 @@ enum {
   DSBDD_GCL_COUNT
 };
 enum {
-  DSBDD_EQ_C1_WT = 0,  /* [H][4H]: coord row | coord col | cross row | cross col
-                          ([H][2H] if reflection_equivariant)                   */
+  DSBDD_EQ_C1_WT = 0,  /* [H][4H]: coord col | cross col | coord row | cross row parts of
+                          {coord,cross_product}_mlp.0.weight^T ([H][2H]: coord col |
+                          coord row if reflection_equivariant)                  */
   DSBDD_EQ_C_WD,       /* coord_mlp: same five slots as the GCL edge MLP        */
   DSBDD_EQ_C_WD0, DSBDD_EQ_C_TAB, DSBDD_EQ_C_W2T, DSBDD_EQ_C_B2,
   DSBDD_EQ_X_WD,       /* cross_product_mlp (ignored if reflection_equivariant) */

@@ -128,7 +128,16 @@ def forward(cfg, slots, xh_lig, xh_pocket, t, mask_l, mask_p, edges=None, trace=
         pq = node_linear(h, H, None, 0, eq(blk, "C1_WT"), None, None, PQ, 0)
         ru, cu, du, d0u, tu = row[:e_upd], col[:e_upd], d[:e_upd], d0[:e_upd], typ[:e_upd]
         w3 = eq(blk, "W3")
-        a1 = edge_mlp_first(pq[:, :H], pq[:, H:2 * H], ru, cu, du, d0u, tu, eq(blk, "C_WD"), eq(blk, "C_WD0"),
+        QW = n_mlp * H   # column order [Q_coord | Q_cross | P_coord | P_cross]
+        if not c.update_pocket_coords:
+            # engine computes the Q part only for active nodes and the P part only for ligand rows
+            active = torch.zeros(N, dtype=torch.bool)
+            active[:nl] = True
+            active[cu] = True
+            pq = pq.clone()
+            pq[~active, :QW] = float("nan")
+            pq[nl:, QW:] = float("nan")
+        a1 = edge_mlp_first(pq[:, QW:QW + H], pq[:, :H], ru, cu, du, d0u, tu, eq(blk, "C_WD"), eq(blk, "C_WD0"),
                             eq(blk, "C_TAB"))
         phi = F.silu(a1 @ eq(blk, "C_W2T")[:, :H] + eq(blk, "C_B2")) @ w3
         diff = x[ru] - x[cu]
@@ -138,7 +147,7 @@ def forward(cfg, slots, xh_lig, xh_pocket, t, mask_l, mask_p, edges=None, trace=
         else:
             trans = u * phi[:, None]
         if n_mlp == 2:
-            a1 = edge_mlp_first(pq[:, 2 * H:3 * H], pq[:, 3 * H:4 * H], ru, cu, du, d0u, tu, eq(blk, "X_WD"),
+            a1 = edge_mlp_first(pq[:, QW + H:QW + 2 * H], pq[:, H:2 * H], ru, cu, du, d0u, tu, eq(blk, "X_WD"),
                                 eq(blk, "X_WD0"), eq(blk, "X_TAB"))
             phx = F.silu(a1 @ eq(blk, "X_W2T")[:, :H] + eq(blk, "X_B2")) @ w3
             if c.use_tanh:

@@ -237,24 +237,32 @@ def test_se3_equivariance_full_size(arch):
     assert (a_p[:, 3:] - b_p[:, 3:]).abs().max().item() < TOL
 
 
-def test_determinism_and_edge_tile_variants():
-    """Same inputs -> bitwise identical outputs (segmented sums, <= 2 commuting
-    atomics per address); the 64-edge-tile kernel variant agrees to roundoff."""
+def test_run_to_run_agreement_and_kernel_variants():
+    """The default edge kernel (edge_wave.h) aggregates a row whose edges span
+    several 32-edge wave tiles with <= 3 atomic partial sums: run-to-run results
+    agree to fp32 summation order (1e-6), not bitwise.  The LDS-tiled kernel
+    (edge_mlp.h, both tile sizes) IS bitwise reproducible and all variants agree
+    with each other to roundoff."""
     import os
     c = Case("dyn_fullatom_cond")
     sd = c.state_dict()
-    m = make_dynamics(c.cfg, sd)
     args = (c.t("xh_lig"), c.t("xh_pocket"), c.t("t"), c.t("mask_lig"), c.t("mask_pocket"))
+    m = make_dynamics(c.cfg, sd)
     a, _, _ = m.forward_async(*args)
     b, _, _ = m.forward_async(*args)
-    assert torch.equal(a, b)
-    os.environ["DSBDD_EDGE_TILE"] = "64"
-    try:
-        m2 = make_dynamics(c.cfg, sd)
-        d, _, _ = m2.forward_async(*args)
-    finally:
-        del os.environ["DSBDD_EDGE_TILE"]
-    assert (a - d).abs().max().item() < 1e-5
+    assert (a - b).abs().max().item() < 1e-6
+    outs = {}
+    for kern, tile in (("tiled", "64"), ("tiled", "128"), ("pipe", "64")):
+        os.environ["DSBDD_EDGE_KERNEL"], os.environ["DSBDD_EDGE_TILE"] = kern, tile
+        try:
+            mv = make_dynamics(c.cfg, sd)
+            d1, _, _ = mv.forward_async(*args)
+            d2, _, _ = mv.forward_async(*args)
+        finally:
+            del os.environ["DSBDD_EDGE_KERNEL"], os.environ["DSBDD_EDGE_TILE"]
+        assert torch.equal(d1, d2), (kern, tile)          # segmented sums: <= 2 commuting atomics per address
+        assert (a - d1).abs().max().item() < 1e-5, (kern, tile)
+        assert (d1.cpu() - c.t("eps_lig")).abs().max().item() < TOL, (kern, tile)
 
 
 # ---------------------------------------------------------------------------
