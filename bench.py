@@ -185,7 +185,7 @@ def main():
         # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
         bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E + 3 * N + N * H)
         roofline = {
-            "bound": "mfma", "kernel": "edge_mlp_kernel<MODE_GCL> (fused GCL edge stage)",
+            "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
             "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
             "traffic": None,

@@ -156,6 +156,90 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Same GEMM with the structure of edge_wave.h, for the aligned big layers
+// (K1, K2 multiples of 32; N multiple of 64; 16-byte aligned rows):
+//   * lane l IS row (l & 31) of the wave's 32-row tile and reads float4 chunks of its
+//     own row straight from L2 -- the MFMA A operand never touches LDS;
+//   * the weight slice [32][64] is streamed by global_load_lds (double buffered, one
+//     barrier per K step); workgroup = 4 waves x 32 rows = 128 rows x 64 columns.
+template <int DUMMY>
+__global__ __launch_bounds__(kThreads) void node_linear_wave_kernel(NodeLinearArgs p) {
+  constexpr int BN = 64, BK = 32, CT = BN / 32;     // (BK = 64 measured no faster: the A-row loads bound it)
+  __shared__ float sB[2 * BK * BN];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, j = lane & 31;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+  const int K = p.K1 + p.K2;
+  const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
+  if (m0 >= M) return;   // uniform per workgroup
+
+  // weight slice ks -> LDS buffer: [BK][BN] floats = BK*16 float4, BK/16 per thread
+  auto streamB = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < BK / 16; ++i) {
+      const int f = t + kThreads * i;              // float4 index: row f/16, col chunk f%16
+      const float* src = p.WT + (size_t)(ks * BK + (f >> 4)) * p.ldw + n0 + (f & 15) * 4;
+      float* dst = sB + buf * BK * BN + (w * 64 + kThreads * i) * 4;   // wave-uniform base
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  const int rowl = m0 + w * 32 + j;
+  const bool valid = rowl < M;
+  const int row = valid ? (p.row_idx ? p.row_idx[rowl] : rowl) : 0;
+  const float* a1 = p.A1 + (size_t)row * p.lda1 + 4 * half;
+  const float* a2 = p.K2 ? p.A2 + (size_t)row * p.lda2 + 4 * half : a1;
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  streamB(0, 0);
+  float4 ac = ld4(a1), an = ac;
+  __syncthreads();
+  const int nk = K / BK;
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) streamB(kt + 1, (kt + 1) & 1);
+    const float* bcur = sB + (kt & 1) * BK * BN + (4 * half) * BN + j;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      const int kn = kt * BK + 8 * (g + 1);        // first k of the next group
+      if (kn < K) an = ld4(kn < p.K1 ? a1 + kn : a2 + (kn - p.K1));
+      const float a[4] = {ac.x, ac.y, ac.z, ac.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* brow = bcur + (8 * g + i) * BN;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
+      }
+      ac = an;
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int col = n0 + c * 32 + j;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = m0 + w * 32 + mfma_row(r, lane);
+      if (rl >= M) continue;
+      const int ro = p.row_idx ? p.row_idx[rl] : rl;
+      float v = acc[c][r] + bv;
+      if (p.act == 1) v = silu(v);
+      if (p.R) v += p.R[(size_t)ro * p.ldr + col];
+      p.C[(size_t)ro * p.ldc + col] = v;
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Host-side launcher.  Returns hipError_t of the launch.
@@ -163,6 +247,13 @@ inline hipError_t launch_node_linear(hipStream_t s, const NodeLinearArgs& a) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   const bool vec = aligned16(a.A1) && (a.lda1 % 4 == 0) && (a.K1 % 4 == 0) &&
                    (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
+  // aligned big layers: register-A / LDS-DMA kernel
+  if (vec && a.K1 % 32 == 0 && a.K2 % 32 == 0 && a.N % 64 == 0 && a.ldw % 4 == 0 && aligned16(a.WT) &&
+      (long)a.M * a.N >= 64 * 1024) {
+    dim3 grid((a.M + 127) / 128, a.N / 64), block(kThreads);
+    hipLaunchKernelGGL((node_linear_wave_kernel<0>), grid, block, 0, s, a);
+    return hipGetLastError();
+  }
   const int ny = (a.N + 127) / 128;
   const long tiles128 = (long)((a.M + 127) / 128) * ny;
   const bool big = tiles128 >= 512 && !a.row_idx;  // enough 128-row tiles to fill 256 CUs twice
