@@ -184,11 +184,18 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if kern_n else None
         # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
         bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E + 3 * N + N * H)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if args.workload == "crossdock_fullatom_cond" and B == 64 and os.path.isfile(tpath):
+            # PMC counters cannot be read from inside this process; the figure is the one measured
+            # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
         roofline = {
             "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
             "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E,
             "algorithmic_flops_per_launch": flops_per_launch,
             "kernel_share_of_wall": (kern_ms * 1e-3 / elapsed) * (args.steps * n_calls * cfg["n_layers"]
