@@ -122,9 +122,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
-    rank, local_rank, world = sharding.init_distributed()
+    rank, local_rank, world = sharding.init_distributed(args.backend)
+    if args.share_gpu:
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
@@ -155,6 +160,7 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize(device)
 
+    red_dev = device if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     for w in range(args.warmup):
         chain(100 + w)
     sync()
@@ -167,7 +173,7 @@ def main():
     kern_ms, kern_n = eng.profile_read()
     eng.profile(False, 0)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 

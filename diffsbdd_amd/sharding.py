@@ -31,7 +31,7 @@ def shard_range(n_total: int, world: int, rank: int):
     return lo, hi
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, one_gpu_per_rank=True):
     """Initialise torch.distributed from the torchrun environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns
     (rank, local_rank, world).  A single process (no env) is world 1."""
@@ -45,7 +45,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         # dmabuf IPC is the only mode the host driver supports (see task notes)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+        if backend == "nccl" and one_gpu_per_rank:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
@@ -61,7 +61,11 @@ def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return out_lig, lig_mask + sample_lo
     world = dist.get_world_size(group)
-    dev = out_lig.device
+    # RCCL ("nccl") moves device tensors; gloo (CPU tests, or several ranks sharing one GPU)
+    # needs host tensors
+    out_dev = out_lig.device
+    dev = out_dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    out_lig, lig_mask = out_lig.to(dev), lig_mask.to(dev)
     n_rows = torch.tensor([out_lig.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n_rows, group=group)
@@ -74,7 +78,7 @@ def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int
     payload[:out_lig.shape[0], D] = (lig_mask + sample_lo).to(torch.float64)
     bufs = [torch.zeros_like(payload) for _ in range(world)]
     dist.all_gather(bufs, payload, group=group)
-    rows = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    rows = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(out_dev)
     return rows[:, :D].to(out_lig.dtype), rows[:, D].round().to(torch.int64)
 
 

@@ -429,3 +429,26 @@ def test_keyed_noise_statistics_and_sharding():
                                      C.c_uint64(7), C.c_uint64(4), 0))
     torch.cuda.synchronize()
     assert not torch.equal(out2, out[8 * n:])
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    """The N > 1 path of bench.py end to end (torch.distributed.run launch, per-rank
+    sample offsets, gather of the finished ligands, max-over-ranks timing) with two
+    ranks on the one available GPU over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--timesteps", "3", "--batch", "4",
+           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout            # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert d["value"] > 0 and d["unit"] == "ligands/s" and d["cpu_baseline"] is None
