@@ -452,3 +452,88 @@ def test_bench_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert d["value"] > 0 and d["unit"] == "ligands/s" and d["cpu_baseline"] is None
+
+
+# ---------------------------------------------------------------------------
+# edge cases beyond the goldens (oracle computed on the spot)
+# ---------------------------------------------------------------------------
+def _random_problem(cfg, n_lig, n_poc, seed, lig_shift=None, spread=3.0):
+    g = torch.Generator().manual_seed(seed)
+    B = len(n_lig)
+    ml = torch.repeat_interleave(torch.arange(B), torch.tensor(n_lig))
+    mp = torch.repeat_interleave(torch.arange(B), torch.tensor(n_poc))
+    xl = torch.randn(len(ml), 3, generator=g) * spread
+    if lig_shift is not None:
+        xl = xl + torch.tensor(lig_shift)[ml]
+    xp = torch.randn(len(mp), 3, generator=g) * 6.0
+    hl = torch.randn(len(ml), cfg["atom_nf"], generator=g)
+    hp = torch.randn(len(mp), cfg["residue_nf"], generator=g)
+    t = torch.rand(B, 1, generator=g)
+    return torch.cat([xl, hl], 1), torch.cat([xp, hp], 1), t, ml, mp
+
+
+@pytest.mark.parametrize("arch,kernel", [("small_cond", "wave"), ("small_cond", "tiled"), ("small_variant", "wave"),
+                                         ("small_joint", "wave")])
+def test_rows_spanning_many_tiles(arch, kernel):
+    """A 150-atom ligand: fully connected ligand rows have degree > 150, so one
+    row's edge segment spans 5+ wave tiles / 2+ workgroup tiles."""
+    import os
+    cfg, _ = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, 3)
+    xl, xp, t, ml, mp = _random_problem(cfg, [150, 3, 40], [40, 30, 5], seed=11,
+                                        spread=0.5 if arch == "small_joint" else 3.0)
+    o_l, o_p, edges = eo.dynamics_forward(sd, cfg, xl, xp, t, ml, mp)
+    os.environ["DSBDD_EDGE_KERNEL"] = kernel
+    try:
+        m = make_dynamics(cfg, sd)
+        e_l, e_p, st = m.forward_async(xl, xp, t, ml, mp, edges=edges)
+        f_l, f_p = m(xl.to(dev()), xp.to(dev()), t.to(dev()), ml.to(dev()), mp.to(dev()))   # device-built edges
+    finally:
+        del os.environ["DSBDD_EDGE_KERNEL"]
+    assert int(st.item()) == 0
+    assert excess(e_l, o_l) <= 0 and excess(e_p, o_p) <= 0
+    er, ec = m.engine().last_edges(len(ml) + len(mp))
+    if er.numel() == edges.shape[1] and torch.equal(er, edges[0]) and torch.equal(ec, edges[1]):
+        assert excess(f_l, o_l) <= 0 and excess(f_p, o_p) <= 0
+
+
+def test_ligand_without_pocket_neighbours_and_batch_of_one():
+    """No interaction edges at all (ligand 100 A away): the active-node list is
+    the ligand alone; and a single sample with a single t (dynamics.py:105-107)."""
+    cfg, _ = W.arch_cfg("small_cond")
+    sd = W.random_state_dict(cfg, 5)
+    xl, xp, t, ml, mp = _random_problem(cfg, [6], [25], seed=2, lig_shift=[[100.0, 0.0, 0.0]])
+    t1 = t.reshape(1, 1)
+    o_l, o_p, edges = eo.dynamics_forward(sd, cfg, xl, xp, t1, ml, mp)
+    assert int(((edges[0] < 6) & (edges[1] >= 6)).sum()) == 0
+    m = make_dynamics(cfg, sd)
+    f_l, f_p = m(xl.to(dev()), xp.to(dev()), t1.to(dev()), ml.to(dev()), mp.to(dev()))
+    assert excess(f_l, o_l) <= 0 and excess(f_p, o_p) <= 0
+    assert f_p[:, :3].abs().max().item() == 0.0          # pocket coordinates are not updated
+
+
+def test_joint_full_width_inpaint_runs_at_scale():
+    """moad_fullatom_joint (H = 192, edge-type embedding, pocket coordinates updated):
+    RePaint with resamplings = 2 as BASELINE configs[4] uses it, 8 pockets, 3 steps:
+    finite, COM-free, one-hot, fixed pocket returned unchanged up to the rigid shift."""
+    from diffsbdd_amd.en_diffusion import EnVariationalDiffusion
+    cfg, dd = W.arch_cfg("moad_fullatom_joint")
+    sd = W.random_state_dict(cfg, 0)
+    model = EnVariationalDiffusion(dynamics=make_dynamics(cfg, sd), atom_nf=10, residue_nf=10, n_dims=3,
+                                   size_histogram=np.ones((4, 8)), timesteps=dd["timesteps"],
+                                   noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
+                                   loss_type="l2", norm_values=dd["norm_values"]).to(dev())
+    _, _, pocket = _bench_problem("crossdock_fullatom_cond", 8)
+    B, nl = 8, 23
+    lmask = torch.repeat_interleave(torch.arange(B), nl)
+    ligand = {"x": torch.zeros(B * nl, 3), "one_hot": torch.zeros(B * nl, 10),
+              "size": torch.full((B,), nl), "mask": lmask}
+    model.seed(7)
+    out_l, out_p, lm, pm = model.inpaint(ligand, pocket, torch.zeros(B * nl), torch.ones(len(pocket["mask"])),
+                                         resamplings=2, jump_length=1, timesteps=3)
+    assert out_l.shape == (B * nl, 13) and out_p.shape == (B * 286, 13)
+    assert torch.isfinite(out_l).all() and torch.isfinite(out_p).all()
+    oh = out_l[:, 3:]
+    assert torch.all((oh == 0) | (oh == 1)) and torch.all(oh.sum(1) == 1)
+    com = torch.zeros(B, 3, device=out_l.device).index_add_(0, torch.cat([lm, pm]), torch.cat([out_l[:, :3], out_p[:, :3]]))
+    assert (com / (nl + 286)).abs().max().item() < 5e-2
