@@ -48,6 +48,9 @@ WORKLOADS = {
     # name: (arch, pocket key, default batch per GPU)
     "crossdock_fullatom_cond": ("crossdock_fullatom_cond", "fa", 64),
     "crossdock_ca_cond": ("crossdock_ca_cond", "ca", 32),
+    # joint model: RePaint inpainting with the pocket fixed, resamplings=2, jump_length=1
+    # (what generate_ligands does for the joint model; 999 + 1 EGNN calls at T=500)
+    "moad_fullatom_joint": ("moad_fullatom_joint", "fa", 64),
 }
 
 
@@ -60,10 +63,12 @@ def load_pocket(key, batch, device):
 def build_model(arch, device):
     from diffsbdd_amd.conditional_model import ConditionalDDPM
     from diffsbdd_amd.dynamics import EGNNDynamics
+    from diffsbdd_amd.en_diffusion import EnVariationalDiffusion
     cfg, dd = synthetic.arch_cfg(arch)
     dyn = EGNNDynamics(**cfg, device=device)
     dyn.load_state_dict(synthetic.random_state_dict(cfg, seed=0))
-    model = ConditionalDDPM(dynamics=dyn, atom_nf=cfg["atom_nf"], residue_nf=cfg["residue_nf"], n_dims=3,
+    cls = ConditionalDDPM if dd["conditional"] else EnVariationalDiffusion
+    model = cls(dynamics=dyn, atom_nf=cfg["atom_nf"], residue_nf=cfg["residue_nf"], n_dims=3,
                             size_histogram=np.ones((40, 400)), timesteps=dd["timesteps"],
                             noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
                             loss_type="l2", norm_values=dd["norm_values"]).to(device)
@@ -122,6 +127,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the HIP-event timing of the dominant kernel (roofline = null); the engine "
+                         "then replays its captured hipGraph instead of launching eagerly")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -142,7 +150,8 @@ def main():
     B = args.batch or default_batch
     cfg, dd, model = build_model(arch, device)
     T = args.timesteps or dd["timesteps"]
-    n_calls = T + 1
+    joint = not dd["conditional"]
+    n_calls = (sum(model.get_repaint_schedule(2, 1, T)) + 1) if joint else T + 1
     pocket0 = load_pocket(key, B, device)
     n_lig = torch.full((B,), args.n_lig, dtype=torch.int64)
     lo = rank * B                                   # weak scaling: every rank owns B global samples
@@ -151,7 +160,16 @@ def main():
     def chain(seed):
         model.seed(seed, sample_offset=lo)
         pocket = {k: v.clone() for k, v in pocket0.items()}
-        out_l, out_p, lm, pm = model.sample_given_pocket(pocket, n_lig, timesteps=T)
+        if joint:
+            lmask = torch.repeat_interleave(torch.arange(B, device=device), args.n_lig)
+            ligand = {"x": torch.zeros(B * args.n_lig, 3, device=device),
+                      "one_hot": torch.zeros(B * args.n_lig, cfg["atom_nf"], device=device),
+                      "size": n_lig.to(device), "mask": lmask}
+            out_l, out_p, lm, pm = model.inpaint(ligand, pocket, torch.zeros(B * args.n_lig, device=device),
+                                                 torch.ones(pocket["x"].shape[0], device=device),
+                                                 resamplings=2, jump_length=1, timesteps=T)
+        else:
+            out_l, out_p, lm, pm = model.sample_given_pocket(pocket, n_lig, timesteps=T)
         return sharding.gather_ligands(out_l, lm, lo)
 
     def sync():
@@ -164,13 +182,14 @@ def main():
     for w in range(args.warmup):
         chain(100 + w)
     sync()
-    eng.profile(True, max_launches=min(args.steps, 5) * n_calls * cfg["n_layers"] * cfg["inv_sublayers"] + 8)
+    if not args.no_kernel_timing:
+        eng.profile(True, max_launches=min(args.steps, 5) * n_calls * cfg["n_layers"] * cfg["inv_sublayers"] + 8)
     t0 = time.perf_counter()
     for k in range(args.steps):
         all_lig, all_mask = chain(200 + k)
     sync()
     elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = eng.profile_read()
+    kern_ms, kern_n = (eng.profile_read() if not args.no_kernel_timing else (0.0, 0))
     eng.profile(False, 0)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -210,7 +229,7 @@ def main():
             "hbm_frac_of_8TBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_n else None,
         }
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not joint:
             cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, max_threads=args.cpu_threads)
         value = n_ligands_total / elapsed
         line = {
@@ -219,12 +238,14 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {B} pockets/GPU (3rfm {key} pocket, "
                                    f"{pocket0['x'].shape[0] // B} nodes) x {args.n_lig} ligand atoms, "
-                                   f"T={T} reverse steps + final decode = {n_calls} EGNN calls per chain",
+                                   f"T={T} reverse steps" + (" (RePaint, resamplings=2)" if joint else "") +
+                                   f" + final decode = {n_calls} EGNN calls per chain",
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
+            "hipgraph": dict(zip(("replays", "captures", "eager_calls"), eng.graph_stats())),
             "host_cores": os.cpu_count(),
         }
         print(json.dumps(line), flush=True)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dsbdd_dynamics_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64,
                                          _P, _P, _I64, _P, _P, _P]),
     "dsbdd_engine_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "dsbdd_engine_graph_stats": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "dsbdd_engine_profile": (C.c_int, [_P, C.c_int, C.c_int]),
     "dsbdd_engine_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "dsbdd_cond_reverse_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,

@@ -53,8 +53,27 @@ struct dsbdd_engine {
   bool profile = false;
   std::vector<hipEvent_t> ev;   // pairs: start, stop
   size_t ev_used = 0;
+  // hipGraph cache: the launch sequence of one dynamics call is captured once per argument
+  // signature (pointers + sizes) and replayed; a sampling chain calls with identical
+  // arguments every reverse step.  DSBDD_GRAPH=0 disables.
+  struct GraphEntry {
+    std::vector<uint64_t> key;
+    int seen = 0;                 // 1st call runs eagerly (warm-up), 2nd captures, then replay
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+  };
+  std::vector<GraphEntry> graphs;
+  int use_graph = 1;
+  int64_t n_replay = 0, n_capture = 0, n_eager = 0;
+  hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
+                                      // legacy default stream, which cannot be captured)
   ~dsbdd_engine() {
-    for (hipEvent_t e : ev) hipEventDestroy(e);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    for (GraphEntry& g : graphs) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
   }
 };
 
@@ -120,6 +139,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
     e->n_cu = prop.multiProcessorCount;
   const char* bm = getenv("DSBDD_EDGE_TILE");
   if (bm && atoi(bm) == 128) e->edge_bm = 128;
+  const char* ug = getenv("DSBDD_GRAPH");
+  if (ug && atoi(ug) == 0) e->use_graph = 0;
   const char* ek = getenv("DSBDD_EDGE_KERNEL");
   if (ek && !strcmp(ek, "pipe")) { e->edge_pipe = 1; e->edge_wave = 0; }
   if (ek && !strcmp(ek, "tiled")) { e->edge_pipe = 0; e->edge_wave = 0; }
@@ -216,6 +237,12 @@ int dsbdd_engine_profile_read(dsbdd_engine* e, double* total_ms, int64_t* launch
   *total_ms = tot;
   *launches = (int64_t)(e->ev_used / 2);
   e->ev_used = 0;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_graph_stats(const dsbdd_engine* e, int64_t* replays, int64_t* captures, int64_t* eager) {
+  if (!e || !replays || !captures || !eager) return fail(DSBDD_ERR_ARG, "null argument");
+  *replays = e->n_replay; *captures = e->n_capture; *eager = e->n_eager;
   return DSBDD_OK;
 }
 
@@ -355,26 +382,13 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   return DSBDD_OK;
 }
 
-extern "C" {
-
-int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, const float* xh_pocket,
+// The launch sequence of one EGNNDynamics.forward (enqueue only).
+static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, const float* xh_pocket,
                            const float* t, int64_t t_count, const int64_t* mask_lig,
                            const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
                            const int32_t* ext_row, const int32_t* ext_col, int64_t ext_n_edges,
                            float* eps_lig, float* eps_pocket, int32_t* status) {
-  if (!e || !xh_lig || !xh_pocket || !t || !mask_lig || !mask_pocket || !eps_lig || !status)
-    return fail(DSBDD_ERR_ARG, "null argument");
-  if (!e->has_weights) return fail(DSBDD_ERR_STATE, "weights not set");
-  if (!e->ws) return fail(DSBDD_ERR_STATE, "workspace not bound");
-  if (n_lig > e->cap_lig || n_pocket > e->cap_poc || batch > e->cap_batch || n_lig < 0 || n_pocket < 0 ||
-      batch < 1)
-    return fail(DSBDD_ERR_CAPACITY, "sizes exceed the bound workspace");
-  if (t_count != 1 && t_count != batch) return fail(DSBDD_ERR_ARG, "t must have 1 or batch entries");
   const bool ext = ext_row != nullptr;
-  if (ext && (!ext_col || ext_n_edges < 0 || ext_n_edges > e->cap_edges))
-    return fail(DSBDD_ERR_CAPACITY, "external edge list exceeds edge capacity");
-
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const dsbdd_config& c = e->cfg;
   const int H = c.hidden_nf, J = c.joint_nf, JP = pad4(J + 1);
   const int a = c.atom_nf, r = c.residue_nf, dl = 3 + a, dp = 3 + r;
@@ -535,6 +549,90 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
                      (const int*)e->lig_off, (const int*)e->poc_off, nlig, c.update_pocket_coords, eps_lig, dl,
                      eps_pocket, dp, status);
   HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+extern "C" {
+
+int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, const float* xh_pocket,
+                           const float* t, int64_t t_count, const int64_t* mask_lig,
+                           const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                           const int32_t* ext_row, const int32_t* ext_col, int64_t ext_n_edges,
+                           float* eps_lig, float* eps_pocket, int32_t* status) {
+  if (!e || !xh_lig || !xh_pocket || !t || !mask_lig || !mask_pocket || !eps_lig || !status)
+    return fail(DSBDD_ERR_ARG, "null argument");
+  if (!e->has_weights) return fail(DSBDD_ERR_STATE, "weights not set");
+  if (!e->ws) return fail(DSBDD_ERR_STATE, "workspace not bound");
+  if (n_lig > e->cap_lig || n_pocket > e->cap_poc || batch > e->cap_batch || n_lig < 0 || n_pocket < 0 ||
+      batch < 1)
+    return fail(DSBDD_ERR_CAPACITY, "sizes exceed the bound workspace");
+  if (t_count != 1 && t_count != batch) return fail(DSBDD_ERR_ARG, "t must have 1 or batch entries");
+  if (ext_row && (!ext_col || ext_n_edges < 0 || ext_n_edges > e->cap_edges))
+    return fail(DSBDD_ERR_CAPACITY, "external edge list exceeds edge capacity");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  // eager path: graphs off, timing / tracing hooks active (they enqueue event records and
+  // copies that must not be frozen into a graph), or teacher-forced edges (test-only)
+  const bool eager = !e->use_graph || e->profile || e->trace_h || e->trace_x || ext_row;
+  if (eager) {
+    ++e->n_eager;
+    return forward_impl(e, s, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig, n_pocket, batch,
+                        ext_row, ext_col, ext_n_edges, eps_lig, eps_pocket, status);
+  }
+
+  std::vector<uint64_t> key = {(uint64_t)(uintptr_t)xh_lig, (uint64_t)(uintptr_t)xh_pocket, (uint64_t)(uintptr_t)t,
+                               (uint64_t)t_count, (uint64_t)(uintptr_t)mask_lig, (uint64_t)(uintptr_t)mask_pocket,
+                               (uint64_t)n_lig, (uint64_t)n_pocket, (uint64_t)batch, (uint64_t)(uintptr_t)eps_lig,
+                               (uint64_t)(uintptr_t)eps_pocket, (uint64_t)(uintptr_t)status,
+                               (uint64_t)(uintptr_t)e->ws, (uint64_t)(uintptr_t)e->slots.data()[0],
+                               (uint64_t)(uintptr_t)s};
+  dsbdd_engine::GraphEntry* g = nullptr;
+  for (auto& ge : e->graphs)
+    if (ge.key == key) { g = &ge; break; }
+  if (!g) {
+    if (e->graphs.size() >= 8) {       // bounded cache: drop the oldest entry
+      if (e->graphs.front().exec) (void)hipGraphExecDestroy(e->graphs.front().exec);
+      if (e->graphs.front().graph) (void)hipGraphDestroy(e->graphs.front().graph);
+      e->graphs.erase(e->graphs.begin());
+    }
+    e->graphs.emplace_back();
+    g = &e->graphs.back();
+    g->key = key;
+  }
+  if (g->exec) {
+    ++e->n_replay;
+    HIP_TRY(hipGraphLaunch(g->exec, s));
+    return DSBDD_OK;
+  }
+  ++e->n_eager;
+  if (g->seen++ == 0)                  // first sight of this signature: plain launches
+    return forward_impl(e, s, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig, n_pocket, batch,
+                        nullptr, nullptr, 0, eps_lig, eps_pocket, status);
+  // second call with the same arguments: capture the sequence, then replay it
+  if (!e->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+  const int rc = forward_impl(e, e->cap_stream, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig,
+                              n_pocket, batch, nullptr, nullptr, 0, eps_lig, eps_pocket, status);
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(e->cap_stream, &graph);
+  if (rc != DSBDD_OK || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    e->use_graph = 0;                  // do not try again; fall back to plain launches
+    if (rc != DSBDD_OK) return rc;
+    return forward_impl(e, s, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig, n_pocket, batch,
+                        nullptr, nullptr, 0, eps_lig, eps_pocket, status);
+  }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+    (void)hipGraphDestroy(graph);
+    e->use_graph = 0;
+    return forward_impl(e, s, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig, n_pocket, batch,
+                        nullptr, nullptr, 0, eps_lig, eps_pocket, status);
+  }
+  g->graph = graph;
+  g->exec = exec;
+  ++e->n_capture;
+  HIP_TRY(hipGraphLaunch(g->exec, s));
   return DSBDD_OK;
 }
 

@@ -197,7 +197,7 @@ class EGNNDynamics(nn.Module):
 
     @torch.no_grad()
     def forward_async(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues, edges=None,
-                      status=None, want_pocket=True, eps_lig=None, batch=None):
+                      status=None, want_pocket=True, eps_lig=None, batch=None, eps_pocket=None):
         """Same as forward() but without the host sync: returns
         (eps_atoms, eps_residues, status) where `status` is an int32 device
         word (bit 0: NaN, bit 1: edge overflow).  `edges` ([2,E]) teacher-forces
@@ -218,7 +218,7 @@ class EGNNDynamics(nn.Module):
         cap = self._edge_cap(mask_atoms, mask_residues, batch) if edges is None else 0
         return eng.forward_async(xh_atoms, xh_residues, t, mask_atoms, mask_residues, batch, cap,
                                  ext_edges=edges, status=status, want_pocket=want_pocket,
-                                 eps_lig=eps_lig)
+                                 eps_lig=eps_lig, eps_pocket=eps_pocket)
 
     @torch.no_grad()
     def get_edges(self, batch_mask_ligand, batch_mask_pocket, x_ligand, x_pocket):

@@ -339,9 +339,22 @@ class EnVariationalDiffusion(nn.Module):
             raise ValueError("NaN detected in EGNN output")
 
     def _dyn(self, z_lig, z_pocket, t_value, lig_mask, pocket_mask, batch, status, want_pocket):
-        t = torch.full((batch,), float(t_value), dtype=torch.float32, device=z_lig.device)
+        """One denoiser call.  t and the eps outputs live in persistent buffers keyed by the
+        state tensors, so that consecutive reverse steps of a chain call the engine with
+        identical pointers (the engine replays its captured hipGraph)."""
+        key = (z_lig.data_ptr(), z_pocket.data_ptr(), batch, bool(want_pocket), z_lig.shape, z_pocket.shape)
+        buf = self._dyn_bufs.get(key) if hasattr(self, "_dyn_bufs") else None
+        if buf is None:
+            if not hasattr(self, "_dyn_bufs") or len(self._dyn_bufs) > 16:
+                self._dyn_bufs = {}
+            buf = (torch.empty((batch,), dtype=torch.float32, device=z_lig.device),
+                   torch.empty_like(z_lig), torch.empty_like(z_pocket) if want_pocket else None)
+            self._dyn_bufs[key] = buf
+        t, eps_l, eps_p = buf
+        t.fill_(float(t_value))
         return self.dynamics.forward_async(z_lig, z_pocket, t, lig_mask, pocket_mask, status=status,
-                                           want_pocket=want_pocket, batch=batch)
+                                           want_pocket=want_pocket, batch=batch, eps_lig=eps_l,
+                                           eps_pocket=eps_p)
 
     # ---- joint noise (en_diffusion.py:559-578) ------------------------------------------
     def sample_combined_position_feature_noise(self, lig_indices, pocket_indices):

@@ -237,6 +237,12 @@ class HipEngine:
         _lib.check(self.lib.dsbdd_engine_profile_read(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def graph_stats(self):
+        """(graph replays, captures, eager calls) of dsbdd_dynamics_forward so far."""
+        r, c, g = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.dsbdd_engine_graph_stats(self.handle, C.byref(r), C.byref(c), C.byref(g)))
+        return r.value, c.value, g.value
+
     def edge_count(self, n_nodes):
         """Number of edges of the last forward (syncs)."""
         import numpy as np

@@ -158,6 +158,14 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig,
 int dsbdd_engine_profile(dsbdd_engine* e, int enable, int max_launches);
 int dsbdd_engine_profile_read(dsbdd_engine* e, double* total_ms, int64_t* launches);
 
+/* hipGraph bookkeeping.  dsbdd_dynamics_forward captures its launch sequence into a
+ * hipGraph the second time it is called with an identical argument signature
+ * (pointers + sizes + stream) and replays it afterwards -- a sampling chain calls it
+ * with identical arguments every reverse step.  Eager launches are used while the
+ * timing / trace hooks are active, for teacher-forced edge lists, or with
+ * DSBDD_GRAPH=0.  Counters: graph replays, captures, eager calls. */
+int dsbdd_engine_graph_stats(const dsbdd_engine* e, int64_t* replays, int64_t* captures, int64_t* eager);
+
 /* Introspection of the last forward (device pointers into the workspace). */
 enum {
   DSBDD_BUF_EDGE_ROW = 0, DSBDD_BUF_EDGE_COL, DSBDD_BUF_EDGE_D0, DSBDD_BUF_ROW_PTR,
