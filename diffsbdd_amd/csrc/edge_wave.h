@@ -64,6 +64,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   constexpr int BMW = 32, BMB = 128;    // edges per wave / per workgroup
   static_assert(H % 64 == 0 && H <= 256, "hidden_nf must be 64,128,192 or 256");
   static_assert((BK * NQ) % kThreads == 0, "B slice split");
+  // s_setprio 1 around every MFMA cluster: the two workgroups sharing a CU are in different
+  // phases, so favouring the wave that has MFMAs ready keeps the matrix pipe fed (+2.7 %)
+  constexpr bool SETPRIO = true;
 
   __shared__ float smem[L::TOTAL];
   float* sB = smem;                         // [2][BK][H]
@@ -197,12 +200,14 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         a[1] = silu(pc.y + qc.y + my_d * wd4.y + my_d0 * wz4.y + tb4.y);
         a[2] = silu(pc.z + qc.z + my_d * wd4.z + my_d0 * wz4.z + tb4.z);
         a[3] = silu(pc.w + qc.w + my_d * wd4.w + my_d0 * wz4.w + tb4.w);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float* brow = bcur + (8 * g + i) * H;
 #pragma unroll
           for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
         }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         pc = pn; qc = qn4;
       }
       ++bslice;
