@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffsbdd_hip.so")
+# DSBDD_LIB: load another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("DSBDD_LIB") or os.path.join(_HERE, "libdiffsbdd_hip.so")
 ABI_VERSION = 1
 
 # error / status codes (include/diffsbdd_hip.h)

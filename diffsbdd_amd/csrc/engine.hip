@@ -43,7 +43,7 @@ struct dsbdd_engine {
   int64_t cap_lig = 0, cap_poc = 0, cap_batch = 0, cap_edges = 0;
   int *node_batch, *lig_off, *poc_off, *deg, *row_ptr, *erow, *ecol;
   int *act_flag, *act_ptr, *act_list;
-  float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *hout;
+  float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *pqg, *hout;
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   int edge_bm = 64;    // 64-edge tiles, 2 workgroups per CU (measured faster than 128 / 1)
@@ -64,6 +64,7 @@ struct dsbdd_engine {
   };
   std::vector<GraphEntry> graphs;
   int use_graph = 1;
+  int node_group = 1;  // coordinate projections + next block's P|Q in one launch (DSBDD_NODE_GROUP=0: separate)
   int64_t n_replay = 0, n_capture = 0, n_eager = 0;
   hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
                                       // legacy default stream, which cannot be captured)
@@ -106,7 +107,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * JP * 4, (size_t)N * LE * 4,                                                       // 12 h0, 13 enc_tmp
       (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * PQ * 4,                  // 14 h 15 t1 16 agg 17 pq
       (size_t)N * JP * 4,                                                                           // 18 hout
-      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4};                                           // 19-21 act flag/ptr/list
+      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
+      (size_t)N * 2 * H * 4};                                                                       // 22 pqg (GCL P|Q)
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -141,6 +143,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (bm && atoi(bm) == 128) e->edge_bm = 128;
   const char* ug = getenv("DSBDD_GRAPH");
   if (ug && atoi(ug) == 0) e->use_graph = 0;
+  const char* ngp = getenv("DSBDD_NODE_GROUP");
+  if (ngp && atoi(ngp) == 0) e->node_group = 0;
   const char* ek = getenv("DSBDD_EDGE_KERNEL");
   if (ek && !strcmp(ek, "pipe")) { e->edge_pipe = 1; e->edge_wave = 0; }
   if (ek && !strcmp(ek, "tiled")) { e->edge_pipe = 0; e->edge_wave = 0; }
@@ -204,6 +208,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->h = (float*)(b + L.off[14]); e->t1 = (float*)(b + L.off[15]); e->agg = (float*)(b + L.off[16]);
   e->pq = (float*)(b + L.off[17]); e->hout = (float*)(b + L.off[18]);
   e->act_flag = (int*)(b + L.off[19]); e->act_ptr = (int*)(b + L.off[20]); e->act_list = (int*)(b + L.off[21]);
+  e->pqg = (float*)(b + L.off[22]);
   return DSBDD_OK;
 }
 
@@ -466,6 +471,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   const int* e_all = e->row_ptr + N;
   const int* e_upd = e->row_ptr + n_upd;                 // edges are row-sorted: a prefix
 
+  auto gcl_pq = [&](int blk, int sub) {
+    return NodeLinearArgs{e->h, H, H, nullptr, 0, 0, W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, nullptr,
+                          nullptr, 0, e->pqg, 2 * H, (int)N, 2 * H, 0, nullptr, nullptr};
+  };
+  bool pqg_ready = false;
   for (int blk = 0; blk < c.n_layers; ++blk) {
     if (n_mlp == 2) {   // coord2cross needs the per-sample mean of the block's input x
       hipLaunchKernelGGL(sample_mean_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)e->x,
@@ -474,13 +484,15 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     }
     for (int sub = 0; sub < c.inv_sublayers; ++sub) {
       auto G = [&](int which) { return W[gcl_slot(c, blk, sub, which)]; };
-      // P | Q projections of the edge MLP's first layer
-      HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, G(DSBDD_GCL_E1_WT), 2 * H, nullptr, nullptr, 0, e->pq, PQ, N, 2 * H, 0));
+      // P | Q projections of the edge MLP's first layer (those of a block's first sublayer
+      // were launched together with the previous block's coordinate projections)
+      if (!pqg_ready) HIP_TRY(launch_node_linear(s, gcl_pq(blk, sub)));
+      pqg_ready = false;
       HIP_TRY(hipMemsetAsync(e->agg, 0, (size_t)N * H * 4, s));
       EdgeArgs ea{};
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.x = e->x;
-      ea.n_lig = nlig; ea.ldpq = PQ;
-      ea.mlp[0] = EdgeMlpW{e->pq, e->pq + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
+      ea.n_lig = nlig; ea.ldpq = 2 * H;
+      ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B)};
       ea.mlp[1] = ea.mlp[0];
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
@@ -498,14 +510,27 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     }
     {
       auto Q = [&](int which) { return W[eq_slot(c, blk, which)]; };
-      // first-layer projections, column order [Q_coord | Q_cross | P_coord | P_cross]
+      // first-layer projections, column order [Q_coord | Q_cross | P_coord | P_cross]; the next
+      // block's GCL P|Q projection reads the same h and shares the launch when it can
       const int QW = n_mlp * H;   // width of the Q (column-node) part
+      NodeLinearArgs grp[kMaxGroup];
+      int ng = 0;
       if (subset) {
-        HIP_TRY(nl_rows(s, e->h, H, H, Q(DSBDD_EQ_C1_WT), PQ, e->pq, PQ, N, QW, e->act_list, e->act_ptr + N));
-        HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT) + QW, PQ, nullptr, nullptr, 0, e->pq + QW, PQ,
-                   n_lig, QW, 0));
+        grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
+                                   (int)N, QW, 0, e->act_list, e->act_ptr + N};
+        grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT) + QW, PQ, nullptr, nullptr, 0,
+                                   e->pq + QW, PQ, (int)n_lig, QW, 0, nullptr, nullptr};
       } else {
-        HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ, N, PQ, 0));
+        grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
+                                   (int)N, PQ, 0, nullptr, nullptr};
+      }
+      if (blk + 1 < c.n_layers) grp[ng++] = gcl_pq(blk + 1, 0);
+      if (e->node_group && launch_node_group(s, grp, ng) == hipSuccess) {
+        pqg_ready = blk + 1 < c.n_layers;
+      } else {
+        (void)hipGetLastError();
+        const int nc = ng - (blk + 1 < c.n_layers ? 1 : 0);   // the coordinate projections only
+        for (int i = 0; i < nc; ++i) HIP_TRY(launch_node_linear(s, grp[i]));
       }
       EdgeArgs ea{};
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.x = e->x;

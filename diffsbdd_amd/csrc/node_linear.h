@@ -159,28 +159,39 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
 
 // ---------------------------------------------------------------------------
 // Same GEMM with the structure of edge_wave.h, for the aligned big layers
-// (K1, K2 multiples of 32; N multiple of 64; 16-byte aligned rows):
+// (K1, K2 multiples of BK; N multiple of 32*CT; 16-byte aligned rows):
 //   * lane l IS row (l & 31) of the wave's 32-row tile and reads float4 chunks of its
-//     own row straight from L2 -- the MFMA A operand never touches LDS;
-//   * the weight slice [32][64] is streamed by global_load_lds (double buffered, one
-//     barrier per K step); workgroup = 4 waves x 32 rows = 128 rows x 64 columns.
-template <int DUMMY>
-__global__ __launch_bounds__(kThreads) void node_linear_wave_kernel(NodeLinearArgs p) {
-  constexpr int BN = 64, BK = 32, CT = BN / 32;     // (BK = 64 measured no faster: the A-row loads bound it)
+//     own row straight from L2 -- the MFMA A operand never touches LDS.  The chunks of
+//     a whole K step are requested one K step ahead (register double buffer), so an
+//     L1 miss (every row opens a new 128-byte line every 32 k) has 64 MFMAs to land;
+//   * the weight slice [BK][32*CT] is streamed by global_load_lds (double buffered, one
+//     barrier per K step); workgroup = 4 waves x 32 rows = 128 rows x 32*CT columns;
+//   * BK = 128 / CT keeps 64 MFMAs per wave between barriers for both tile widths;
+//   * up to three independent problems share one launch (blockIdx.z): the small
+//     ligand-row / active-subset projections of the coordinate MLPs ride along with
+//     the next block's P|Q projection instead of running alone on a fraction of the CUs.
+constexpr int kMaxGroup = 3;
+struct NodeGroupArgs { NodeLinearArgs p[kMaxGroup]; };
+
+template <int CT>
+__global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga) {
+  constexpr int BN = 32 * CT, BK = 128 / CT, NG = BK / 8;
+  constexpr int BI = BK * BN / 4 / kThreads;          // float4 DMA pieces per thread per slice
+  constexpr int RQ = BN / 4;                          // float4 per slice row
   __shared__ float sB[2 * BK * BN];
+  const NodeLinearArgs& p = ga.p[blockIdx.z];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, j = lane & 31;
   const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
   const int K = p.K1 + p.K2;
   const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
-  if (m0 >= M) return;   // uniform per workgroup
+  if (m0 >= M || n0 >= p.N) return;   // uniform per workgroup
 
-  // weight slice ks -> LDS buffer: [BK][BN] floats = BK*16 float4, BK/16 per thread
   auto streamB = [&](int ks, int buf) {
 #pragma unroll
-    for (int i = 0; i < BK / 16; ++i) {
-      const int f = t + kThreads * i;              // float4 index: row f/16, col chunk f%16
-      const float* src = p.WT + (size_t)(ks * BK + (f >> 4)) * p.ldw + n0 + (f & 15) * 4;
+    for (int i = 0; i < BI; ++i) {
+      const int f = t + kThreads * i;                // float4 index: row f/RQ, column chunk f%RQ
+      const float* src = p.WT + (size_t)(ks * BK + f / RQ) * p.ldw + n0 + (f % RQ) * 4;
       float* dst = sB + buf * BK * BN + (w * 64 + kThreads * i) * 4;   // wave-uniform base
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -188,10 +199,15 @@ __global__ __launch_bounds__(kThreads) void node_linear_wave_kernel(NodeLinearAr
   };
 
   const int rowl = m0 + w * 32 + j;
-  const bool valid = rowl < M;
-  const int row = valid ? (p.row_idx ? p.row_idx[rowl] : rowl) : 0;
+  const int row = rowl < M ? (p.row_idx ? p.row_idx[rowl] : rowl) : 0;
   const float* a1 = p.A1 + (size_t)row * p.lda1 + 4 * half;
   const float* a2 = p.K2 ? p.A2 + (size_t)row * p.lda2 + 4 * half : a1;
+  auto loadA = [&](int ks, float4 (&dst)[NG]) {
+    const int k0 = ks * BK;                          // a K step never straddles A1 | A2
+    const float* src = k0 < p.K1 ? a1 + k0 : a2 + (k0 - p.K1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dst[g] = ld4(src + 8 * g);
+  };
 
   f32x16 acc[CT];
 #pragma unroll
@@ -199,61 +215,121 @@ __global__ __launch_bounds__(kThreads) void node_linear_wave_kernel(NodeLinearAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
+  float4 cur[NG], nxt[NG];
   streamB(0, 0);
-  float4 ac = ld4(a1), an = ac;
+  loadA(0, cur);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) nxt[g] = cur[g];
   __syncthreads();
   const int nk = K / BK;
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) streamB(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk) {
+      streamB(kt + 1, (kt + 1) & 1);
+      loadA(kt + 1, nxt);
+    }
     const float* bcur = sB + (kt & 1) * BK * BN + (4 * half) * BN + j;
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      const int kn = kt * BK + 8 * (g + 1);        // first k of the next group
-      if (kn < K) an = ld4(kn < p.K1 ? a1 + kn : a2 + (kn - p.K1));
-      const float a[4] = {ac.x, ac.y, ac.z, ac.w};
+    for (int g = 0; g < NG; ++g) {
+      const float a[4] = {cur[g].x, cur[g].y, cur[g].z, cur[g].w};
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float* brow = bcur + (8 * g + i) * BN;
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
       }
-      ac = an;
+      __builtin_amdgcn_s_setprio(0);
     }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
     __syncthreads();
   }
 
+  // epilogue.  C may alias R (the node MLP's residual is updated in place), so the compiler
+  // must keep every R load behind the previous C store: gather the row ids and all residual
+  // values of a column tile first, then store -- CT memory round trips instead of 16 * CT.
+  int ro[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rl = m0 + w * 32 + mfma_row(r, lane);
+    ro[r] = rl < M ? (p.row_idx ? p.row_idx[rl] : rl) : -1;
+  }
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     const int col = n0 + c * 32 + j;
     const float bv = p.bias ? p.bias[col] : 0.f;
+    f32x16 res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = (p.R && ro[r] >= 0) ? p.R[(size_t)ro[r] * p.ldr + col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rl = m0 + w * 32 + mfma_row(r, lane);
-      if (rl >= M) continue;
-      const int ro = p.row_idx ? p.row_idx[rl] : rl;
+      if (ro[r] < 0) continue;
       float v = acc[c][r] + bv;
       if (p.act == 1) v = silu(v);
-      if (p.R) v += p.R[(size_t)ro * p.ldr + col];
-      p.C[(size_t)ro * p.ldc + col] = v;
+      p.C[(size_t)ro[r] * p.ldc + col] = v + res[r];
     }
   }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+inline bool vec_ok(const NodeLinearArgs& a) {
+  return aligned16(a.A1) && (a.lda1 % 4 == 0) && (a.K1 % 4 == 0) &&
+         (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
+}
+
+// column-tile count (2 or 4) of the register-A kernel for this problem, 0 = not eligible
+inline int gemm_ct(const NodeLinearArgs& a, int forced_ct) {
+  if (!vec_ok(a) || a.ldw % 4 != 0 || !aligned16(a.WT) || a.K1 <= 0) return 0;
+  auto fits = [&](int ct) {
+    const int bk = 128 / ct, bn = 32 * ct;
+    return a.K1 % bk == 0 && a.K2 % bk == 0 && a.N % bn == 0;
+  };
+  if (forced_ct && fits(forced_ct)) return forced_ct;
+  if (a.N >= 512 && fits(4)) return 4;
+  return fits(2) ? 2 : (fits(4) ? 4 : 0);
+}
+
+inline int node_ct_override() {
+  static const int v = [] {
+    const char* s = getenv("DSBDD_NODE_CT");
+    return s ? atoi(s) : 0;
+  }();
+  return v;
+}
+
+// One launch for up to kMaxGroup eligible problems (all must accept the same CT).
+// Returns hipErrorInvalidValue when the group cannot share a launch.
+inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int n) {
+  if (n <= 0 || n > kMaxGroup) return hipErrorInvalidValue;
+  int ct = 4;
+  for (int i = 0; i < n; ++i) {
+    const int c = gemm_ct(a[i], node_ct_override());
+    if (c == 0) return hipErrorInvalidValue;
+    if (c < ct) ct = c;
+  }
+  for (int i = 0; i < n; ++i)
+    if (gemm_ct(a[i], ct) != ct) return hipErrorInvalidValue;
+  NodeGroupArgs ga{};
+  int gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    ga.p[i] = a[i];
+    gx = max(gx, (a[i].M + 127) / 128);
+    gy = max(gy, a[i].N / (32 * ct));
+  }
+  dim3 grid(gx, gy, n), block(kThreads);
+  if (ct == 4) hipLaunchKernelGGL((node_gemm_kernel<4>), grid, block, 0, s, ga);
+  else         hipLaunchKernelGGL((node_gemm_kernel<2>), grid, block, 0, s, ga);
+  return hipGetLastError();
+}
+
 // Host-side launcher.  Returns hipError_t of the launch.
 inline hipError_t launch_node_linear(hipStream_t s, const NodeLinearArgs& a) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  const bool vec = aligned16(a.A1) && (a.lda1 % 4 == 0) && (a.K1 % 4 == 0) &&
-                   (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
+  const bool vec = vec_ok(a);
   // aligned big layers: register-A / LDS-DMA kernel
-  if (vec && a.K1 % 32 == 0 && a.K2 % 32 == 0 && a.N % 64 == 0 && a.ldw % 4 == 0 && aligned16(a.WT) &&
-      (long)a.M * a.N >= 64 * 1024) {
-    dim3 grid((a.M + 127) / 128, a.N / 64), block(kThreads);
-    hipLaunchKernelGGL((node_linear_wave_kernel<0>), grid, block, 0, s, a);
-    return hipGetLastError();
-  }
+  if ((long)a.M * a.N >= 64 * 1024 && gemm_ct(a, node_ct_override()) != 0) return launch_node_group(s, &a, 1);
   const int ny = (a.N + 127) / 128;
   const long tiles128 = (long)((a.M + 127) / 128) * ny;
   const bool big = tiles128 >= 512 && !a.row_idx;  // enough 128-row tiles to fill 256 CUs twice

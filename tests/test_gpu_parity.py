@@ -68,6 +68,9 @@ def make_ddpm(c, sd=None):
     (65, 20, 0, 10, 0, False, True),          # decoder -> strided output
     (70000, 192, 0, 768, 0, False, True),     # big-M path (128-row tiles)
     (1, 64, 0, 64, 1, False, True),
+    (2500, 192, 192, 192, 1, False, True),    # H = 192 (joint model): 64-wide K steps, 64-column tiles
+    (3000, 128, 0, 384, 0, True, True),       # H = 128, residual
+    (129, 256, 0, 1024, 0, False, True),      # one full + one 1-row workgroup tile, 128-column tiles
 ])
 def test_node_linear_vs_torch_fp32(M, K1, K2, N, act, res, vec):
     from diffsbdd_amd import _lib
