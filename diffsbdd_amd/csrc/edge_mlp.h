@@ -63,6 +63,10 @@ struct EdgeArgs {
   float norm_constant; float coords_range; int use_tanh; int n_mlp;
   float* xagg;            // [N][3], zero on entry
   float norm_factor;
+  // edge_wave_kernel, MODE_COORD with two MLPs: alternate workgroups take the coordinate /
+  // cross-product MLP of a tile (twice as many, half as long work items: better balance when
+  // the masked edge prefix is only a few tiles per CU); the two terms of trans are linear
+  int pass_split;
 };
 
 enum { MODE_GCL = 0, MODE_COORD = 1 };

@@ -75,10 +75,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int half = lane >> 5, j = lane & 31;
   float* s_phi = smem + L::SCR_OFF + w * L::SCR_PER;   // [32]
   float* s_tr = s_phi + 32;                             // [32][3]
-  const int n_pass = (MODE == MODE_GCL) ? 1 : p.n_mlp;
+  const bool split = MODE == MODE_COORD && p.pass_split && p.n_mlp == 2;
+  const int qsel = split ? ((blockIdx.x >> 3) & 1) : 0;   // the MLP this workgroup evaluates when split
+  const int n_pass = (MODE == MODE_GCL || split) ? 1 : p.n_mlp;
 
   for (int q = 0; q < n_pass; ++q) {
-    const EdgeMlpW& mw = p.mlp[q];
+    const EdgeMlpW& mw = p.mlp[qsel + q];
     float* v = sV + q * L::VEC_PER;
     for (int i = t; i < H; i += kThreads) {
       v[i] = mw.wd[i];
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 
   const int E = *p.e_count;
   const int ntiles = (E + BMB - 1) / BMB;
-  const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3, gx = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int kx = split ? (blockIdx.x >> 4) : (blockIdx.x >> 3);
+  const int gx = split ? (gridDim.x >> 4) : (gridDim.x >> 3);
   const int tq = ntiles / 8, tr = ntiles % 8;
   const int csize = tq + (xcd < tr ? 1 : 0);
   const int cbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // tracked by vmcnt; the __syncthreads() that ends a K step drains it (vmcnt(0)) and
   // publishes the slice to the other waves.
   auto streamB = [&](int q, int ks, int buf) {
-    const float* src = p.mlp[q].W2T + (size_t)ks * BK * H + t * 4;
+    const float* src = p.mlp[qsel + q].W2T + (size_t)ks * BK * H + t * 4;
     float* dst = sB + buf * L::B_BUF + w * 256;          // wave-uniform
 #pragma unroll
     for (int i = 0; i < BI; ++i)
@@ -153,8 +157,8 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   __syncthreads();          // sV + slice 0 visible
   int bslice = 0;           // running slice counter (buffer = bslice & 1)
 
-  const float* Pp = p.mlp[0].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + 4 * half;
-  const float* Qp = p.mlp[0].Q + (size_t)my_c * p.ldpq + 4 * half;
+  const float* Pp = p.mlp[qsel].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + 4 * half;
+  const float* Qp = p.mlp[qsel].Q + (size_t)my_c * p.ldpq + 4 * half;
   float4 pc = ld4(Pp), qc = ld4(Qp), pn = pc, qn4 = qc;
   float phi0 = 0.f, phi1 = 0.f;
 
@@ -217,8 +221,8 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     // first P/Q chunk of the NEXT unit: in flight during the epilogue
     if (!last_unit) {
       const int r_n = tile_ends ? nx_r : my_r, c_n = tile_ends ? nx_c : my_c;
-      Pp = p.mlp[qn].P + (size_t)(r_n < 0 ? 0 : r_n) * p.ldpq + 4 * half;
-      Qp = p.mlp[qn].Q + (size_t)c_n * p.ldpq + 4 * half;
+      Pp = p.mlp[qsel + qn].P + (size_t)(r_n < 0 ? 0 : r_n) * p.ldpq + 4 * half;
+      Qp = p.mlp[qsel + qn].Q + (size_t)c_n * p.ldpq + 4 * half;
       pc = ld4(Pp); qc = ld4(Qp);
     }
 
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       wave_lds_fence();
       const float ph = s_phi[j];                            // this lane's edge
       wave_lds_fence();
-      if (q == 0) phi0 = ph; else phi1 = ph;
+      if (qsel + q == 0) phi0 = ph; else phi1 = ph;
 
       if (tile_ends) {
         // trans = u*phi + cross*phi_x   (egnn_new.py:100-109, 296-316); lane = edge
@@ -324,13 +328,15 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           const float dx = xr[0] - xc[0], dy = xr[1] - xc[1], dz = xr[2] - xc[2];
           const float den = sqrtf(my_d + 1e-8f) + p.norm_constant;
           const float ux = dx / den, uy = dy / den, uz = dz / den;
-          if (p.use_tanh) {
+          if (split && qsel == 1) {
+            // this workgroup only adds the cross-product term
+          } else if (p.use_tanh) {
             const float th = tanhf(phi0);
             tx = ux * th * p.coords_range; ty = uy * th * p.coords_range; tz = uz * th * p.coords_range;
           } else {
             tx = ux * phi0; ty = uy * phi0; tz = uz * phi0;
           }
-          if (p.n_mlp == 2) {
+          if (p.n_mlp == 2 && !(split && qsel == 0)) {
             const int b = p.node_batch[my_r];
             const float m0 = p.mean[3 * b], m1 = p.mean[3 * b + 1], m2 = p.mean[3 * b + 2];
             const float a0 = xr[0] - m0, a1 = xr[1] - m1, a2 = xr[2] - m2;

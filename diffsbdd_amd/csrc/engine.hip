@@ -64,6 +64,7 @@ struct dsbdd_engine {
   };
   std::vector<GraphEntry> graphs;
   int use_graph = 1;
+  int coord_split = 1; // edge_wave MODE_COORD: one workgroup per (tile, MLP) (DSBDD_COORD_SPLIT=0: per tile)
   int node_group = 1;  // coordinate projections + next block's P|Q in one launch (DSBDD_NODE_GROUP=0: separate)
   int64_t n_replay = 0, n_capture = 0, n_eager = 0;
   hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
@@ -143,6 +144,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (bm && atoi(bm) == 128) e->edge_bm = 128;
   const char* ug = getenv("DSBDD_GRAPH");
   if (ug && atoi(ug) == 0) e->use_graph = 0;
+  const char* csp = getenv("DSBDD_COORD_SPLIT");
+  if (csp && atoi(csp) == 0) e->coord_split = 0;
   const char* ngp = getenv("DSBDD_NODE_GROUP");
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
   const char* ek = getenv("DSBDD_EDGE_KERNEL");
@@ -316,9 +319,12 @@ static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, co
   if (e->edge_wave) {   // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU
     int64_t tiles = (edge_bound + 127) / 128;
     int64_t resident = 2LL * e->n_cu;
-    int64_t g = tiles < resident ? tiles : resident;
-    int grid = (int)((g + 7) / 8 * 8);
-    if (grid < 8) grid = 8;
+    const bool split = mode == MODE_COORD && a.pass_split && a.n_mlp == 2;
+    int64_t g = split ? 2 * tiles : tiles;             // split: one workgroup per (tile, MLP)
+    if (g > resident) g = resident;
+    const int q8 = split ? 16 : 8;                      // 8 XCDs (x 2 MLPs)
+    int grid = (int)((g + q8 - 1) / q8 * q8);
+    if (grid < q8) grid = q8;
     switch (H) {
       case 64: return launch_wave_t<64>(s, mode, a, grid);
       case 128: return launch_wave_t<128>(s, mode, a, grid);
@@ -545,6 +551,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
       ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
       ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.norm_factor = c.normalization_factor;
+      ea.pass_split = e->coord_split;
      
       HIP_TRY(launch_edge(e, s, MODE_COORD, ea, edge_bound));
       hipLaunchKernelGGL(coord_update_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, s, e->x, e->xagg,
