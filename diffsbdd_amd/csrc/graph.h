@@ -99,25 +99,60 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
 }
 
 // Exclusive scan of deg[0..n) -> row_ptr[0..n], row_ptr[n] = total.  One
-// workgroup of 1024 threads (n is tens of thousands).
+// workgroup of 1024 threads (n is tens of thousands) walks tiles of 4096
+// elements: coalesced 16-byte loads, 4-element serial prefix per lane, wave
+// scan by lane shuffles, 16 wave totals through LDS, running carry in a register.
 __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr, int n) {
-  __shared__ int s[1024];
-  const int t = threadIdx.x;
-  const int chunk = (n + 1023) / 1024;
-  const int b = t * chunk, e = min(b + chunk, n);
-  int local = 0;
-  for (int i = b; i < e; ++i) local += deg[i];
-  s[t] = local;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
-    const int v = (t >= o) ? s[t - o] : 0;
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const bool vec = ((reinterpret_cast<uintptr_t>(deg) | reinterpret_cast<uintptr_t>(row_ptr)) & 15) == 0;
+  int carry = 0;
+  for (int base = 0; base < n; base += 4096) {
+    const int i0 = base + 4 * t;
+    int v[4] = {0, 0, 0, 0};
+    if (vec && i0 + 3 < n) {
+      const int4 q = *reinterpret_cast<const int4*>(deg + i0);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (i0 + k < n) v[k] = deg[i0 + k];
+    }
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    int incl = mine;                                   // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[w] = incl;
     __syncthreads();
-    s[t] += v;
+    if (w == 0) {                                      // scan of the 16 wave totals
+      int tot = lane < 16 ? s_wave[lane] : 0;
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+      }
+      if (lane < 16) s_wave[lane] = inc - tot;         // exclusive offset of each wave
+      if (lane == 15) s_carry = inc;                   // tile total
+    }
     __syncthreads();
+    int run = carry + s_wave[w] + incl - mine;
+    const int tile_total = s_carry;
+    if (vec && i0 + 3 < n) {
+      int4 o4;
+      o4.x = run; o4.y = run + v[0]; o4.z = o4.y + v[1]; o4.w = o4.z + v[2];
+      *reinterpret_cast<int4*>(row_ptr + i0) = o4;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (i0 + k < n) { row_ptr[i0 + k] = run; run += v[k]; }
+    }
+    carry += tile_total;
+    __syncthreads();                                   // s_wave / s_carry are reused by the next tile
   }
-  int run = s[t] - local;
-  for (int i = b; i < e; ++i) { row_ptr[i] = run; run += deg[i]; }
-  if (t == 1023) row_ptr[n] = s[1023];
+  if (t == 0) row_ptr[n] = carry;
 }
 
 // Teacher-forced edge list: copy rows/cols, compute d0, build row_ptr counts.
