@@ -74,6 +74,8 @@ SIGNATURES = {
                                     _P, _I32, _I64, _I32, _I32]),
     "dsbdd_build_edges": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, C.POINTER(Config),
                                     _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "dsbdd_bond_orders": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.c_float, C.c_float,
+                                    C.c_float, _I32, _P]),
 }
 
 _lib = None

@@ -16,6 +16,7 @@
 #include "edge_pipe.h"
 #include "edge_wave.h"
 #include "graph.h"
+#include "molecule.h"
 #include "node_linear.h"
 
 using namespace dsbdd;
@@ -717,6 +718,22 @@ int dsbdd_node_linear(void* stream, const float* A1, int32_t lda1, int32_t K1, c
       (reinterpret_cast<uintptr_t>(WT) & 15))
     return fail(DSBDD_ERR_ARG, "bad argument (WT must be 16-byte aligned with ldw % 4 == 0)");
   HIP_TRY(nl(static_cast<hipStream_t>(stream), A1, lda1, K1, A2, lda2, K2, WT, ldw, bias, R, ldr, C, ldc, M, N, act));
+  return DSBDD_OK;
+}
+
+int dsbdd_bond_orders(void* stream, const float* x, const int32_t* atom_type, const int32_t* mol_off,
+                      int64_t batch, int32_t n_types, const float* bonds1, const float* bonds2,
+                      const float* bonds3, float margin1, float margin2, float margin3, int32_t n_max,
+                      int8_t* order) {
+  if (!x || !atom_type || !mol_off || !bonds1 || !bonds2 || !bonds3 || !order || batch < 1 || n_types < 1 ||
+      n_max < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(order, 0, (size_t)batch * n_max * n_max, s));
+  BondArgs a{x, atom_type, mol_off, bonds1, bonds2, bonds3, margin1, margin2, margin3, n_types, n_max,
+             reinterpret_cast<signed char*>(order)};
+  hipLaunchKernelGGL(bond_orders_kernel, dim3((unsigned)batch), dim3(64), 0, s, a);
+  HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
 

@@ -1,0 +1,257 @@
+"""De-novo ligand generation driver: PDB in, molecules out.
+
+Host-side mirror of `LigandPocketDDPM.__init__` / `prepare_pocket` /
+`generate_ligands` (/root/reference/lightning_modules.py:31-186, :714-752,
+:754-872) on top of the HIP sampling path, without Lightning, BioPython, RDKit
+or OpenBabel:
+
+  * `LigandGenerator.from_checkpoint(path)` reads a reference training
+    checkpoint (Lightning format: `hyper_parameters` + `state_dict` with the
+    `ddpm.` prefix) and builds the drop-in modules with the same keyword
+    arguments the reference passes (`lightning_modules.py:137-173`);
+  * `generate_ligands(...)` keeps the reference's signature and tensor logic:
+    pocket selection, size sampling, conditional sampling or joint inpainting,
+    moving the result back to the pocket frame, molecule building.
+
+Molecules are built with the distance-table bonds of `molecules.py` (the
+reference's `use_openbabel=False` path); `sanitize` / `relax_iter` need RDKit and
+are refused here (convert with `Molecule.to_rdkit()` where RDKit exists).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from . import pocket as pocket_io
+from .chem_tables import dataset_info
+from .conditional_model import ConditionalDDPM, SimpleConditionalDDPM
+from .dynamics import EGNNDynamics
+from .en_diffusion import EnVariationalDiffusion, num_nodes_to_batch_mask, seg_mean
+from .molecules import build_molecules
+
+_DDPM_BY_MODE = {"joint": EnVariationalDiffusion,
+                 "pocket_conditioning": ConditionalDDPM,
+                 "pocket_conditioning_simple": SimpleConditionalDDPM}
+
+
+def _get(ns, key, default=None):
+    """Hyper-parameters are argparse.Namespace objects or dicts, depending on
+    how the checkpoint was written."""
+    if isinstance(ns, dict):
+        return ns.get(key, default)
+    return getattr(ns, key, default)
+
+
+def load_checkpoint(path, trusted=False):
+    """-> (hyper_parameters dict, state_dict).  The file is unpickled with
+    `weights_only=True` plus the few plain-data classes Lightning stores; pass
+    trusted=True to fall back to a full unpickle for files you wrote yourself."""
+    safe = [argparse.Namespace]
+    try:
+        import numpy.core.multiarray as _ncm  # numpy < 2 name, kept as alias in numpy 2
+        safe += [_ncm._reconstruct, np.ndarray, np.dtype]
+        safe += [type(np.dtype(np.float64)), type(np.dtype(np.int64)), type(np.dtype(np.float32))]
+    except Exception:   # pragma: no cover
+        pass
+    try:
+        with torch.serialization.safe_globals(safe):
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        if not trusted:
+            raise
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    if "state_dict" not in ckpt or "hyper_parameters" not in ckpt:
+        raise ValueError(f"{path}: not a Lightning checkpoint (need 'state_dict' and 'hyper_parameters')")
+    return ckpt["hyper_parameters"], ckpt["state_dict"]
+
+
+class LigandGenerator:
+    """Sampling-only counterpart of the reference's LightningModule."""
+
+    def __init__(self, dataset, egnn_params, diffusion_params, mode, node_histogram,
+                 pocket_representation="CA", virtual_nodes=False, device="cuda"):
+        if mode not in _DDPM_BY_MODE:
+            raise ValueError(f"mode must be one of {sorted(_DDPM_BY_MODE)}")
+        if pocket_representation not in ("CA", "full-atom"):
+            raise ValueError("pocket_representation must be 'CA' or 'full-atom'")
+        if virtual_nodes:
+            raise NotImplementedError("virtual_nodes checkpoints are not supported by the sampling path")
+        self.mode = mode
+        self.pocket_representation = pocket_representation
+        self.dataset_name = dataset
+        self.dataset_info = dataset_info(dataset)
+        self.device = torch.device(device)
+        info = self.dataset_info
+        self.lig_type_encoder, self.lig_type_decoder = info["atom_encoder"], info["atom_decoder"]
+        ca = pocket_representation == "CA"
+        self.pocket_type_encoder = info["aa_encoder"] if ca else info["atom_encoder"]
+        self.pocket_type_decoder = info["aa_decoder"] if ca else info["atom_decoder"]
+        self.atom_nf, self.aa_nf, self.x_dims = len(self.lig_type_decoder), len(self.pocket_type_decoder), 3
+        self.T = _get(diffusion_params, "diffusion_steps")
+        # same keyword arguments as lightning_modules.py:137-159
+        dyn = EGNNDynamics(
+            atom_nf=self.atom_nf, residue_nf=self.aa_nf, n_dims=self.x_dims,
+            joint_nf=_get(egnn_params, "joint_nf"), device=self.device,
+            hidden_nf=_get(egnn_params, "hidden_nf"), act_fn=torch.nn.SiLU(),
+            n_layers=_get(egnn_params, "n_layers"), attention=_get(egnn_params, "attention"),
+            tanh=_get(egnn_params, "tanh"), norm_constant=_get(egnn_params, "norm_constant"),
+            inv_sublayers=_get(egnn_params, "inv_sublayers"),
+            sin_embedding=_get(egnn_params, "sin_embedding"),
+            normalization_factor=_get(egnn_params, "normalization_factor"),
+            aggregation_method=_get(egnn_params, "aggregation_method"),
+            edge_cutoff_ligand=_get(egnn_params, "edge_cutoff_ligand"),
+            edge_cutoff_pocket=_get(egnn_params, "edge_cutoff_pocket"),
+            edge_cutoff_interaction=_get(egnn_params, "edge_cutoff_interaction"),
+            update_pocket_coords=(mode == "joint"),
+            reflection_equivariant=_get(egnn_params, "reflection_equivariant"),
+            edge_embedding_dim=_get(egnn_params, "edge_embedding_dim"))
+        # lightning_modules.py:161-173
+        self.ddpm = _DDPM_BY_MODE[mode](
+            dynamics=dyn, atom_nf=self.atom_nf, residue_nf=self.aa_nf, n_dims=self.x_dims,
+            timesteps=self.T, noise_schedule=_get(diffusion_params, "diffusion_noise_schedule"),
+            noise_precision=_get(diffusion_params, "diffusion_noise_precision"),
+            loss_type=_get(diffusion_params, "diffusion_loss_type"),
+            norm_values=_get(diffusion_params, "normalize_factors"),
+            size_histogram=np.asarray(node_histogram), virtual_node_idx=None).to(self.device)
+        self.ddpm.eval()
+
+    # -- construction from a reference checkpoint ---------------------------------------
+    @classmethod
+    def from_checkpoint(cls, path, device="cuda", trusted=False):
+        hp, sd = load_checkpoint(path, trusted=trusted)
+        gen = cls(dataset=hp["dataset"], egnn_params=hp["egnn_params"],
+                  diffusion_params=hp["diffusion_params"], mode=hp["mode"],
+                  node_histogram=hp["node_histogram"],
+                  pocket_representation=hp.get("pocket_representation", "CA"),
+                  virtual_nodes=hp.get("virtual_nodes", False), device=device)
+        own = {k[len("ddpm."):]: v for k, v in sd.items() if k.startswith("ddpm.")}
+        missing, unexpected = gen.ddpm.load_state_dict(own, strict=False)
+        # `.4.weight` of the cross-product head aliases the coordinate head in the reference
+        # (egnn_new.py:88-92); older checkpoints may or may not carry both names
+        real_missing = [k for k in missing if "cross_product_mlp.4" not in k]
+        if real_missing or unexpected:
+            raise ValueError(f"{path}: state_dict mismatch, missing {real_missing[:5]}, "
+                             f"unexpected {list(unexpected)[:5]}")
+        gen.ddpm.dynamics.invalidate_engine()
+        return gen
+
+    # -- lightning_modules.py:714-752 ------------------------------------------------------
+    def prepare_pocket(self, residues, repeats=1):
+        if self.pocket_representation == "CA":
+            coords, types, n_types = pocket_io.featurize_pocket(residues, "CA")
+        else:
+            coords, types, n_types = pocket_io.featurize_pocket(residues, "full-atom",
+                                                                atom_encoder=self.pocket_type_encoder)
+        return pocket_io.prepare_pocket(coords, types, len(self.pocket_type_encoder), repeats, self.device)
+
+    def select_pocket_residues(self, pdb_file, pocket_ids=None, ref_ligand=None):
+        """Residue selection of generate_ligands (lightning_modules.py:781-795,
+        utils.py:101-128): a list of `<chain>:<resi>` ids, or everything within 8 A of
+        a reference ligand given as an SDF path or as `<chain>:<resi>` of the PDB."""
+        assert (pocket_ids is None) ^ (ref_ligand is None)
+        residues = pocket_io.read_pdb_residues(pdb_file, hetero=True)
+        if pocket_ids is not None:
+            by_id = {(r["chain"], r["resseq"]): r for r in residues if not r.get("hetero")}
+            return [by_id[(x.split(":")[0], int(x.split(":")[1]))] for x in pocket_ids]
+        if str(ref_ligand).endswith(".sdf"):
+            lig_xyz, skip = pocket_io.read_sdf_coords(ref_ligand), None
+        else:
+            chain, resi = ref_ligand.split(":")
+            hit = [r for r in residues if r["chain"] == chain and r["resseq"] == int(resi)]
+            assert len(hit) == 1, f"{ref_ligand}: {len(hit)} residues match"
+            lig_xyz = np.asarray([a[2] for a in hit[0]["atoms"]], np.float32)
+            skip = int(resi)
+        cand = [r for r in residues if r["resseq"] != skip]   # the reference skips that number in every chain
+        return pocket_io.pocket_residues_from_ligand(cand, lig_xyz)
+
+    # -- lightning_modules.py:754-872 ------------------------------------------------------
+    @torch.no_grad()
+    def generate_ligands(self, pdb_file, n_samples, pocket_ids=None, ref_ligand=None, num_nodes_lig=None,
+                         sanitize=False, largest_frag=False, relax_iter=0, timesteps=None,
+                         n_nodes_bias=0, n_nodes_min=0, **kwargs):
+        if sanitize or relax_iter:
+            raise NotImplementedError(
+                "sanitize / relax_iter are RDKit operations; take the returned molecules' "
+                ".to_rdkit() and apply the reference's process_molecule where RDKit is installed")
+        residues = self.select_pocket_residues(pdb_file, pocket_ids, ref_ligand)
+        pocket = self.prepare_pocket(residues, repeats=n_samples)
+        xh_lig, lig_mask = self.sample_for_pocket(pocket, n_samples, num_nodes_lig, timesteps,
+                                                  n_nodes_bias, n_nodes_min, **kwargs)
+        x = xh_lig[:, :self.x_dims]
+        atom_type = xh_lig[:, self.x_dims:].argmax(1)
+        return build_molecules(x, atom_type, lig_mask, self.dataset_info, largest_frag=largest_frag)
+
+    @torch.no_grad()
+    def sample_for_pocket(self, pocket, n_samples, num_nodes_lig=None, timesteps=None,
+                          n_nodes_bias=0, n_nodes_min=0, **kwargs):
+        """The tensor part of generate_ligands (lightning_modules.py:797-852):
+        returns (xh_lig in the pocket's original frame, lig_mask)."""
+        pocket_com_before = seg_mean(pocket["x"], pocket["mask"], n_samples)
+        if num_nodes_lig is None:
+            num_nodes_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket["size"])
+        num_nodes_lig = torch.as_tensor(num_nodes_lig, dtype=torch.int64)
+        num_nodes_lig = torch.clamp(num_nodes_lig + n_nodes_bias, min=n_nodes_min)
+        if type(self.ddpm) == EnVariationalDiffusion:
+            lig_mask = num_nodes_to_batch_mask(len(num_nodes_lig), num_nodes_lig, self.device)
+            ligand = {"x": torch.zeros((len(lig_mask), self.x_dims), device=self.device),
+                      "one_hot": torch.zeros((len(lig_mask), self.atom_nf), device=self.device),
+                      "size": num_nodes_lig.to(self.device), "mask": lig_mask}
+            lig_fixed = torch.zeros(len(lig_mask), device=self.device)
+            pocket_fixed = torch.ones(len(pocket["mask"]), device=self.device)
+            xh_lig, xh_pocket, lig_mask, pocket_mask = self.ddpm.inpaint(
+                ligand, pocket, lig_fixed, pocket_fixed, timesteps=timesteps, **kwargs)
+        elif type(self.ddpm) == ConditionalDDPM:
+            xh_lig, xh_pocket, lig_mask, pocket_mask = self.ddpm.sample_given_pocket(
+                pocket, num_nodes_lig, timesteps=timesteps)
+        else:
+            raise NotImplementedError
+        pocket_com_after = seg_mean(xh_pocket[:, :self.x_dims], pocket_mask, n_samples)
+        shift = pocket_com_before - pocket_com_after
+        xh_lig = xh_lig.clone()
+        xh_lig[:, :self.x_dims] += shift[lig_mask]
+        return xh_lig, lig_mask
+
+
+def main(argv=None):
+    """`python -m diffsbdd_amd.generate <checkpoint> --pdbfile ... --outfile ...`:
+    same options as the reference's generate_ligands.py (:13-27)."""
+    from .molecules import write_sdf
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("checkpoint")
+    ap.add_argument("--pdbfile", required=True)
+    ap.add_argument("--resi_list", nargs="+", default=None)
+    ap.add_argument("--ref_ligand", default=None)
+    ap.add_argument("--outfile", required=True)
+    ap.add_argument("--n_samples", type=int, default=20)
+    ap.add_argument("--batch_size", type=int, default=None)
+    ap.add_argument("--num_nodes_lig", type=int, default=None)
+    ap.add_argument("--all_frags", action="store_true")
+    ap.add_argument("--sanitize", action="store_true")
+    ap.add_argument("--relax", action="store_true")
+    ap.add_argument("--resamplings", type=int, default=10)
+    ap.add_argument("--jump_length", type=int, default=1)
+    ap.add_argument("--timesteps", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=0, help="noise is keyed by (seed, global sample index)")
+    ap.add_argument("--trusted-checkpoint", action="store_true",
+                    help="allow a full unpickle of the checkpoint file")
+    a = ap.parse_args(argv)
+    bs = a.batch_size or a.n_samples
+    assert a.n_samples % bs == 0
+    gen = LigandGenerator.from_checkpoint(a.checkpoint, device="cuda", trusted=a.trusted_checkpoint)
+    molecules = []
+    for i in range(a.n_samples // bs):
+        gen.ddpm.seed(a.seed, sample_offset=i * bs)
+        n_lig = None if a.num_nodes_lig is None else torch.full((bs,), a.num_nodes_lig, dtype=torch.int64)
+        molecules += gen.generate_ligands(
+            a.pdbfile, bs, a.resi_list, a.ref_ligand, n_lig, a.sanitize, largest_frag=not a.all_frags,
+            relax_iter=(200 if a.relax else 0), resamplings=a.resamplings, jump_length=a.jump_length,
+            timesteps=a.timesteps)
+    write_sdf(a.outfile, molecules)
+    print(f"wrote {len(molecules)} molecules to {a.outfile}")
+
+
+if __name__ == "__main__":
+    main()

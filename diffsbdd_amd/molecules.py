@@ -1,0 +1,163 @@
+"""Finished point clouds -> molecular graphs, without RDKit / OpenBabel
+(SURVEY.md §8f-2).
+
+The reference builds one RDKit molecule per sample on the host, by default
+through an OpenBabel temp-file round trip (analysis/molecule_builder.py:58-98);
+its distance-table path (`make_mol_edm`, :101-137, `get_bond_order_batch`,
+:30-55) is the batchable one and is what this module implements: bond orders of
+the whole batch in one HIP launch (`dsbdd_bond_orders`), one small device->host
+copy, then plain-Python graph objects that can be written as V2000 SDF or, when
+RDKit is installed, converted with `Molecule.to_rdkit()` for the reference's
+`process_molecule` filters (:162-214).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .chem_tables import dataset_info
+
+
+@dataclass
+class Molecule:
+    positions: np.ndarray                 # [n, 3] float32, Angstrom
+    symbols: list                         # element symbols
+    bonds: list = field(default_factory=list)   # (i, j, order) with i > j
+
+    @property
+    def num_atoms(self):
+        return len(self.symbols)
+
+    def fragments(self):
+        """Connected components (lists of atom indices), largest first; ties
+        keep the component with the smallest atom index first."""
+        parent = list(range(self.num_atoms))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+
+        for i, j, _ in self.bonds:
+            ri, rj = find(i), find(j)
+            if ri != rj:
+                parent[max(ri, rj)] = min(ri, rj)
+        comp = {}
+        for a in range(self.num_atoms):
+            comp.setdefault(find(a), []).append(a)
+        return sorted(comp.values(), key=lambda c: (-len(c), c[0]))
+
+    def largest_fragment(self):
+        """What `process_molecule(largest_frag=True)` keeps (molecule_builder.py:188-196)."""
+        frags = self.fragments()
+        if len(frags) <= 1:
+            return self
+        keep = frags[0]
+        new_index = {a: k for k, a in enumerate(keep)}
+        bonds = [(new_index[i], new_index[j], o) for i, j, o in self.bonds
+                 if i in new_index and j in new_index]
+        return Molecule(self.positions[keep], [self.symbols[a] for a in keep], bonds)
+
+    def to_sdf_block(self, name=""):
+        """V2000 mol block + `$$$$` record separator."""
+        lines = [name, "  diffsbdd_amd", ""]
+        lines.append(f"{self.num_atoms:3d}{len(self.bonds):3d}  0  0  0  0  0  0  0  0999 V2000")
+        for (x, y, z), s in zip(self.positions, self.symbols):
+            lines.append(f"{x:10.4f}{y:10.4f}{z:10.4f} {s:<3s} 0  0  0  0  0  0  0  0  0  0  0  0")
+        for i, j, o in self.bonds:
+            lines.append(f"{j + 1:3d}{i + 1:3d}{o:3d}  0")
+        lines += ["M  END", "$$$$"]
+        return "\n".join(lines) + "\n"
+
+    def to_rdkit(self):
+        """RDKit molecule with a conformer (the object the reference's
+        `build_molecule(..., add_coords=True)` returns); needs RDKit."""
+        from rdkit import Chem  # noqa: WPS433  (optional dependency)
+        order = {1: Chem.rdchem.BondType.SINGLE, 2: Chem.rdchem.BondType.DOUBLE,
+                 3: Chem.rdchem.BondType.TRIPLE}
+        mol = Chem.RWMol()
+        for s in self.symbols:
+            mol.AddAtom(Chem.Atom(s))
+        for i, j, o in self.bonds:
+            mol.AddBond(int(i), int(j), order[int(o)])
+        conf = Chem.Conformer(mol.GetNumAtoms())
+        for a, (x, y, z) in enumerate(self.positions):
+            conf.SetAtomPosition(a, (float(x), float(y), float(z)))
+        mol.AddConformer(conf)
+        return mol
+
+
+def write_sdf(path, molecules, names=None):
+    with open(path, "w") as f:
+        for k, m in enumerate(molecules):
+            f.write(m.to_sdf_block(names[k] if names else f"mol_{k}"))
+
+
+def _tables_on(device, info):
+    key = (info["name"], str(device))
+    cache = _tables_on.cache
+    if key not in cache:
+        cache[key] = tuple(torch.as_tensor(np.ascontiguousarray(info[k]), dtype=torch.float32, device=device)
+                           for k in ("bonds1", "bonds2", "bonds3"))
+    return cache[key]
+
+
+_tables_on.cache = {}
+
+
+def bond_orders(x, atom_type, lig_mask, info, n_max=None):
+    """Bond-order matrices of a batch on the GPU.
+
+    x [N,3] float32 (Angstrom), atom_type [N] integer class ids, lig_mask [N]
+    sorted sample ids (as returned by the samplers).  Returns (orders int8
+    [B, n_max, n_max] strictly lower triangular, sizes int64 [B]) on x's device.
+    """
+    if not x.is_cuda:
+        raise _lib.HipLibraryError("bond_orders needs device tensors (HIP path; no CPU fallback)")
+    lib = _lib.load()
+    dev = x.device
+    x = x.contiguous().float()
+    at = atom_type.to(device=dev, dtype=torch.int32).contiguous()
+    B = int(lig_mask.max().item()) + 1 if lig_mask.numel() else 0
+    sizes = torch.bincount(lig_mask.to(dev), minlength=B)
+    off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    off[1:] = torch.cumsum(sizes, 0).to(torch.int32)
+    if n_max is None:
+        n_max = int(sizes.max().item())
+    b1, b2, b3 = _tables_on(dev, info)
+    m1, m2, m3 = info["margins"]
+    out = torch.empty((B, n_max, n_max), dtype=torch.int8, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.dsbdd_bond_orders(stream, x.data_ptr(), at.data_ptr(), off.data_ptr(), B, b1.shape[0],
+                               b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), m1, m2, m3, n_max,
+                               out.data_ptr())
+    _lib.check(rc, "dsbdd_bond_orders")
+    return out, sizes
+
+
+def build_molecules(x, atom_type, lig_mask, info, largest_frag=False):
+    """Batch version of `build_molecule(..., use_openbabel=False)` +
+    `process_molecule(largest_frag=...)` (molecule_builder.py:140-160, 162-214):
+    list of `Molecule`, one per sample, in sample order."""
+    if isinstance(info, str):
+        info = dataset_info(info)
+    orders, sizes = bond_orders(x, atom_type, lig_mask, info)
+    orders = orders.cpu().numpy()
+    sizes = sizes.cpu().numpy()
+    xs = x.detach().float().cpu().numpy()
+    ts = atom_type.detach().cpu().numpy()
+    dec = info["atom_decoder"]
+    mols, o = [], 0
+    for b, n in enumerate(sizes):
+        n = int(n)
+        ii, jj = np.nonzero(orders[b, :n, :n])
+        bonds = [(int(i), int(j), int(orders[b, i, j])) for i, j in zip(ii, jj)]
+        m = Molecule(xs[o:o + n].copy(), [dec[int(t)] for t in ts[o:o + n]], bonds)
+        mols.append(m.largest_fragment() if largest_frag else m)
+        o += n
+    return mols

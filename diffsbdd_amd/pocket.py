@@ -34,17 +34,20 @@ def read_sdf_coords(path):
     return np.asarray(xyz, dtype=np.float32)
 
 
-def read_pdb_residues(path, model=0):
+def read_pdb_residues(path, model=0, hetero=False):
     """Fixed-column PDB reader (first model, ATOM records, altloc ' '/'A').
     Returns a list of residues in file order; each residue is a dict
-    {'chain','resseq','icode','resname','atoms': [(name, element, xyz)]}."""
+    {'chain','resseq','icode','resname','atoms': [(name, element, xyz)]}.
+    hetero=True also returns HETATM groups (flagged 'hetero': True) so that a
+    ligand can be addressed as <chain>:<resi> (utils.py:111-116)."""
     residues, index = [], {}
     with open(path) as f:
         for line in f:
             rec = line[0:6]
             if rec.startswith("ENDMDL"):
                 break
-            if not rec.startswith("ATOM"):
+            het = rec.startswith("HETATM")
+            if not (rec.startswith("ATOM") or (hetero and het)):
                 continue
             if line[16] not in (" ", "A"):
                 continue
@@ -57,11 +60,11 @@ def read_pdb_residues(path, model=0):
             elem = line[76:78].strip() if len(line) >= 78 else ""
             if not elem:
                 elem = "".join(c for c in name if c.isalpha())[:1]
-            key = (chain, resseq, icode)
+            key = (chain, resseq, icode, het)
             if key not in index:
                 index[key] = len(residues)
                 residues.append(dict(chain=chain, resseq=resseq, icode=icode,
-                                     resname=resname, atoms=[]))
+                                     resname=resname, atoms=[], hetero=het))
             residues[index[key]]["atoms"].append((name, elem.capitalize(), xyz))
     return residues
 

@@ -221,6 +221,21 @@ int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig,
                       int32_t* poc_off, int32_t* deg, int32_t* row_ptr, int32_t* edge_row,
                       int32_t* edge_col, float* edge_d0, int64_t edge_capacity, int32_t* status);
 
+/* ---- post-processing of a finished batch ------------------*/
+/* Distance-based bond orders of a batch of molecules: replaces
+ * get_bond_order_batch + the (X, A, E) step of make_mol_edm
+ * (analysis/molecule_builder.py:30-55, :101-118).  x [N][3] in Angstrom,
+ * atom_type [N] indices into the [n_types][n_types] single/double/triple
+ * length tables (pm), mol_off [batch+1] first atom of each molecule.
+ * order [batch][n_max][n_max] int8 receives the strictly lower triangle
+ * (order[b][i][j], i > j: 0 none, 1 single, 2 double, 3 triple); everything
+ * else is set to 0.  Molecules longer than n_max are truncated to n_max atoms. */
+int dsbdd_bond_orders(void* stream, const float* x, const int32_t* atom_type,
+                      const int32_t* mol_off, int64_t batch, int32_t n_types,
+                      const float* bonds1, const float* bonds2, const float* bonds3,
+                      float margin1, float margin2, float margin3, int32_t n_max,
+                      int8_t* order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,43 @@ def import_reference():
                  or n.startswith("equivariant_diffusion.") or n == "utils"]:
         sys.modules["_ref_" + name] = sys.modules.pop(name)
     return mods
+
+
+def import_reference_chem():
+    """Returns (constants_mod, molecule_builder_mod) of the reference
+    (/root/reference/constants.py, analysis/molecule_builder.py) for the golden
+    vectors of the molecule post-processing row.  RDKit /
+    OpenBabel are absent here: only the pure-torch functions
+    (get_bond_order_batch, the tables) are usable."""
+    if not reference_available():
+        raise RuntimeError(f"reference not found under {REF_ROOT}")
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    chem = sys.modules["rdkit.Chem"]
+    bt = types.SimpleNamespace(SINGLE=1, DOUBLE=2, TRIPLE=3, AROMATIC=12)
+    if not hasattr(chem, "rdchem"):
+        chem.rdchem = types.SimpleNamespace(BondType=bt)
+    if "rdkit.Chem.rdForceFieldHelpers" not in sys.modules:
+        ff = types.ModuleType("rdkit.Chem.rdForceFieldHelpers")
+        ff.UFFOptimizeMolecule = lambda *a, **k: 0
+        ff.UFFHasAllMoleculeParams = lambda *a, **k: True
+        sys.modules["rdkit.Chem.rdForceFieldHelpers"] = ff
+        chem.rdForceFieldHelpers = ff
+    if "openbabel" not in sys.modules:
+        sys.modules["openbabel"] = types.ModuleType("openbabel")
+    import importlib.util
+    saved = {n: sys.modules.pop(n) for n in ("utils", "constants") if n in sys.modules}
+    sys.path.insert(0, REF_ROOT)
+    try:
+        import constants as const_mod
+        spec = importlib.util.spec_from_file_location(
+            "_ref_molecule_builder", os.path.join(REF_ROOT, "analysis", "molecule_builder.py"))
+        mb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mb)
+    finally:
+        sys.path.remove(REF_ROOT)
+        for n in ("utils", "constants"):
+            if n in sys.modules:
+                sys.modules["_ref_" + n] = sys.modules.pop(n)
+        sys.modules.update(saved)
+    return const_mod, mb
