@@ -215,6 +215,44 @@ class LigandGenerator:
         return xh_lig, lig_mask
 
 
+    # -- several different pockets in one batch ---------------------------
+    @torch.no_grad()
+    def generate_for_pockets(self, jobs, timesteps=None, largest_frag=False, n_nodes_bias=0,
+                             n_nodes_min=0, **kwargs):
+        """One sampling batch over several different pockets.
+
+        The reference's test driver (test.py:59-176) samples one pocket at a time; the
+        graph is block diagonal per sample (dynamics.py:170-172), so pockets of different
+        proteins can share a batch and keep the GPU full when a single pocket needs fewer
+        samples than fit.  `jobs`: list of (residues, n_samples, num_nodes_lig or None).
+        Returns one list of molecules per job.  With keyed noise (`ddpm.seed`) sample g of
+        the packed batch equals sample g of any other packing that gives it the same
+        global index."""
+        parts, sizes, counts = [], [], []
+        base = 0
+        for residues, n, n_lig in jobs:
+            pk = self.prepare_pocket(residues, repeats=n)
+            pk["mask"] = pk["mask"] + base
+            parts.append(pk)
+            if n_lig is None:
+                n_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pk["size"])
+            n_lig = torch.as_tensor(n_lig, dtype=torch.int64).cpu()
+            assert n_lig.numel() == n
+            sizes.append(n_lig)
+            counts.append(n)
+            base += n
+        pocket = {k: torch.cat([p[k] for p in parts]) for k in ("x", "one_hot", "size", "mask")}
+        xh_lig, lig_mask = self.sample_for_pocket(pocket, base, torch.cat(sizes), timesteps,
+                                                  n_nodes_bias, n_nodes_min, **kwargs)
+        mols = build_molecules(xh_lig[:, :self.x_dims], xh_lig[:, self.x_dims:].argmax(1), lig_mask,
+                               self.dataset_info, largest_frag=largest_frag)
+        out, o = [], 0
+        for n in counts:
+            out.append(mols[o:o + n])
+            o += n
+        return out
+
+
 def main(argv=None):
     """`python -m diffsbdd_amd.generate <checkpoint> --pdbfile ... --outfile ...`:
     same options as the reference's generate_ligands.py (:13-27)."""
