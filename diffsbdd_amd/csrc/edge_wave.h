@@ -193,17 +193,27 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       for (int g = 0; g < BK / 8; ++g) {
         const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
         if (g + 1 < BK / 8 || more) {                      // prefetch the next group's P/Q chunk
+#ifdef DSBDD_DIAG_NOGATHER
+          pn = make_float4(0.1f, 0.2f, 0.3f, 0.4f); qn4 = pn;   // DIAGNOSTIC ONLY
+#else
           pn = ld4(Pp + kb + 8);
           qn4 = ld4(Qp + kb + 8);
+#endif
         }
         const float4 wd4 = *reinterpret_cast<const float4*>(vq + kb + 4 * half);
         const float4 wz4 = *reinterpret_cast<const float4*>(vq + H + kb + 4 * half);
         const float4 tb4 = *reinterpret_cast<const float4*>(vq + (2 + my_ty) * H + kb + 4 * half);
         float a[4];
-        a[0] = silu(pc.x + qc.x + my_d * wd4.x + my_d0 * wz4.x + tb4.x);
-        a[1] = silu(pc.y + qc.y + my_d * wd4.y + my_d0 * wz4.y + tb4.y);
-        a[2] = silu(pc.z + qc.z + my_d * wd4.z + my_d0 * wz4.z + tb4.z);
-        a[3] = silu(pc.w + qc.w + my_d * wd4.w + my_d0 * wz4.w + tb4.w);
+#ifdef DSBDD_DIAG_NOSILU
+#define DSBDD_ACT(v) (v)   /* DIAGNOSTIC ONLY */
+#else
+#define DSBDD_ACT(v) silu(v)
+#endif
+        a[0] = DSBDD_ACT(pc.x + qc.x + my_d * wd4.x + my_d0 * wz4.x + tb4.x);
+        a[1] = DSBDD_ACT(pc.y + qc.y + my_d * wd4.y + my_d0 * wz4.y + tb4.y);
+        a[2] = DSBDD_ACT(pc.z + qc.z + my_d * wd4.z + my_d0 * wz4.z + tb4.z);
+        a[3] = DSBDD_ACT(pc.w + qc.w + my_d * wd4.w + my_d0 * wz4.w + tb4.w);
+#undef DSBDD_ACT
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -215,7 +225,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         pc = pn; qc = qn4;
       }
       ++bslice;
+#ifdef DSBDD_DIAG_NOBARRIER
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // DIAGNOSTIC ONLY (racy): vmcnt(0) without the workgroup barrier
+#else
       __syncthreads();
+#endif
     }
 
     // first P/Q chunk of the NEXT unit: in flight during the epilogue
@@ -227,6 +241,16 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     }
 
     // ================= wave-private epilogue =================
+#ifdef DSBDD_DIAG_NOEPI
+    if (MODE == MODE_GCL) {   // DIAGNOSTIC ONLY: consume the accumulators with 127 adds
+      float tot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += acc[c][r];
+      if (tot == 12345.678f) p.agg[lane] = tot;
+    } else
+#endif
     if (MODE == MODE_GCL) {
       // messages m = SiLU(acc + b2)   (egnn_new.py:18-19)
 #pragma unroll
