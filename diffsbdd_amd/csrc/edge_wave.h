@@ -112,6 +112,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // tracked by vmcnt; the __syncthreads() that ends a K step drains it (vmcnt(0)) and
   // publishes the slice to the other waves.
   auto streamB = [&](int q, int ks, int buf) {
+#ifdef DSBDD_DIAG_NODMA
+    return;   // DIAGNOSTIC ONLY: W2^T is never streamed
+#endif
     const float* src = p.mlp[qsel + q].W2T + (size_t)ks * BK * H + t * 4;
     float* dst = sB + buf * L::B_BUF + w * 256;          // wave-uniform
 #pragma unroll
@@ -219,7 +222,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         for (int i = 0; i < 4; ++i) {
           const float* brow = bcur + (8 * g + i) * H;
 #pragma unroll
+#ifdef DSBDD_DIAG_NOBREAD
+          for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], a[(i + c) & 3], acc[c]);   // DIAGNOSTIC ONLY
+#else
           for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
+#endif
         }
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         pc = pn; qc = qn4;
