@@ -70,12 +70,17 @@ struct dsbdd_engine {
   int64_t n_replay = 0, n_capture = 0, n_eager = 0;
   hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
                                       // legacy default stream, which cannot be captured)
-  ~dsbdd_engine() {
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  // captured graphs hold the raw weight / workspace pointers of the moment they were captured
+  void drop_graphs() {
     for (GraphEntry& g : graphs) {
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (g.graph) (void)hipGraphDestroy(g.graph);
     }
+    graphs.clear();
+  }
+  ~dsbdd_engine() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    drop_graphs();
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
   }
 };
@@ -184,6 +189,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
       return fail(DSBDD_ERR_ARG, "weight slot " + std::to_string(i) + " not 16-byte aligned");
     e->slots[i] = ptr;
   }
+  e->drop_graphs();
   e->has_weights = true;
   return DSBDD_OK;
 }
@@ -202,6 +208,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   WsLayout L = carve(e->cfg, nl, np, B, E);
   if (bytes < L.total) return fail(DSBDD_ERR_CAPACITY, "workspace too small");
   char* b = static_cast<char*>(ws);
+  e->drop_graphs();
   e->ws = b; e->ws_bytes = bytes;
   e->cap_lig = nl; e->cap_poc = np; e->cap_batch = B; e->cap_edges = E;
   e->node_batch = (int*)(b + L.off[0]); e->lig_off = (int*)(b + L.off[1]); e->poc_off = (int*)(b + L.off[2]);

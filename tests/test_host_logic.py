@@ -212,3 +212,50 @@ def test_c_abi_exports_every_declared_symbol():
     bad = make_config(**{**_hp(W.arch_cfg("small_cond")[0]), "hidden_nf": 96})
     assert lib.dsbdd_engine_create(ctypes.byref(bad), ctypes.byref(h)) == _lib.ERR_ARG
     assert b"hidden_nf" in lib.dsbdd_last_error()
+
+
+def test_c_abi_argument_and_state_errors():
+    """Error behaviour of the entry points that can be exercised without a GPU: every
+    misuse returns a negative DSBDD_ERR_* code with a message, nothing is launched."""
+    lib = _lib.load()
+    cfg = make_config(**_hp(W.arch_cfg("small_cond")[0]))
+    h = ctypes.c_void_p()
+    assert lib.dsbdd_engine_create(None, ctypes.byref(h)) == _lib.ERR_ARG
+    assert lib.dsbdd_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    n_slots = lib.dsbdd_engine_weight_slots(h)
+    assert n_slots == 20 + 2 * 24
+    # forward before weights / workspace
+    one = ctypes.c_void_p(4096)          # any non-null, never dereferenced on these paths
+    args = (h, None, one, one, one, 1, one, one, 4, 8, 1, None, None, 0, one, one, one)
+    assert lib.dsbdd_dynamics_forward(*args) == _lib.ERR_STATE
+    assert b"weights" in lib.dsbdd_last_error()
+    assert lib.dsbdd_dynamics_forward(None, *args[1:]) == _lib.ERR_ARG
+    # weights: wrong count, null slot, misaligned slot
+    arr = (ctypes.c_void_p * n_slots)(*([4096] * n_slots))
+    assert lib.dsbdd_engine_set_weights(h, arr, n_slots - 1) == _lib.ERR_ARG
+    arr_null = (ctypes.c_void_p * n_slots)(*([4096] * (n_slots - 1) + [None]))
+    assert lib.dsbdd_engine_set_weights(h, arr_null, n_slots) == _lib.ERR_ARG
+    arr_mis = (ctypes.c_void_p * n_slots)(*([4096] * (n_slots - 1) + [4100]))
+    assert lib.dsbdd_engine_set_weights(h, arr_mis, n_slots) == _lib.ERR_ARG
+    assert b"aligned" in lib.dsbdd_last_error()
+    assert lib.dsbdd_engine_set_weights(h, arr, n_slots) == 0
+    assert lib.dsbdd_dynamics_forward(*args) == _lib.ERR_STATE
+    assert b"workspace" in lib.dsbdd_last_error()
+    # workspace: misaligned, too small, too large for int32 indexing
+    need = lib.dsbdd_engine_workspace_bytes(h, 4, 8, 1, 144)
+    assert need > 0 and lib.dsbdd_engine_workspace_bytes(h, 4, 8, 0, 144) == 0
+    assert lib.dsbdd_engine_bind_workspace(h, ctypes.c_void_p(4096 + 64), need, 4, 8, 1, 144) == _lib.ERR_ARG
+    assert lib.dsbdd_engine_bind_workspace(h, ctypes.c_void_p(4096), need - 1, 4, 8, 1, 144) == _lib.ERR_CAPACITY
+    assert lib.dsbdd_engine_bind_workspace(h, ctypes.c_void_p(4096), need, 1 << 30, 8, 1, 144) == _lib.ERR_ARG
+    assert lib.dsbdd_engine_bind_workspace(h, ctypes.c_void_p(4096), need, 4, 8, 1, 144) == 0
+    # call sizes beyond the bound capacity, bad t count
+    big = list(args)
+    big[8] = 5
+    assert lib.dsbdd_dynamics_forward(*big) == _lib.ERR_CAPACITY
+    bad_t = list(args)
+    bad_t[5] = 3
+    assert lib.dsbdd_dynamics_forward(*bad_t) == _lib.ERR_ARG
+    lib.dsbdd_engine_destroy(h)
+    # stand-alone kernels validate too
+    assert lib.dsbdd_node_linear(None, None, 4, 4, None, 0, 0, one, 4, None, None, 0, one, 4, 1, 4, 0) == _lib.ERR_ARG
+    assert lib.dsbdd_bond_orders(None, one, one, one, 0, 10, one, one, one, 3.0, 2.0, 1.0, 8, one) == _lib.ERR_ARG
