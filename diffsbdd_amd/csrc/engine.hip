@@ -15,6 +15,7 @@
 #include "edge_mlp.h"
 #include "edge_pipe.h"
 #include "edge_wave.h"
+#include "edge_w16.h"
 #include "graph.h"
 #include "molecule.h"
 #include "node_linear.h"
@@ -49,6 +50,7 @@ struct dsbdd_engine {
   int n_cu = 256;
   int edge_bm = 64;    // 64-edge tiles, 2 workgroups per CU (measured faster than 128 / 1)
   int edge_pipe = 0;   // 1 = wave-specialised pipelined variant (edge_pipe.h): correct, but measured slower
+  int edge_w16 = 0;    // 16-edge wave tiles on v_mfma_f32_16x16x4_f32, 4 waves per SIMD (edge_w16.h)
   int edge_wave = 1;   // wave-owns-32-edges kernel with register-resident A operand (edge_wave.h)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
   bool profile = false;
@@ -155,6 +157,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   const char* ngp = getenv("DSBDD_NODE_GROUP");
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
   const char* ek = getenv("DSBDD_EDGE_KERNEL");
+  if (ek && !strcmp(ek, "w16")) e->edge_w16 = 1;
+  if (ek && !strcmp(ek, "wave")) e->edge_w16 = 0;
   if (ek && !strcmp(ek, "pipe")) { e->edge_pipe = 1; e->edge_wave = 0; }
   if (ek && !strcmp(ek, "tiled")) { e->edge_pipe = 0; e->edge_wave = 0; }
   *out = e;
@@ -313,6 +317,15 @@ static hipError_t launch_pipe_t(hipStream_t s, int mode, const EdgeArgs& a, int 
 }
 
 template <int H>
+static hipError_t launch_w16_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+  if (mode == MODE_GCL)
+    hipLaunchKernelGGL((edge_w16_kernel<H, MODE_GCL>), dim3(grid), dim3(64 * W16Waves<H>::value), 0, s, a);
+  else
+    hipLaunchKernelGGL((edge_w16_kernel<H, MODE_COORD>), dim3(grid), dim3(64 * W16Waves<H>::value), 0, s, a);
+  return hipGetLastError();
+}
+
+template <int H>
 static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
   if (mode == MODE_GCL)
     hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
@@ -324,6 +337,24 @@ static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int 
 static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
                               int64_t edge_bound) {
   const int H = e->cfg.hidden_nf;
+  if (e->edge_w16) {    // 16-edge wave tiles, 8 or 6 waves per workgroup, 2 workgroups per CU
+    const int bmb = 16 * (H > 128 ? 12 : 8);
+    int64_t tiles = (edge_bound + bmb - 1) / bmb;
+    int64_t resident = (H > 128 ? 1LL : 2LL) * e->n_cu;
+    const bool two = mode == MODE_COORD && a.n_mlp == 2;
+    int64_t g = two ? 2 * tiles : tiles;
+    if (g > resident) g = resident;
+    const int q8 = two ? 16 : 8;
+    int grid = (int)((g + q8 - 1) / q8 * q8);
+    if (grid < q8) grid = q8;
+    switch (H) {
+      case 64: return launch_w16_t<64>(s, mode, a, grid);
+      case 128: return launch_w16_t<128>(s, mode, a, grid);
+      case 192: return launch_w16_t<192>(s, mode, a, grid);
+      case 256: return launch_w16_t<256>(s, mode, a, grid);
+    }
+    return hipErrorInvalidValue;
+  }
   if (e->edge_wave) {   // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU
     int64_t tiles = (edge_bound + 127) / 128;
     int64_t resident = 2LL * e->n_cu;

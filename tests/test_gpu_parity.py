@@ -266,6 +266,17 @@ def test_run_to_run_agreement_and_kernel_variants():
         assert torch.equal(d1, d2), (kern, tile)          # segmented sums: <= 2 commuting atomics per address
         assert (a - d1).abs().max().item() < 1e-5, (kern, tile)
         assert (d1.cpu() - c.t("eps_lig")).abs().max().item() < TOL, (kern, tile)
+    for kern in ("wave", "w16"):                          # the two register-A kernels: atomics, roundoff agreement
+        os.environ["DSBDD_EDGE_KERNEL"] = kern
+        try:
+            mv = make_dynamics(c.cfg, sd)
+            d1, _, _ = mv.forward_async(*args)
+            d2, _, _ = mv.forward_async(*args)
+        finally:
+            del os.environ["DSBDD_EDGE_KERNEL"]
+        assert (d1 - d2).abs().max().item() < 1e-6, kern
+        assert (a - d1).abs().max().item() < 1e-5, kern
+        assert (d1.cpu() - c.t("eps_lig")).abs().max().item() < TOL, kern
 
 
 # ---------------------------------------------------------------------------
@@ -476,7 +487,8 @@ def _random_problem(cfg, n_lig, n_poc, seed, lig_shift=None, spread=3.0):
 
 
 @pytest.mark.parametrize("arch,kernel", [("small_cond", "wave"), ("small_cond", "tiled"), ("small_variant", "wave"),
-                                         ("small_joint", "wave")])
+                                         ("small_joint", "wave"), ("small_cond", "w16"), ("small_variant", "w16"),
+                                         ("small_joint", "w16")])
 def test_rows_spanning_many_tiles(arch, kernel):
     """A 150-atom ligand: fully connected ligand rows have degree > 150, so one
     row's edge segment spans 5+ wave tiles / 2+ workgroup tiles."""
