@@ -46,6 +46,10 @@ struct EdgeMlpW {
   const float* table;  // [3][H]
   const float* W2T;    // [H][H]
   const float* b2;     // [H]
+  // optional: W2T with the columns of every row regrouped per MFMA lane,
+  // W2TP[k][j * (H/32) + c] = W2T[k][c * 32 + j], so that lane j finds the B values of all its
+  // column tiles in consecutive words (16-byte LDS reads in edge_wave.h); nullptr = not available
+  const float* W2TP;
 };
 
 struct EdgeArgs {

@@ -53,7 +53,7 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int H, int MODE>
+template <int H, int MODE, bool BPERM>
 __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   using L = WaveLayout<H, MODE>;
   constexpr int BK = L::BK;
@@ -67,6 +67,13 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // s_setprio 1 around every MFMA cluster: the two workgroups sharing a CU are in different
   // phases, so favouring the wave that has MFMAs ready keeps the matrix pipe fed (+2.7 %)
   constexpr bool SETPRIO = true;
+  // B operand from the lane-grouped W2^T copy (EdgeMlpW::W2TP): lane j finds the values of all its
+  // column tiles in CT consecutive words -> one (CT = 4) or two (CT = 8) ds_read_b128 per k step
+  // instead of CT/2 ds_read2_b32.  For CT = 8 the two 16-byte halves are read in swapped order by
+  // the lanes with bit 3 set, which spreads a ds_read_b128 lane group over all 16 slots of the
+  // 256-byte bank row; accumulator tile c of such a lane then holds feature tile c ^ 4.
+  static_assert(!BPERM || CT == 8 || CT == 4, "lane-grouped B reads need 4 or 8 column tiles");
+  constexpr bool bperm = BPERM;
 
   __shared__ float smem[L::TOTAL];
   float* sB = smem;                         // [2][BK][H]
@@ -97,6 +104,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // segment (<= 1 ulp from the reference's division)
   const float inv_norm = 1.0f / p.norm_factor;
 
+  const int swb = (bperm && CT == 8) ? ((j >> 3) & 1) : 0;          // this lane reads its halves swapped
+  auto feat = [&](int c) { return ((c ^ (4 * swb)) * 32) + j; };    // feature held by accumulator tile c
+
   const int E = *p.e_count;
   const int ntiles = (E + BMB - 1) / BMB;
   const int xcd = blockIdx.x & 7;
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #ifdef DSBDD_DIAG_NODMA
     return;   // DIAGNOSTIC ONLY: W2^T is never streamed
 #endif
-    const float* src = p.mlp[qsel + q].W2T + (size_t)ks * BK * H + t * 4;
+    const float* src = (bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H + t * 4;
     float* dst = sB + buf * L::B_BUF + w * 256;          // wave-uniform
 #pragma unroll
     for (int i = 0; i < BI; ++i)
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         if (kt == 0) fetch_idx(cbase + li + gx);
         if (kt == 1) fetch_x();
       }
-      const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + j;
+      const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
@@ -221,11 +231,24 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float* brow = bcur + (8 * g + i) * H;
-#pragma unroll
 #ifdef DSBDD_DIAG_NOBREAD
+#pragma unroll
           for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], a[(i + c) & 3], acc[c]);   // DIAGNOSTIC ONLY
 #else
-          for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
+          if constexpr (BPERM) {
+            float bv[CT];
+            const float4 lo = *reinterpret_cast<const float4*>(brow);
+            bv[0] = lo.x; bv[1] = lo.y; bv[2] = lo.z; bv[3] = lo.w;
+            if constexpr (CT == 8) {
+              const float4 hi = *reinterpret_cast<const float4*>(brow + 4 - 8 * swb);
+              bv[4] = hi.x; bv[5] = hi.y; bv[6] = hi.z; bv[7] = hi.w;
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], bv[c], acc[c]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
+          }
 #endif
         }
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       // messages m = SiLU(acc + b2)   (egnn_new.py:18-19)
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const float bv = vq[5 * H + c * 32 + j];
+        const float bv = vq[5 * H + feat(c)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = silu(acc[c][r] + bv);
       }
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const float aw = vq[6 * H + c * 32 + j];
+          const float aw = vq[6 * H + feat(c)];
 #pragma unroll
           for (int r = 0; r < 16; ++r) part[r] += acc[c][r] * aw;
         }
@@ -297,9 +320,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       int cur = -1;
       auto flush = [&](int owner) {                        // the owning half holds the full sums
         if (cur >= 0 && half == owner) {
-          float* dst = p.agg + (size_t)cur * H + j;
+          float* dst = p.agg + (size_t)cur * H;
 #pragma unroll
-          for (int c = 0; c < CT; ++c) unsafeAtomicAdd(dst + c * 32, sum[c] * inv_norm);
+          for (int c = 0; c < CT; ++c) unsafeAtomicAdd(dst + feat(c), sum[c] * inv_norm);
         }
       };
 #pragma unroll
@@ -335,7 +358,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const float bv = vq[5 * H + c * 32 + j], wv = vq[6 * H + c * 32 + j];
+        const float bv = vq[5 * H + feat(c)], wv = vq[6 * H + feat(c)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[r] += silu(acc[c][r] + bv) * wv;
       }

@@ -45,11 +45,13 @@ struct dsbdd_engine {
   int64_t cap_lig = 0, cap_poc = 0, cap_batch = 0, cap_edges = 0;
   int *node_batch, *lig_off, *poc_off, *deg, *row_ptr, *erow, *ecol;
   int *act_flag, *act_ptr, *act_list;
-  float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *pqg, *hout;
+  float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *pqg, *hout, *w2tp;
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   int edge_bm = 64;    // 64-edge tiles, 2 workgroups per CU (measured faster than 128 / 1)
   int edge_pipe = 0;   // 1 = wave-specialised pipelined variant (edge_pipe.h): correct, but measured slower
+  bool w2tp_ready = false;   // lane-grouped W2^T copies in the workspace are current
+  int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   int edge_w16 = 0;    // 16-edge wave tiles on v_mfma_f32_16x16x4_f32, 4 waves per SIMD (edge_w16.h)
   int edge_wave = 1;   // wave-owns-32-edges kernel with register-resident A operand (edge_wave.h)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
@@ -117,7 +119,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * PQ * 4,                  // 14 h 15 t1 16 agg 17 pq
       (size_t)N * JP * 4,                                                                           // 18 hout
       (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
-      (size_t)N * 2 * H * 4};                                                                       // 22 pqg (GCL P|Q)
+      (size_t)N * 2 * H * 4,                                                                        // 22 pqg (GCL P|Q)
+      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 4};                                     // 23 lane-grouped W2^T copies
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -152,6 +155,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (bm && atoi(bm) == 128) e->edge_bm = 128;
   const char* ug = getenv("DSBDD_GRAPH");
   if (ug && atoi(ug) == 0) e->use_graph = 0;
+  const char* bpe = getenv("DSBDD_EDGE_BPERM");
+  if (bpe && atoi(bpe) == 0) e->edge_bperm = 0;
   const char* csp = getenv("DSBDD_COORD_SPLIT");
   if (csp && atoi(csp) == 0) e->coord_split = 0;
   const char* ngp = getenv("DSBDD_NODE_GROUP");
@@ -194,6 +199,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
     e->slots[i] = ptr;
   }
   e->drop_graphs();
+  e->w2tp_ready = false;
   e->has_weights = true;
   return DSBDD_OK;
 }
@@ -224,6 +230,8 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->pq = (float*)(b + L.off[17]); e->hout = (float*)(b + L.off[18]);
   e->act_flag = (int*)(b + L.off[19]); e->act_ptr = (int*)(b + L.off[20]); e->act_list = (int*)(b + L.off[21]);
   e->pqg = (float*)(b + L.off[22]);
+  e->w2tp = (float*)(b + L.off[23]);
+  e->w2tp_ready = false;
   return DSBDD_OK;
 }
 
@@ -327,10 +335,21 @@ static hipError_t launch_w16_t(hipStream_t s, int mode, const EdgeArgs& a, int g
 
 template <int H>
 static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+  // lane-grouped W2^T copies present (EdgeMlpW::W2TP): 16-byte B-operand reads
+  constexpr bool can_perm = (H == 256 || H == 128);
+  if constexpr (can_perm) {
+    if (a.mlp[0].W2TP && a.mlp[1].W2TP) {
+      if (mode == MODE_GCL)
+        hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, true>), dim3(grid), dim3(kThreads), 0, s, a);
+      else
+        hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, true>), dim3(grid), dim3(kThreads), 0, s, a);
+      return hipGetLastError();
+    }
+  }
   if (mode == MODE_GCL)
-    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, false>), dim3(grid), dim3(kThreads), 0, s, a);
   else
-    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, false>), dim3(grid), dim3(kThreads), 0, s, a);
   return hipGetLastError();
 }
 
@@ -516,6 +535,23 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   const int* e_all = e->row_ptr + N;
   const int* e_upd = e->row_ptr + n_upd;                 // edges are row-sorted: a prefix
 
+  // lane-grouped copies of the three W2^T matrices of every block (see EdgeMlpW::W2TP)
+  const bool bperm = e->edge_bperm && e->edge_wave && !e->edge_w16 && (H == 256 || H == 128);
+  auto w2tp_of = [&](int blk, int which) -> const float* {   // which: 0 .. inv_sublayers-1 GCL, then coord, cross
+    return bperm ? e->w2tp + ((size_t)blk * (c.inv_sublayers + 2) + which) * H * H : nullptr;
+  };
+  if (bperm && !e->w2tp_ready) {
+    for (int blk = 0; blk < c.n_layers; ++blk)
+      for (int which = 0; which < c.inv_sublayers + 2; ++which) {
+        const float* src = which < c.inv_sublayers ? W[gcl_slot(c, blk, which, DSBDD_GCL_E2_WT)]
+                         : W[eq_slot(c, blk, which == c.inv_sublayers ? DSBDD_EQ_C_W2T : DSBDD_EQ_X_W2T)];
+        if (!src) continue;                                   // reflection-equivariant models have no cross MLP
+        hipLaunchKernelGGL(permute_w2t_kernel, dim3((H * H + 255) / 256), dim3(256), 0, s, src,
+                           const_cast<float*>(w2tp_of(blk, which)), H);
+        HIP_TRY(hipGetLastError());
+      }
+    e->w2tp_ready = true;
+  }
   auto gcl_pq = [&](int blk, int sub) {
     return NodeLinearArgs{e->h, H, H, nullptr, 0, 0, W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, nullptr,
                           nullptr, 0, e->pqg, 2 * H, (int)N, 2 * H, 0, nullptr, nullptr};
@@ -538,7 +574,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
-                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B)};
+                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
       ea.agg = e->agg; ea.norm_factor = c.normalization_factor;
@@ -581,10 +617,10 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
-                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2)};
+                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers)};
       if (n_mlp == 2)
         ea.mlp[1] = EdgeMlpW{e->pq + QW + H, e->pq + H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
-                             Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2)};
+                             Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2), w2tp_of(blk, c.inv_sublayers + 1)};
       else
         ea.mlp[1] = ea.mlp[0];
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;

@@ -155,6 +155,15 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
   if (t == 0) row_ptr[n] = carry;
 }
 
+// dst[k][j * CT + c] = src[k][c * 32 + j] for an [H][H] matrix, CT = H / 32 (see EdgeMlpW::W2TP).
+__global__ void permute_w2t_kernel(const float* src, float* dst, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * H) return;
+  const int k = i / H, o = i % H, ct = H / 32;
+  const int j = o / ct, c = o % ct;
+  dst[i] = src[k * H + c * 32 + j];
+}
+
 // Teacher-forced edge list: copy rows/cols, compute d0, build row_ptr counts.
 __global__ void ext_edges_kernel(const int* row, const int* col, int E, const float* x, int* erow,
                                  int* ecol, float* ed0, int* deg) {
