@@ -229,6 +229,7 @@ class HipEngine:
         return eps_lig, eps_pocket, status
 
     def profile(self, enable, max_launches=16384):
+        """enable: 0/False off, k > 0: time the GCL launches of every k-th forward call."""
         _lib.check(self.lib.dsbdd_engine_profile(self.handle, int(enable), int(max_launches)))
 
     def profile_read(self):

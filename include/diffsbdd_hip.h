@@ -150,10 +150,11 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig,
                            const int32_t* ext_col, int64_t ext_n_edges, float* eps_lig,
                            float* eps_pocket, int32_t* status);
 
-/* Timing of the dominant kernel (the fused GCL edge stage): while enabled,
- * every launch of that kernel inside dsbdd_dynamics_forward is bracketed by
- * hipEventRecord on the caller's stream (up to max_launches launches between
- * reads).  dsbdd_engine_profile_read waits for the recorded events, returns
+/* Timing of the dominant kernel (the fused GCL edge stage): with enable = k > 0,
+ * every launch of that kernel inside every k-th dsbdd_dynamics_forward call is
+ * bracketed by hipEventRecord on the caller's stream (up to max_launches timed
+ * launches between reads); those calls run eagerly, the others may replay their
+ * captured graph.  enable = 1 times every call, 0 switches timing off.  dsbdd_engine_profile_read waits for the recorded events, returns
  * the summed kernel time and the number of timed launches, and resets. */
 int dsbdd_engine_profile(dsbdd_engine* e, int enable, int max_launches);
 int dsbdd_engine_profile_read(dsbdd_engine* e, double* total_ms, int64_t* launches);
