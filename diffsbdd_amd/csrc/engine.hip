@@ -499,7 +499,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // ---- edges (dynamics.py:114, 169-187) ---------------------------------------
   int64_t edge_bound = e->cap_edges;
   if (ext) {
-    HIP_TRY(hipMemsetAsync(e->deg, 0, (size_t)N * 4, s));
+    HIP_TRY(zero_async(e->deg, (size_t)N * 4, s));
     if (ext_n_edges > 0) {
       hipLaunchKernelGGL(ext_edges_kernel, dim3((int)((ext_n_edges + 255) / 256)), dim3(256), 0, s, ext_row,
                          ext_col, (int)ext_n_edges, (const float*)e->x, e->erow, e->ecol, e->ed0, e->deg);
@@ -532,7 +532,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   }
   // ---- embedding (egnn_new.py:233) ---------------------------------------------
   HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
-  HIP_TRY(hipMemsetAsync(e->xagg, 0, (size_t)N * 12, s));
+  HIP_TRY(zero_async(e->xagg, (size_t)N * 12, s));
 
   const int n_upd = c.update_pocket_coords ? N : nlig;   // update_coords_mask, dynamics.py:130-132
   const int* e_all = e->row_ptr + N;
@@ -572,7 +572,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       // were launched together with the previous block's coordinate projections)
       if (!pqg_ready) HIP_TRY(launch_node_linear(s, gcl_pq(blk, sub)));
       pqg_ready = false;
-      HIP_TRY(hipMemsetAsync(e->agg, 0, (size_t)N * H * 4, s));
+      HIP_TRY(zero_async(e->agg, (size_t)N * H * 4, s));
       EdgeArgs ea{};
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = 2 * H;

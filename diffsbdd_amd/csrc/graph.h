@@ -155,6 +155,29 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
   if (t == 0) row_ptr[n] = carry;
 }
 
+// Zero fill as an ordinary kernel on the caller's stream.  hipMemsetAsync is avoided inside
+// dsbdd_dynamics_forward: its blit submissions were observed to lose their ordering against launches
+// of a captured graph on the same stream (profiles/README.md, "eager calls between graph replays").
+__global__ void zero_kernel(uint4* p, size_t n16, unsigned char* tail, int n_tail) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0;
+}
+
+// ptr must be 16-byte aligned (every workspace buffer is 256-byte aligned)
+inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const size_t n16 = bytes / 16;
+  const int n_tail = (int)(bytes % 16);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint4*>(ptr), n16,
+                     static_cast<unsigned char*>(ptr) + n16 * 16, n_tail);
+  return hipGetLastError();
+}
+
 // dst[k][j * CT + c] = src[k][c * 32 + j] for an [H][H] matrix, CT = H / 32 (see EdgeMlpW::W2TP).
 __global__ void permute_w2t_kernel(const float* src, float* dst, int H) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
