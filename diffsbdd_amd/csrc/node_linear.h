@@ -175,7 +175,7 @@ struct NodeGroupArgs { NodeLinearArgs p[kMaxGroup]; };
 
 template <int CT>
 __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga) {
-  constexpr int BN = 32 * CT, BK = 128 / CT, NG = BK / 8;
+  constexpr int BN = 32 * CT, BK = (CT == 1 ? 64 : 128 / CT), NG = BK / 8;
   constexpr int BI = BK * BN / 4 / kThreads;          // float4 DMA pieces per thread per slice
   constexpr int RQ = BN / 4;                          // float4 per slice row
   __shared__ float sB[2 * BK * BN];
@@ -279,14 +279,17 @@ inline bool vec_ok(const NodeLinearArgs& a) {
          (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
 }
 
-// column-tile count (2 or 4) of the register-A kernel for this problem, 0 = not eligible
-inline int gemm_ct(const NodeLinearArgs& a, int forced_ct) {
+// column-tile count (1, 2 or 4) of the register-A kernel for this problem, 0 = not eligible
+inline int gemm_ct(const NodeLinearArgs& a, int forced_ct, bool allow_small = true) {
   if (!vec_ok(a) || a.ldw % 4 != 0 || !aligned16(a.WT) || a.K1 <= 0) return 0;
   auto fits = [&](int ct) {
-    const int bk = 128 / ct, bn = 32 * ct;
+    const int bk = ct == 1 ? 64 : 128 / ct, bn = 32 * ct;
     return a.K1 % bk == 0 && a.K2 % bk == 0 && a.N % bn == 0;
   };
   if (forced_ct && fits(forced_ct)) return forced_ct;
+  // few rows (e.g. the C-alpha workloads, M ~ 2k): 32-column tiles make twice as many, half as long
+  // workgroups -- the launch is bounded by one workgroup's latency, not by throughput
+  if (allow_small && (long)((a.M + 127) / 128) * (a.N / 64) < 128 && fits(1)) return 1;
   if (a.N >= 512 && fits(4)) return 4;
   return fits(2) ? 2 : (fits(4) ? 4 : 0);
 }
@@ -303,9 +306,12 @@ inline int node_ct_override() {
 // Returns hipErrorInvalidValue when the group cannot share a launch.
 inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int n) {
   if (n <= 0 || n > kMaxGroup) return hipErrorInvalidValue;
+  // 32-column tiles only when every problem of the group is small
+  bool all_small = true;
+  for (int i = 0; i < n; ++i) all_small = all_small && gemm_ct(a[i], node_ct_override()) == 1;
   int ct = 4;
   for (int i = 0; i < n; ++i) {
-    const int c = gemm_ct(a[i], node_ct_override());
+    const int c = gemm_ct(a[i], node_ct_override(), all_small);
     if (c == 0) return hipErrorInvalidValue;
     if (c < ct) ct = c;
   }
@@ -319,8 +325,9 @@ inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int 
     gy = max(gy, a[i].N / (32 * ct));
   }
   dim3 grid(gx, gy, n), block(kThreads);
-  if (ct == 4) hipLaunchKernelGGL((node_gemm_kernel<4>), grid, block, 0, s, ga);
-  else         hipLaunchKernelGGL((node_gemm_kernel<2>), grid, block, 0, s, ga);
+  if (ct == 4)      hipLaunchKernelGGL((node_gemm_kernel<4>), grid, block, 0, s, ga);
+  else if (ct == 2) hipLaunchKernelGGL((node_gemm_kernel<2>), grid, block, 0, s, ga);
+  else              hipLaunchKernelGGL((node_gemm_kernel<1>), grid, block, 0, s, ga);
   return hipGetLastError();
 }
 
