@@ -181,7 +181,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         pocket = self._prepare_pocket(pocket, dev)
         ligand = self._prepare_pocket(ligand, dev)
         lig_fixed = lig_fixed.to(dev).float()
-        fixed = lig_fixed.bool().view(-1)
+        fixed = torch.nonzero(lig_fixed.view(-1) != 0).view(-1)   # row ids once: no per-step nonzero sync
         n = len(ligand['size'])
         nd = self.n_dims
         ligand, pocket = self.normalize(ligand, pocket)
@@ -190,8 +190,9 @@ class ConditionalDDPM(EnVariationalDiffusion):
         xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
         com_pocket_0 = seg_mean(pocket['x'], pm, n)
         xh_ligand = torch.cat([ligand['x'], ligand['one_hot']], dim=1).clone()
+        lm_fixed = lm[fixed]
         if center == 'ligand':
-            mean_known = seg_mean(ligand['x'][fixed], lm[fixed], n)
+            mean_known = seg_mean(ligand['x'][fixed], lm_fixed, n)
         elif center == 'pocket':
             mean_known = seg_mean(pocket['x'], pm, n)
         else:
@@ -215,8 +216,8 @@ class ConditionalDDPM(EnVariationalDiffusion):
                 xh_ligand[:, :nd] = ligand['x'] + (com_pocket - com_pocket_0)[lm]
                 z_known, xh_pocket, _ = self.noised_representation(xh_ligand, xh_pocket, lm, pm, g_s)
                 # align the COM of the fixed atoms of both parts, then blend
-                com_noised = seg_mean(z_known[fixed][:, :nd], lm[fixed], n)
-                com_denoised = seg_mean(z_unknown[fixed][:, :nd], lm[fixed], n)
+                com_noised = seg_mean(z_known[fixed][:, :nd], lm_fixed, n)
+                com_denoised = seg_mean(z_unknown[fixed][:, :nd], lm_fixed, n)
                 dx = com_denoised - com_noised
                 z_known[:, :nd] = z_known[:, :nd] + dx[lm]
                 xh_pocket[:, :nd] = xh_pocket[:, :nd] + dx[pm]

@@ -552,7 +552,10 @@ class EnVariationalDiffusion(nn.Module):
         lm = ligand['mask'].to(dev).contiguous()
         pm = pocket['mask'].to(dev).contiguous()
         lig_fixed, pocket_fixed = lig_fixed.to(dev).float(), pocket_fixed.to(dev).float()
-        lfb, pfb = lig_fixed.bool().view(-1), pocket_fixed.bool().view(-1)
+        # row ids of the fixed nodes, found once: boolean-mask indexing inside the loop would cost a
+        # host sync (nonzero) four times per step
+        lfb = torch.nonzero(lig_fixed.view(-1) != 0).view(-1)
+        pfb = torch.nonzero(pocket_fixed.view(-1) != 0).view(-1)
         comb = torch.cat((lm, pm))
         known_idx = torch.cat((lm[lfb], pm[pfb]))
         xh0_l = torch.cat([ligand['x'], ligand['one_hot']], dim=1).to(dev)
