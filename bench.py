@@ -11,7 +11,8 @@ reverse steps + the final decode = 501 EGNN evaluations).  Inputs are resident
 in HBM before the timed region; weights are seeded random (no checkpoint is
 reachable), pockets are the 3rfm full-atom pocket fixture repeated.
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run;
+For N > 1 either the driver launches one process per GPU with torch.distributed.run,
+or a plain `python bench.py --gpus N` starts the same job itself (self_launch);
 every rank runs its own 64 pockets (weak scaling, no data-path collective) and
 the finished ligands are gathered once per chain over RCCL.  value = ligands of
 all ranks / max-over-ranks wall time.
@@ -115,6 +116,21 @@ def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
             "torch_threads": torch.get_num_threads()}
 
 
+def self_launch(n):
+    """Re-exec this script under torch.distributed.run with n ranks on this node
+    (rendezvous on 127.0.0.1 and a free port); returns the job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,7 +141,8 @@ def main():
     ap.add_argument("--timesteps", type=int, default=None, help="DDPM steps (default: the config's 500)")
     ap.add_argument("--n-lig", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed reverse steps of the CPU baseline")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP-event timing of the dominant kernel on every k-th EGNN call (1 = every call)")
@@ -137,12 +154,14 @@ def main():
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one rank per GPU ourselves (the same launch the
+        # driver uses) and hand the result through; rank 0 of the child job prints the JSON line
+        sys.exit(self_launch(args.gpus))
     rank, local_rank, world = sharding.init_distributed(args.backend)
     if args.share_gpu:
         local_rank = 0
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
@@ -235,7 +254,8 @@ def main():
         }
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not joint:
-            cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, max_threads=args.cpu_threads)
+            cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, steps=args.cpu_steps,
+                               max_threads=args.cpu_threads)
         value = n_ligands_total / elapsed
         line = {
             "metric": METRIC, "value": value, "unit": "ligands/s", "n_gpus": world, "steps": args.steps,
@@ -251,6 +271,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
             "hipgraph": dict(zip(("replays", "captures", "eager_calls"), eng.graph_stats())),
+            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "backend": torch.distributed.get_backend() if world > 1 else None,
             "host_cores": os.cpu_count(),
         }
         print(json.dumps(line), flush=True)

@@ -98,7 +98,10 @@ class ConditionalDDPM(EnVariationalDiffusion):
         return self.sample_normal_zero_com(mu, xh0_pocket, sigma_ts, ligand_mask, pocket_mask, fix_noise)
 
     # ---- p(x, h | z_0) (conditional_model.py:112-135) ---------------------------------------------
-    def sample_p_xh_given_z0(self, z0_lig, xh0_pocket, lig_mask, pocket_mask, batch_size, fix_noise=False):
+    def sample_p_xh_given_z0(self, z0_lig, xh0_pocket, lig_mask, pocket_mask, batch_size, fix_noise=False,
+                             _in_chain=False):
+        if not _in_chain:
+            lig_mask, pocket_mask = self._begin_chain(lig_mask, pocket_mask, batch_size)
         dev = z0_lig.device
         nd = self.n_dims
         t0 = torch.zeros((batch_size, 1), device=dev)
@@ -136,6 +139,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         pm = pocket['mask']
         xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
         lig_mask = num_nodes_to_batch_mask(n, num_nodes_lig, dev).contiguous()
+        lig_mask, pm = self._begin_chain(lig_mask, pm, n)
 
         # z_T ~ N(pocket COM, I), then ligand-COM-free (conditional_model.py:501-508)
         mu_x = seg_mean(pocket['x'], pm, n)
@@ -156,7 +160,8 @@ class ConditionalDDPM(EnVariationalDiffusion):
         if self._remove_com:
             self.assert_mean_zero_with_mask(z_lig[:, :nd], lig_mask)
 
-        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lig_mask, pm, n)
+        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lig_mask, pm, n,
+                                                                     _in_chain=True)
         if self._remove_com:
             self.assert_mean_zero_with_mask(x_lig, lig_mask)
         if return_frames == 1:                                              # :541-547
@@ -185,7 +190,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         n = len(ligand['size'])
         nd = self.n_dims
         ligand, pocket = self.normalize(ligand, pocket)
-        lm, pm = ligand['mask'], pocket['mask']
+        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
 
         xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
         com_pocket_0 = seg_mean(pocket['x'], pm, n)
@@ -228,7 +233,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
                     idx = (s * return_frames) // timesteps
                     out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_lig, xh_pocket)
         self._check_status(status)
-        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n)
+        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n, _in_chain=True)
         out_lig[0] = torch.cat([x_lig, h_lig], dim=1)
         out_pocket[0] = torch.cat([x_pocket, h_pocket], dim=1)
         return out_lig.squeeze(0), out_pocket.squeeze(0), lm, pm
@@ -253,15 +258,16 @@ class ConditionalDDPM(EnVariationalDiffusion):
         pocket = self._prepare_pocket(pocket, dev)
         ligand = self._prepare_pocket(ligand, dev)
         ligand, pocket = self.normalize(ligand, pocket)
-        z_lig, xh_pocket, _ = self.partially_noised_ligand(ligand, pocket, noising_steps)
         n = len(pocket['size'])
-        lm, pm = ligand['mask'], pocket['mask']
+        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
+        ligand['mask'], pocket['mask'] = lm, pm
+        z_lig, xh_pocket, _ = self.partially_noised_ligand(ligand, pocket, noising_steps)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         co = self._coefs(self.T)
         for s in reversed(range(0, noising_steps)):
             self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
         self._check_status(status)
-        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n)
+        x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n, _in_chain=True)
         if self._remove_com:
             self.assert_mean_zero_with_mask(x_lig, lm)
         return torch.cat([x_lig, h_lig], dim=1), torch.cat([x_pocket, h_pocket], dim=1), lm, pm

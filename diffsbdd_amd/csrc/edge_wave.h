@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int swb = (bperm && CT == 8) ? ((j >> 3) & 1) : 0;          // this lane reads its halves swapped
   auto feat = [&](int c) { return ((c ^ (4 * swb)) * 32) + j; };    // feature held by accumulator tile c
 
-  const int E = *p.e_count;
+  const int E = min(*p.e_count, p.e_cap);
   const int ntiles = (E + BMB - 1) / BMB;
   const int xcd = blockIdx.x & 7;
   const int kx = split ? (blockIdx.x >> 4) : (blockIdx.x >> 3);

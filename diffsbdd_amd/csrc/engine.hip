@@ -13,9 +13,7 @@
 #include "common.h"
 #include "ddpm.h"
 #include "edge_mlp.h"
-#include "edge_pipe.h"
 #include "edge_wave.h"
-#include "edge_w16.h"
 #include "graph.h"
 #include "molecule.h"
 #include "node_linear.h"
@@ -48,12 +46,8 @@ struct dsbdd_engine {
   float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *pqg, *hout, *w2tp;
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
-  int edge_bm = 64;    // 64-edge tiles, 2 workgroups per CU (measured faster than 128 / 1)
-  int edge_pipe = 0;   // 1 = wave-specialised pipelined variant (edge_pipe.h): correct, but measured slower
   bool w2tp_ready = false;   // lane-grouped W2^T copies in the workspace are current
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
-  int edge_w16 = 0;    // 16-edge wave tiles on v_mfma_f32_16x16x4_f32, 4 waves per SIMD (edge_w16.h)
-  int edge_wave = 1;   // wave-owns-32-edges kernel with register-resident A operand (edge_wave.h)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
   int profile = 0;        // 0 off, k: the GCL launches of every k-th forward call are timed with HIP events
   int64_t prof_call = 0;
@@ -73,6 +67,8 @@ struct dsbdd_engine {
   int use_graph = 1;
   int coord_split = 1; // edge_wave MODE_COORD: one workgroup per (tile, MLP) (DSBDD_COORD_SPLIT=0: per tile)
   int node_group = 1;  // coordinate projections + next block's P|Q in one launch (DSBDD_NODE_GROUP=0: separate)
+  int edge_max_wg = 0;  // test hook (DSBDD_EDGE_MAX_WG): cap on the persistent edge grid, so that small problems
+                        // run several tiles per workgroup (the path large batches take)
   int64_t n_replay = 0, n_capture = 0, n_eager = 0;
   hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
                                       // legacy default stream, which cannot be captured)
@@ -153,8 +149,6 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
       prop.multiProcessorCount > 0)
     e->n_cu = prop.multiProcessorCount;
-  const char* bm = getenv("DSBDD_EDGE_TILE");
-  if (bm && atoi(bm) == 128) e->edge_bm = 128;
   const char* ug = getenv("DSBDD_GRAPH");
   if (ug && atoi(ug) == 0) e->use_graph = 0;
   const char* bpe = getenv("DSBDD_EDGE_BPERM");
@@ -163,11 +157,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (csp && atoi(csp) == 0) e->coord_split = 0;
   const char* ngp = getenv("DSBDD_NODE_GROUP");
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
-  const char* ek = getenv("DSBDD_EDGE_KERNEL");
-  if (ek && !strcmp(ek, "w16")) e->edge_w16 = 1;
-  if (ek && !strcmp(ek, "wave")) e->edge_w16 = 0;
-  if (ek && !strcmp(ek, "pipe")) { e->edge_pipe = 1; e->edge_wave = 0; }
-  if (ek && !strcmp(ek, "tiled")) { e->edge_pipe = 0; e->edge_wave = 0; }
+  const char* mwg = getenv("DSBDD_EDGE_MAX_WG");
+  if (mwg && atoi(mwg) > 0) e->edge_max_wg = atoi(mwg);
   *out = e;
   return DSBDD_OK;
 }
@@ -309,33 +300,6 @@ static hipError_t nl_rows(hipStream_t s, const float* A1, int lda1, int K1, cons
   return launch_node_linear(s, a);
 }
 
-template <int H, int BM, int BK>
-static hipError_t launch_edge_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
-  if (mode == MODE_GCL)
-    hipLaunchKernelGGL((edge_mlp_kernel<H, BM, BK, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
-  else
-    hipLaunchKernelGGL((edge_mlp_kernel<H, BM, BK, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
-  return hipGetLastError();
-}
-
-template <int H>
-static hipError_t launch_pipe_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
-  if (mode == MODE_GCL)
-    hipLaunchKernelGGL((edge_pipe_kernel<H, MODE_GCL>), dim3(grid), dim3(512), 0, s, a);
-  else
-    hipLaunchKernelGGL((edge_pipe_kernel<H, MODE_COORD>), dim3(grid), dim3(512), 0, s, a);
-  return hipGetLastError();
-}
-
-template <int H>
-static hipError_t launch_w16_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
-  if (mode == MODE_GCL)
-    hipLaunchKernelGGL((edge_w16_kernel<H, MODE_GCL>), dim3(grid), dim3(64 * W16Waves<H>::value), 0, s, a);
-  else
-    hipLaunchKernelGGL((edge_w16_kernel<H, MODE_COORD>), dim3(grid), dim3(64 * W16Waves<H>::value), 0, s, a);
-  return hipGetLastError();
-}
-
 template <int H>
 static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
   // lane-grouped W2^T copies present (EdgeMlpW::W2TP): 16-byte B-operand reads
@@ -359,71 +323,22 @@ static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int 
 static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
                               int64_t edge_bound) {
   const int H = e->cfg.hidden_nf;
-  if (e->edge_w16) {    // 16-edge wave tiles, 8 or 6 waves per workgroup, 2 workgroups per CU
-    const int bmb = 16 * (H > 128 ? 12 : 8);
-    int64_t tiles = (edge_bound + bmb - 1) / bmb;
-    int64_t resident = (H > 128 ? 1LL : 2LL) * e->n_cu;
-    const bool two = mode == MODE_COORD && a.n_mlp == 2;
-    int64_t g = two ? 2 * tiles : tiles;
-    if (g > resident) g = resident;
-    const int q8 = two ? 16 : 8;
-    int grid = (int)((g + q8 - 1) / q8 * q8);
-    if (grid < q8) grid = q8;
-    switch (H) {
-      case 64: return launch_w16_t<64>(s, mode, a, grid);
-      case 128: return launch_w16_t<128>(s, mode, a, grid);
-      case 192: return launch_w16_t<192>(s, mode, a, grid);
-      case 256: return launch_w16_t<256>(s, mode, a, grid);
-    }
-    return hipErrorInvalidValue;
-  }
-  if (e->edge_wave) {   // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU
-    int64_t tiles = (edge_bound + 127) / 128;
-    int64_t resident = 2LL * e->n_cu;
-    const bool split = mode == MODE_COORD && a.pass_split && a.n_mlp == 2;
-    int64_t g = split ? 2 * tiles : tiles;             // split: one workgroup per (tile, MLP)
-    if (g > resident) g = resident;
-    const int q8 = split ? 16 : 8;                      // 8 XCDs (x 2 MLPs)
-    int grid = (int)((g + q8 - 1) / q8 * q8);
-    if (grid < q8) grid = q8;
-    switch (H) {
-      case 64: return launch_wave_t<64>(s, mode, a, grid);
-      case 128: return launch_wave_t<128>(s, mode, a, grid);
-      case 192: return launch_wave_t<192>(s, mode, a, grid);
-      case 256: return launch_wave_t<256>(s, mode, a, grid);
-    }
-    return hipErrorInvalidValue;
-  }
-  if (e->edge_pipe) {   // 64-edge tiles, one 512-thread workgroup per CU
-    int64_t tiles = (edge_bound + 63) / 64;
-    int64_t g = tiles < e->n_cu ? tiles : e->n_cu;
-    int grid = (int)((g + 7) / 8 * 8);
-    if (grid < 8) grid = 8;
-    switch (H) {
-      case 64: return launch_pipe_t<64>(s, mode, a, grid);
-      case 128: return launch_pipe_t<128>(s, mode, a, grid);
-      case 192: return launch_pipe_t<192>(s, mode, a, grid);
-      case 256: return launch_pipe_t<256>(s, mode, a, grid);
-    }
-    return hipErrorInvalidValue;
-  }
-  const int bm = e->edge_bm;
-  int64_t tiles = (edge_bound + bm - 1) / bm;
-  int64_t resident = (int64_t)e->n_cu * (bm == 64 ? 2 : 1);
-  int64_t g = tiles < resident ? tiles : resident;
-  int grid = (int)((g + 7) / 8 * 8);
-  if (grid < 8) grid = 8;
-#define DSBDD_EDGE_CASE(HH)                                                        \
-  case HH:                                                                         \
-    return bm == 64 ? launch_edge_t<HH, 64, 16>(s, mode, a, grid)                  \
-                    : launch_edge_t<HH, 128, 32>(s, mode, a, grid);
+  // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU, persistent over tiles
+  int64_t tiles = (edge_bound + 127) / 128;
+  int64_t resident = 2LL * e->n_cu;
+  if (e->edge_max_wg > 0 && e->edge_max_wg < resident) resident = e->edge_max_wg;
+  const bool split = mode == MODE_COORD && a.pass_split && a.n_mlp == 2;
+  int64_t g = split ? 2 * tiles : tiles;             // split: one workgroup per (tile, MLP)
+  if (g > resident) g = resident;
+  const int q8 = split ? 16 : 8;                      // 8 XCDs (x 2 MLPs)
+  int grid = (int)((g + q8 - 1) / q8 * q8);
+  if (grid < q8) grid = q8;
   switch (H) {
-    DSBDD_EDGE_CASE(64)
-    DSBDD_EDGE_CASE(128)
-    DSBDD_EDGE_CASE(192)
-    DSBDD_EDGE_CASE(256)
+    case 64: return launch_wave_t<64>(s, mode, a, grid);
+    case 128: return launch_wave_t<128>(s, mode, a, grid);
+    case 192: return launch_wave_t<192>(s, mode, a, grid);
+    case 256: return launch_wave_t<256>(s, mode, a, grid);
   }
-#undef DSBDD_EDGE_CASE
   return hipErrorInvalidValue;
 }
 
@@ -539,7 +454,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   const int* e_upd = e->row_ptr + n_upd;                 // edges are row-sorted: a prefix
 
   // lane-grouped copies of the three W2^T matrices of every block (see EdgeMlpW::W2TP)
-  const bool bperm = e->edge_bperm && e->edge_wave && !e->edge_w16 && (H == 256 || H == 128);
+  const bool bperm = e->edge_bperm && (H == 256 || H == 128);
   auto w2tp_of = [&](int blk, int which) -> const float* {   // which: 0 .. inv_sublayers-1 GCL, then coord, cross
     return bperm ? e->w2tp + ((size_t)blk * (c.inv_sublayers + 2) + which) * H * H : nullptr;
   };
@@ -574,7 +489,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       pqg_ready = false;
       HIP_TRY(zero_async(e->agg, (size_t)N * H * 4, s));
       EdgeArgs ea{};
-      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.x = e->x;
+      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.e_cap = (int)e->cap_edges; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
@@ -617,7 +532,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         for (int i = 0; i < nc; ++i) HIP_TRY(launch_node_linear(s, grp[i]));
       }
       EdgeArgs ea{};
-      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.x = e->x;
+      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.e_cap = (int)e->cap_edges; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
                            Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers)};

@@ -148,8 +148,6 @@ class EGNNDynamics(nn.Module):
                         norm_constant=norm_constant, normalization_factor=normalization_factor,
                         coords_range=15.0)   # egnn_new.py:190,218: the un-divided range reaches the layer
         self._engine = None
-        self._cap_key = None
-        self._cap_val = 0
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_engine())
         self.to(device)
 
@@ -174,14 +172,6 @@ class EGNNDynamics(nn.Module):
             self._engine = HipEngine(make_config(**self._hp), self.state_dict(), p.device)
         return self._engine
 
-    def _edge_cap(self, mask_atoms, mask_residues, batch):
-        key = (mask_atoms.data_ptr(), mask_residues.data_ptr(), mask_atoms.numel(),
-               mask_residues.numel(), batch)
-        if key != self._cap_key:
-            self._cap_val = edge_capacity(mask_atoms, mask_residues, batch)
-            self._cap_key = key
-        return self._cap_val
-
     # ---- the reference API -------------------------------------------------
     @torch.no_grad()
     def forward(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues):
@@ -197,11 +187,15 @@ class EGNNDynamics(nn.Module):
 
     @torch.no_grad()
     def forward_async(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues, edges=None,
-                      status=None, want_pocket=True, eps_lig=None, batch=None, eps_pocket=None):
+                      status=None, want_pocket=True, eps_lig=None, batch=None, eps_pocket=None,
+                      edge_cap=None):
         """Same as forward() but without the host sync: returns
         (eps_atoms, eps_residues, status) where `status` is an int32 device
         word (bit 0: NaN, bit 1: edge overflow).  `edges` ([2,E]) teacher-forces
-        the edge list (parity tests)."""
+        the edge list (parity tests).  `edge_cap` = upper bound on the number of
+        edges (engine.edge_capacity of these masks): a sampling chain computes it
+        once and passes it; without it the bound is recomputed from the mask
+        contents on every call (one host sync) -- never cached by pointer."""
         eng = self.engine()
         dev = eng.device
         xh_atoms = xh_atoms.to(device=dev, dtype=torch.float32).contiguous()
@@ -215,7 +209,12 @@ class EGNNDynamics(nn.Module):
             else:   # dynamics.py:105-107: a single t for the whole batch
                 batch = int(max(int(mask_atoms.max()) if mask_atoms.numel() else 0,
                                 int(mask_residues.max()) if mask_residues.numel() else 0)) + 1
-        cap = self._edge_cap(mask_atoms, mask_residues, batch) if edges is None else 0
+        if edges is not None:
+            cap = 0
+        elif edge_cap is not None:
+            cap = int(edge_cap)
+        else:
+            cap = edge_capacity(mask_atoms, mask_residues, batch)
         return eng.forward_async(xh_atoms, xh_residues, t, mask_atoms, mask_residues, batch, cap,
                                  ext_edges=edges, status=status, want_pocket=want_pocket,
                                  eps_lig=eps_lig, eps_pocket=eps_pocket)

@@ -217,10 +217,11 @@ class EnVariationalDiffusion(nn.Module):
         # noise: None -> sharding-invariant keyed Philox on the GPU; a callable
         # (shape) -> tensor injects external noise (parity tests)
         self.noise_source = None
-        self._seed = 0
+        self._seed = None           # None: taken from torch's global RNG at the first draw
         self._sample_offset = 0
         self._draw = 0
         self._coef_cache = {}
+        self._chain = None          # (edge bound, device flag "masks sorted") of the running chain
 
     # ---- noise -----------------------------------------------------------------
     def set_noise_source(self, fn):
@@ -228,7 +229,10 @@ class EnVariationalDiffusion(nn.Module):
 
     def seed(self, seed, sample_offset=0):
         """Seed the keyed generator.  `sample_offset` = global index of this
-        shard's first sample, so a chain's noise is independent of sharding."""
+        shard's first sample, so a chain's noise is independent of sharding.
+        Without a call to seed() the key is drawn from torch's global generator at
+        the first use, so `torch.manual_seed` controls the samples and unseeded
+        processes differ (the reference draws from the global generator too)."""
         self._seed, self._sample_offset, self._draw = int(seed), int(sample_offset), 0
 
     def _randn(self, mask, n_cols, batch, stream_id=0):
@@ -236,6 +240,8 @@ class EnVariationalDiffusion(nn.Module):
         if self.noise_source is not None:
             return self.noise_source((n, n_cols)).to(device=mask.device, dtype=torch.float32).contiguous()
         out = torch.empty((n, n_cols), dtype=torch.float32, device=mask.device)
+        if self._seed is None:
+            self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         lib = _lib.load()
         _lib.check(lib.dsbdd_randn_keyed(
             torch.cuda.current_stream(mask.device).cuda_stream, out.data_ptr(), mask.data_ptr(), n,
@@ -332,11 +338,32 @@ class EnVariationalDiffusion(nn.Module):
 
     # ---- dynamics call ---------------------------------------------------------------
     def _check_status(self, status):
+        if self._chain is not None and not bool(self._chain[1].item()):
+            raise ValueError("batch masks must be sorted ascending with ids in [0, batch): the HIP "
+                             "kernels locate a sample's rows by binary search")
         st = int(status.item())
         if st & _lib.STATUS_EDGE_OVERFLOW:
             raise RuntimeError("edge capacity overflow in the EGNN kernels")
         if st & _lib.STATUS_NAN:
             raise ValueError("NaN detected in EGNN output")
+
+    def _begin_chain(self, lig_mask, pocket_mask, batch):
+        """Start of a sampling call: int64 contiguous masks on the device, the edge bound of
+        this batch (one host sync per chain, from the mask CONTENTS) and a device flag
+        'masks are sorted' (the kernels find a sample's rows by binary search) that is
+        read together with the status word at the end of the chain."""
+        from .engine import edge_capacity
+        dev = self._hip_device(None)
+        lm = lig_mask.to(device=dev, dtype=torch.int64).contiguous()
+        pm = pocket_mask.to(device=dev, dtype=torch.int64).contiguous()
+        ok = torch.ones((), dtype=torch.bool, device=dev)
+        for m in (lm, pm):
+            if m.numel() > 1:
+                ok = ok & (m[1:] >= m[:-1]).all()
+            if m.numel():
+                ok = ok & (m[0] >= 0) & (m[-1] < batch)
+        self._chain = (edge_capacity(lm, pm, batch), ok)
+        return lm, pm
 
     def _dyn(self, z_lig, z_pocket, t_value, lig_mask, pocket_mask, batch, status, want_pocket):
         """One denoiser call.  t and the eps outputs live in persistent buffers keyed by the
@@ -354,7 +381,8 @@ class EnVariationalDiffusion(nn.Module):
         t.fill_(float(t_value))
         return self.dynamics.forward_async(z_lig, z_pocket, t, lig_mask, pocket_mask, status=status,
                                            want_pocket=want_pocket, batch=batch, eps_lig=eps_l,
-                                           eps_pocket=eps_p)
+                                           eps_pocket=eps_p,
+                                           edge_cap=self._chain[0] if self._chain is not None else None)
 
     # ---- joint noise (en_diffusion.py:559-578) ------------------------------------------
     def sample_combined_position_feature_noise(self, lig_indices, pocket_indices):
@@ -396,6 +424,7 @@ class EnVariationalDiffusion(nn.Module):
         batch = s.shape[0]
         timesteps, s_int = self._infer_step(s, t)
         co = self._coefs(timesteps)
+        ligand_mask, pocket_mask = self._begin_chain(ligand_mask, pocket_mask, batch)
         z_l, z_p = zt_lig.clone().contiguous(), zt_pocket.clone().contiguous()
         status = torch.zeros(1, dtype=torch.int32, device=z_l.device)
         self._step_impl(s_int, co, z_l, z_p, ligand_mask, pocket_mask, batch, status)
@@ -445,9 +474,12 @@ class EnVariationalDiffusion(nn.Module):
         alpha_t = self.alpha(gamma_t, target_tensor=net_out)
         return 1. / alpha_t[batch_mask] * (zt - sigma_t[batch_mask] * net_out)
 
-    def sample_p_xh_given_z0(self, z0_lig, z0_pocket, lig_mask, pocket_mask, batch_size, fix_noise=False):
+    def sample_p_xh_given_z0(self, z0_lig, z0_pocket, lig_mask, pocket_mask, batch_size, fix_noise=False,
+                             _in_chain=False):
         if fix_noise:
             raise NotImplementedError("fix_noise option isn't implemented yet")
+        if not _in_chain:
+            lig_mask, pocket_mask = self._begin_chain(lig_mask, pocket_mask, batch_size)
         dev = z0_lig.device
         t0 = torch.zeros((batch_size, 1), device=dev)
         gamma_0 = self.gamma(t0)
@@ -469,7 +501,7 @@ class EnVariationalDiffusion(nn.Module):
         return x_l, h_l, x_p, h_p
 
     def _finish_joint(self, z_l, z_p, lig_mask, pocket_mask, n, return_frames, out_lig, out_pocket):
-        x_l, h_l, x_p, h_p = self.sample_p_xh_given_z0(z_l, z_p, lig_mask, pocket_mask, n)
+        x_l, h_l, x_p, h_p = self.sample_p_xh_given_z0(z_l, z_p, lig_mask, pocket_mask, n, _in_chain=True)
         comb = torch.cat((lig_mask, pocket_mask))
         self.assert_mean_zero_with_mask(torch.cat((x_l, x_p), dim=0), comb)
         if return_frames == 1:                                         # en_diffusion.py:636-644
@@ -493,6 +525,7 @@ class EnVariationalDiffusion(nn.Module):
         device = self._hip_device(device)
         lig_mask = num_nodes_to_batch_mask(n_samples, num_nodes_lig, device).contiguous()
         pocket_mask = num_nodes_to_batch_mask(n_samples, num_nodes_pocket, device).contiguous()
+        lig_mask, pocket_mask = self._begin_chain(lig_mask, pocket_mask, n_samples)
         co = self._coefs(timesteps)
         z_l, z_p = self._joint_noise(lig_mask, pocket_mask, n_samples)
         z_l, z_p = z_l.contiguous(), z_p.contiguous()
@@ -549,8 +582,7 @@ class EnVariationalDiffusion(nn.Module):
         dev = self._hip_device(None)
         n = len(ligand['size'])
         nd = self.n_dims
-        lm = ligand['mask'].to(dev).contiguous()
-        pm = pocket['mask'].to(dev).contiguous()
+        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
         lig_fixed, pocket_fixed = lig_fixed.to(dev).float(), pocket_fixed.to(dev).float()
         # row ids of the fixed nodes, found once: boolean-mask indexing inside the loop would cost a
         # host sync (nonzero) four times per step

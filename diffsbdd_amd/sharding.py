@@ -66,16 +66,19 @@ def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int
     out_dev = out_lig.device
     dev = out_dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
     out_lig, lig_mask = out_lig.to(dev), lig_mask.to(dev)
-    n_rows = torch.tensor([out_lig.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n_rows, group=group)
-    counts = [int(c.item()) for c in counts]
+    # row count and feature width of every rank (a rank with an empty shard does not know D)
+    shape = torch.tensor([out_lig.shape[0], out_lig.shape[1] if out_lig.dim() == 2 else 0],
+                         dtype=torch.int64, device=dev)
+    shapes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(shapes, shape, group=group)
+    counts = [int(c[0].item()) for c in shapes]
+    D = max(int(c[1].item()) for c in shapes)
     max_rows = max(max(counts), 1)
-    D = out_lig.shape[1]
     # one padded payload: [max_rows, D + 1] with the global sample id as last column
     payload = torch.zeros((max_rows, D + 1), dtype=torch.float64, device=dev)
-    payload[:out_lig.shape[0], :D] = out_lig.to(torch.float64)
-    payload[:out_lig.shape[0], D] = (lig_mask + sample_lo).to(torch.float64)
+    if out_lig.shape[0]:
+        payload[:out_lig.shape[0], :D] = out_lig.to(torch.float64)
+        payload[:out_lig.shape[0], D] = (lig_mask + sample_lo).to(torch.float64)
     bufs = [torch.zeros_like(payload) for _ in range(world)]
     dist.all_gather(bufs, payload, group=group)
     rows = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(out_dev)
@@ -93,12 +96,9 @@ def sample_sharded(sample_fn, n_total: int, group=None):
         out_lig, mask = sample_fn(lo, hi)
     else:
         out_lig, mask = None, None
-    if out_lig is None:   # empty shard: still has to take part in the gather
+    if out_lig is None:   # empty shard: still has to take part in the gather (width comes from the peers)
         probe_dev = torch.device("cuda", torch.cuda.current_device()) if (
             dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
-        out_lig = torch.zeros((0, sample_sharded.feature_dim), device=probe_dev)
+        out_lig = torch.zeros((0, 0), device=probe_dev)
         mask = torch.zeros((0,), dtype=torch.int64, device=probe_dev)
     return gather_ligands(out_lig, mask, lo, group)
-
-
-sample_sharded.feature_dim = 13  # 3 + atom_nf of the shipped configs; set before use otherwise

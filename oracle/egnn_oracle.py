@@ -90,9 +90,44 @@ def pair_dist(a, b, exact=True):
     return torch.sqrt((d * d).sum(-1))
 
 
+def get_edges_blockwise(mask_l, mask_p, x_l, x_p, cut_l, cut_p, cut_i):
+    """dynamics.py:169-187 evaluated sample by sample with exact distances.
+
+    The reference builds one dense [N, N] adjacency whose same-sample test
+    (dynamics.py:170-172) makes it block diagonal; here only the diagonal blocks
+    are formed (O(sum n_b^2) memory instead of O(N^2): 1.5 GB -> 25 MB at the
+    benchmark batch).  Same edge set and the same (row, col) order as
+    get_edges(..., exact=True); node numbering = [ligand nodes | pocket nodes]."""
+    nl = len(mask_l)
+    B = int(max(mask_l.max() if len(mask_l) else 0, mask_p.max() if len(mask_p) else 0)) + 1
+    rows, cols = [], []
+    for b in range(B):
+        il = torch.nonzero(mask_l == b).view(-1)
+        ip = torch.nonzero(mask_p == b).view(-1)
+        xl, xp = x_l[il], x_p[ip]
+        a_l = torch.ones(len(il), len(il), dtype=torch.bool)
+        a_p = torch.ones(len(ip), len(ip), dtype=torch.bool)
+        a_c = torch.ones(len(il), len(ip), dtype=torch.bool)
+        if cut_l is not None:
+            a_l &= pair_dist(xl, xl) <= cut_l
+        if cut_p is not None:
+            a_p &= pair_dist(xp, xp) <= cut_p
+        if cut_i is not None:
+            a_c &= pair_dist(xl, xp) <= cut_i
+        adj = torch.cat((torch.cat((a_l, a_c), 1), torch.cat((a_c.T, a_p), 1)), 0)
+        ids = torch.cat((il, ip + nl))
+        r, c = torch.where(adj)
+        rows.append(ids[r]); cols.append(ids[c])
+    row, col = torch.cat(rows), torch.cat(cols)
+    order = torch.argsort(row * (nl + len(mask_p)) + col)
+    return torch.stack((row[order], col[order]), 0)
+
+
 def get_edges(mask_l, mask_p, x_l, x_p, cut_l, cut_p, cut_i, exact=True):
     """dynamics.py:169-187.  Returns int64 [2,E], sorted by (row, col), self
     loops kept; node numbering = [ligand nodes | pocket nodes]."""
+    if exact and len(mask_l) + len(mask_p) > 4096:
+        return get_edges_blockwise(mask_l, mask_p, x_l, x_p, cut_l, cut_p, cut_i)
     adj_l = mask_l[:, None] == mask_l[None, :]
     adj_p = mask_p[:, None] == mask_p[None, :]
     adj_c = mask_l[:, None] == mask_p[None, :]

@@ -12,13 +12,13 @@ import torch.multiprocessing as mp
 from diffsbdd_amd import sharding
 
 
-def fake_sampler(n_lig_of):
+def fake_sampler(n_lig_of, width=13):
     def fn(lo, hi):
         rows, mask = [], []
         for g in range(lo, hi):
             n = n_lig_of(g)
             gen = torch.Generator().manual_seed(1000 + g)          # keyed by GLOBAL index
-            rows.append(torch.randn(n, 13, generator=gen))
+            rows.append(torch.randn(n, width, generator=gen))
             mask.append(torch.full((n,), g - lo, dtype=torch.int64))  # LOCAL sample ids
         return torch.cat(rows), torch.cat(mask)
     return fn
@@ -32,22 +32,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, q, width=13):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, lr, w = sharding.init_distributed("gloo")
     assert (r, w) == (rank, world)
-    out, mask = sharding.sample_sharded(fake_sampler(lambda g: 5 + g % 4), n_total)
+    out, mask = sharding.sample_sharded(fake_sampler(lambda g: 5 + g % 4, width), n_total)
     q.put((rank, out.clone(), mask.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_world(world, n_total):
+def _run_world(world, n_total, width=13):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, width)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -81,3 +81,39 @@ def test_world2_with_empty_shard():
     ref_out, ref_mask = sharding.gather_ligands(*fake_sampler(lambda g: 5 + g % 4)(0, 1), 0)
     for rank, out, mask in res:
         assert torch.equal(out, ref_out) and torch.equal(mask, ref_mask)
+
+
+def test_world2_empty_shard_other_feature_width():
+    """The empty rank learns the feature width from its peers (3 + atom_nf is not 13 for every model)."""
+    res = _run_world(2, 1, width=7)
+    ref_out, ref_mask = sharding.gather_ligands(*fake_sampler(lambda g: 5 + g % 4, 7)(0, 1), 0)
+    for rank, out, mask in res:
+        assert out.shape[1] == 7
+        assert torch.equal(out, ref_out) and torch.equal(mask, ref_mask)
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without torchrun: bench.py re-executes itself under
+    torch.distributed.run with N ranks, rendezvous on 127.0.0.1 (command checked here; the
+    launch itself runs in the GPU suite)."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "1"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "1"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
