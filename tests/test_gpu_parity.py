@@ -597,7 +597,7 @@ def test_unsorted_masks_raise_and_manual_seed_controls_noise():
     model._seed, model._draw = None, 0
     torch.manual_seed(12)
     d = run()
-    assert torch.equal(a, b) and not torch.equal(a[:, :3], d[:, :3])
+    assert (a - b).abs().max().item() < 1e-4 and (a[:, :3] - d[:, :3]).abs().max().item() > 1e-2
     bad = c.pocket()
     bad["mask"] = bad["mask"].flip(0)
     with pytest.raises(ValueError, match="sorted"):
