@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSBDD_LIB: load another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("DSBDD_LIB") or os.path.join(_HERE, "libdiffsbdd_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # error / status codes (include/diffsbdd_hip.h)
 OK, ERR_ARG, ERR_STATE, ERR_CAPACITY, ERR_LAUNCH = 0, -1, -2, -3, -4
@@ -28,7 +28,7 @@ GCL_NAMES = ["E1_WT", "E1_WD", "E1_WD0", "E1_TAB", "E2_WT", "E2_B", "ATT_W", "AT
              "N1_WT", "N1_B", "N2_WT", "N2_B"]
 EQ_NAMES = ["C1_WT", "C_WD", "C_WD0", "C_TAB", "C_W2T", "C_B2",
             "X_WD", "X_WD0", "X_TAB", "X_W2T", "X_B2", "W3"]
-BUF_EDGE_ROW, BUF_EDGE_COL, BUF_EDGE_D0, BUF_ROW_PTR, BUF_H, BUF_X, BUF_NODE_BATCH = range(7)
+BUF_EDGE_ROW, BUF_EDGE_COL, BUF_EDGE_D0, BUF_ROW_PTR, BUF_H, BUF_X, BUF_NODE_BATCH, BUF_DEG = range(8)
 
 
 class Config(C.Structure):
@@ -67,7 +67,14 @@ SIGNATURES = {
     "dsbdd_cond_reverse_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
                                             _I32, _I32, _F, _F, _F, _I32]),
     "dsbdd_joint_reverse_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
-                                             _I32, _I32, _F, _F, _F]),
+                                             _I32, _I32, _F, _F, _F, _I32]),
+    "dsbdd_segment_mean3": (C.c_int, [_P, _P, _I32, _P, _I64, _I64, _P]),
+    "dsbdd_cond_affine_noise": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _F, _F, _I32]),
+    "dsbdd_joint_affine_noise": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _F, _F,
+                                           _I32, _I32]),
+    "dsbdd_cond_repaint_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
+                                            _I32, _I32, _F, _F, _F, _F, _I32, _I32]),
+    "dsbdd_joint_repaint_update": (C.c_int, [_P] * 15 + [_I64, _I64, _I64, _I32, _I32, _F, _F, _F, _F, _I32]),
     "dsbdd_randn_keyed": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, C.c_uint64, C.c_uint64,
                                     C.c_uint32]),
     "dsbdd_node_linear": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _P, _P, _I32,

@@ -58,6 +58,17 @@ class ConditionalDDPM(EnVariationalDiffusion):
         return (torch.cat([xl, out[:, nd:]], dim=1).contiguous(),
                 torch.cat([xp, xh0_pocket[:, nd:]], dim=1).contiguous())
 
+    def _cond_gauss_(self, z_lig, xh_pocket, lig_mask, pocket_mask, batch, a, sigma, noise=None):
+        """In place (csrc/ddpm.h cond_affine_noise_kernel): z_lig <- a z_lig + sigma eps, then the ligand
+        COM is removed from ligand and pocket.  The sampling loops use this instead of the tensor
+        formulas below: one launch, fixed summation order."""
+        if noise is None:
+            noise = self._randn(lig_mask, self.n_dims + self.atom_nf, batch)
+        _lib.check(_lib.load().dsbdd_cond_affine_noise(
+            self._cs(z_lig), z_lig.data_ptr(), xh_pocket.data_ptr(), noise.data_ptr(), lig_mask.data_ptr(),
+            pocket_mask.data_ptr(), lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf, self.residue_nf,
+            float(a), float(sigma), self._remove_com), "dsbdd_cond_affine_noise")
+
     def noised_representation(self, xh_lig, xh0_pocket, lig_mask, pocket_mask, gamma_t):
         batch = gamma_t.shape[0]
         nd = self.n_dims
@@ -111,9 +122,12 @@ class ConditionalDDPM(EnVariationalDiffusion):
         net, _, _ = self._dyn(z0_lig.contiguous(), xh0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
                               batch_size, status, False)
         self._check_status(status)
-        mu = self.compute_x_pred(net, z0_lig, gamma_0, lig_mask)
-        xh_lig, xh_pocket = self.sample_normal_zero_com(mu, xh0_pocket, sigma_x, lig_mask, pocket_mask,
-                                                        fix_noise)
+        if fix_noise:
+            raise NotImplementedError("fix_noise option isn't implemented yet")
+        xh_lig = self.compute_x_pred(net, z0_lig, gamma_0, lig_mask).contiguous()
+        xh_pocket = xh0_pocket.clone().contiguous()
+        # sample_normal_zero_com(mu, ., sigma_x) in one kernel; one t (one sigma_x) for the whole batch
+        self._cond_gauss_(xh_lig, xh_pocket, lig_mask, pocket_mask, batch_size, 1.0, float(sigma_x.reshape(-1)[0]))
         x_lig, h_lig = self.unnormalize(xh_lig[:, :nd], z0_lig[:, nd:])
         x_pocket, h_pocket = self.unnormalize(xh_pocket[:, :nd], xh_pocket[:, nd:])
         h_lig = F.one_hot(torch.argmax(h_lig, dim=1), self.atom_nf)
@@ -142,10 +156,10 @@ class ConditionalDDPM(EnVariationalDiffusion):
         lig_mask, pm = self._begin_chain(lig_mask, pm, n)
 
         # z_T ~ N(pocket COM, I), then ligand-COM-free (conditional_model.py:501-508)
-        mu_x = seg_mean(pocket['x'], pm, n)
-        mu = torch.cat((mu_x, torch.zeros((n, self.atom_nf), device=dev)), dim=1)[lig_mask]
-        sigma = torch.ones((n, 1), device=dev)
-        z_lig, xh_pocket = self.sample_normal_zero_com(mu, xh0_pocket, sigma, lig_mask, pm)
+        mu_x = self._seg_mean3(pocket['x'], pm, n)
+        z_lig = torch.cat((mu_x, torch.zeros((n, self.atom_nf), device=dev)), dim=1)[lig_mask].contiguous()
+        xh_pocket = xh0_pocket.clone().contiguous()
+        self._cond_gauss_(z_lig, xh_pocket, lig_mask, pm, n, 1.0, 1.0)
 
         out_lig = torch.zeros((return_frames,) + z_lig.size(), device=dev)
         out_pocket = torch.zeros((return_frames,) + xh_pocket.size(), device=dev)
@@ -185,50 +199,48 @@ class ConditionalDDPM(EnVariationalDiffusion):
         dev = self._hip_device(None)
         pocket = self._prepare_pocket(pocket, dev)
         ligand = self._prepare_pocket(ligand, dev)
-        lig_fixed = lig_fixed.to(dev).float()
-        fixed = torch.nonzero(lig_fixed.view(-1) != 0).view(-1)   # row ids once: no per-step nonzero sync
+        fixed_f = lig_fixed.to(dev).float().reshape(-1).contiguous()
         n = len(ligand['size'])
-        nd = self.n_dims
         ligand, pocket = self.normalize(ligand, pocket)
         lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
 
         xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
-        com_pocket_0 = seg_mean(pocket['x'], pm, n)
-        xh_ligand = torch.cat([ligand['x'], ligand['one_hot']], dim=1).clone()
-        lm_fixed = lm[fixed]
-        if center == 'ligand':
-            mean_known = seg_mean(ligand['x'][fixed], lm_fixed, n)
+        com_pocket_0 = self._seg_mean3(pocket['x'], pm, n)
+        xh0_lig = torch.cat([ligand['x'], ligand['one_hot']], dim=1).contiguous()
+        if center == 'ligand':      # COM of the fixed atoms (row ids found once: one host sync per chain)
+            sel = fixed_f != 0
+            mean_known = self._seg_mean3(ligand['x'][sel], lm[sel].contiguous(), n)
         elif center == 'pocket':
-            mean_known = seg_mean(pocket['x'], pm, n)
+            mean_known = com_pocket_0
         else:
             raise NotImplementedError(f"Centering option {center} not implemented")
-        mu = torch.cat((mean_known, torch.zeros((n, self.atom_nf), device=dev)), dim=1)[lm]
-        z_lig, xh_pocket = self.sample_normal_zero_com(mu, xh0_pocket, torch.ones((n, 1), device=dev), lm, pm)
+        z_lig = torch.cat((mean_known, torch.zeros((n, self.atom_nf), device=dev)), dim=1)[lm].contiguous()
+        xh_pocket = xh0_pocket.clone().contiguous()
+        self._cond_gauss_(z_lig, xh_pocket, lm, pm, n, 1.0, 1.0)
+        zk_tmp = torch.empty_like(z_lig)                                   # kernel scratch
 
         out_lig = torch.zeros((return_frames,) + z_lig.size(), device=dev)
         out_pocket = torch.zeros((return_frames,) + xh_pocket.size(), device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         co = self._coefs(timesteps)
+        lib = _lib.load()
+        dl = self.n_dims + self.atom_nf
         for s in reversed(range(0, timesteps)):
-            g_s = co.gamma[s].view(1, 1).expand(n, 1).to(dev)
-            g_t = co.gamma[s + 1].view(1, 1).expand(n, 1).to(dev)
             for u in range(resamplings):
-                # unknown part: one reverse step (updates the pocket translation too)
-                z_unknown = z_lig.clone()
-                self._cond_step(s, co, z_unknown, xh_pocket, lm, pm, n, status)
-                # known part: move the input ligand with the pocket, noise it to level s
-                com_pocket = seg_mean(xh_pocket[:, :nd], pm, n)
-                xh_ligand[:, :nd] = ligand['x'] + (com_pocket - com_pocket_0)[lm]
-                z_known, xh_pocket, _ = self.noised_representation(xh_ligand, xh_pocket, lm, pm, g_s)
-                # align the COM of the fixed atoms of both parts, then blend
-                com_noised = seg_mean(z_known[fixed][:, :nd], lm_fixed, n)
-                com_denoised = seg_mean(z_unknown[fixed][:, :nd], lm_fixed, n)
-                dx = com_denoised - com_noised
-                z_known[:, :nd] = z_known[:, :nd] + dx[lm]
-                xh_pocket[:, :nd] = xh_pocket[:, :nd] + dx[pm]
-                z_lig = (z_known * lig_fixed + z_unknown * (1 - lig_fixed)).contiguous()
-                if u < resamplings - 1:
-                    z_lig, xh_pocket = self.sample_p_zt_given_zs(z_lig, xh_pocket, lm, pm, g_t, g_s)
+                # z_lig / xh_pocket are updated in place (stable pointers: the engine replays its graph).
+                # unknown part: one reverse step (moves the pocket with the ligand COM) ...
+                self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
+                # ... then known part noised to level s around the moved pocket, COM alignment of the
+                # fixed atoms, blend, and (between resamplings) q(z_t | z_s): one kernel
+                resample = u < resamplings - 1
+                n1 = self._randn(lm, dl, n)
+                n2 = self._randn(lm, dl, n) if resample else None
+                _lib.check(lib.dsbdd_cond_repaint_update(
+                    self._cs(z_lig), z_lig.data_ptr(), xh_pocket.data_ptr(), zk_tmp.data_ptr(), xh0_lig.data_ptr(),
+                    com_pocket_0.data_ptr(), fixed_f.data_ptr(), n1.data_ptr(), n2.data_ptr() if resample else None,
+                    lm.data_ptr(), pm.data_ptr(), lm.numel(), pm.numel(), n, self.atom_nf, self.residue_nf,
+                    float(co.alpha[s]), float(co.sigma_t[s]), float(co.alpha_ts[s]), float(co.sigma_ts[s]),
+                    int(resample), self._remove_com), "dsbdd_cond_repaint_update")
                 if u == resamplings - 1 and (s * return_frames) % timesteps == 0:
                     idx = (s * return_frames) // timesteps
                     out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_lig, xh_pocket)
@@ -261,7 +273,14 @@ class ConditionalDDPM(EnVariationalDiffusion):
         n = len(pocket['size'])
         lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
         ligand['mask'], pocket['mask'] = lm, pm
-        z_lig, xh_pocket, _ = self.partially_noised_ligand(ligand, pocket, noising_steps)
+        # partially_noised_ligand (conditional_model.py:332-362) with the fused kernels: centre at the
+        # ligand COM (a = 1, sigma = 0), then q(z_t | x) at t = noising_steps / T
+        z_lig = torch.cat([ligand['x'], ligand['one_hot']], dim=1).contiguous()
+        xh_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1).contiguous()
+        self._cond_gauss_(z_lig, xh_pocket, lm, pm, n, 1.0, 0.0, noise=z_lig)
+        g_t = self.gamma.gamma[int(noising_steps)].detach().cpu()     # gamma(noising_steps / T)
+        self._cond_gauss_(z_lig, xh_pocket, lm, pm, n, float(torch.sqrt(torch.sigmoid(-g_t))),
+                          float(torch.sqrt(torch.sigmoid(g_t))))
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         co = self._coefs(self.T)
         for s in reversed(range(0, noising_steps)):

@@ -57,32 +57,330 @@ __global__ __launch_bounds__(kThreads) void cond_update_kernel(
 __global__ __launch_bounds__(kThreads) void joint_update_kernel(
     float* z_lig, float* z_poc, const float* eps_l, const float* eps_p, const float* noise_l,
     const float* noise_p, const int64_t* mask_lig, int n_lig, const int64_t* mask_poc, int n_poc,
-    int dl, int dp, float alpha_ts, float c_eps, float sigma) {
+    int dl, int dp, float alpha_ts, float c_eps, float sigma, int center_noise) {
   __shared__ float red[kThreads];
   const int b = blockIdx.x, t = threadIdx.x;
   const int l0 = lower_bound_i64(mask_lig, n_lig, b), l1 = lower_bound_i64(mask_lig, n_lig, b + 1);
   const int p0 = lower_bound_i64(mask_poc, n_poc, b), p1 = lower_bound_i64(mask_poc, n_poc, b + 1);
   const int nl = l1 - l0, np = p1 - p0;
+  const float cnt = (nl + np) > 0 ? (float)(nl + np) : 1.f;
+  float mn[3] = {0.f, 0.f, 0.f};
+  if (center_noise) {   // x part of the noise COM-free over ligand + pocket (en_diffusion.py:932-942)
+    float sl[3] = {0.f, 0.f, 0.f};
+    for (int i = l0 + t; i < l1; i += kThreads)
+      for (int c = 0; c < 3; ++c) sl[c] += noise_l[(size_t)i * dl + c];
+    for (int i = p0 + t; i < p1; i += kThreads)
+      for (int c = 0; c < 3; ++c) sl[c] += noise_p[(size_t)i * dp + c];
+    for (int c = 0; c < 3; ++c) mn[c] = block_sum(sl[c], red) / cnt;
+  }
   float s[3] = {0.f, 0.f, 0.f};
   for (int idx = t; idx < nl * dl; idx += kThreads) {
     const int c = idx % dl;
     const size_t o = (size_t)(l0 + idx / dl) * dl + c;
-    const float v = (z_lig[o] / alpha_ts - c_eps * eps_l[o]) + sigma * noise_l[o];
+    const float nz = c < 3 ? noise_l[o] - mn[c] : noise_l[o];
+    const float v = (z_lig[o] / alpha_ts - c_eps * eps_l[o]) + sigma * nz;
     z_lig[o] = v;
     if (c < 3) s[c] += v;
   }
   for (int idx = t; idx < np * dp; idx += kThreads) {
     const int c = idx % dp;
     const size_t o = (size_t)(p0 + idx / dp) * dp + c;
-    const float v = (z_poc[o] / alpha_ts - c_eps * eps_p[o]) + sigma * noise_p[o];
+    const float nz = c < 3 ? noise_p[o] - mn[c] : noise_p[o];
+    const float v = (z_poc[o] / alpha_ts - c_eps * eps_p[o]) + sigma * nz;
     z_poc[o] = v;
     if (c < 3) s[c] += v;
   }
-  const float cnt = (nl + np) > 0 ? (float)(nl + np) : 1.f;
   float m[3];
   for (int c = 0; c < 3; ++c) m[c] = block_sum(s[c], red) / cnt;
   for (int idx = t; idx < nl * 3; idx += kThreads) z_lig[(size_t)(l0 + idx / 3) * dl + idx % 3] -= m[idx % 3];
   for (int idx = t; idx < np * 3; idx += kThreads) z_poc[(size_t)(p0 + idx / 3) * dp + idx % 3] -= m[idx % 3];
+}
+
+// ---- building blocks of the sampling loops around the reverse step ------------------------
+// All of them: one workgroup per sample, per-sample reductions by block_sum (a fixed reduction
+// tree over the sample's own rows), so the result for a sample is a pure function of that
+// sample's data -- bitwise reproducible and independent of the batch composition.  They replace
+// chains of ~20-100 small torch kernels (index_add_ with float atomics among them).
+
+struct SampleRows { int l0, l1, p0, p1; };
+__device__ __forceinline__ SampleRows sample_rows(const int64_t* mask_lig, int n_lig, const int64_t* mask_poc,
+                                                  int n_poc, int b) {
+  return SampleRows{lower_bound_i64(mask_lig, n_lig, b), lower_bound_i64(mask_lig, n_lig, b + 1),
+                    lower_bound_i64(mask_poc, n_poc, b), lower_bound_i64(mask_poc, n_poc, b + 1)};
+}
+
+// sum over rows [r0, r1) of columns 0..2 of a [rows][ld] matrix (optionally only rows with sel != 0)
+__device__ __forceinline__ void rows_sum3(const float* a, int ld, int r0, int r1, const float* sel, float* red,
+                                          float (&out)[3], float* count = nullptr) {
+  float s[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
+  for (int i = r0 + (int)threadIdx.x; i < r1; i += kThreads) {
+    if (sel && sel[i] == 0.f) continue;
+    s[0] += a[(size_t)i * ld]; s[1] += a[(size_t)i * ld + 1]; s[2] += a[(size_t)i * ld + 2];
+    cnt += 1.f;
+  }
+  for (int c = 0; c < 3; ++c) out[c] = block_sum(s[c], red);
+  if (count) *count = block_sum(cnt, red);
+}
+
+// out[b][0..2] = mean over the rows of sample b of x[:, 0..2]  (scatter_mean, count clamped to >= 1)
+__global__ __launch_bounds__(kThreads) void segment_mean3_kernel(const float* x, int ld, const int64_t* mask,
+                                                                 int n_rows, float* out) {
+  __shared__ float red[kThreads];
+  const int b = blockIdx.x;
+  const int r0 = lower_bound_i64(mask, n_rows, b), r1 = lower_bound_i64(mask, n_rows, b + 1);
+  float s[3];
+  rows_sum3(x, ld, r0, r1, nullptr, red, s);
+  const float cnt = r1 > r0 ? (float)(r1 - r0) : 1.f;
+  if (threadIdx.x < 3) out[3 * b + threadIdx.x] = s[threadIdx.x] / cnt;
+}
+
+// Conditional model:  z_lig <- a * z_lig + sigma * noise ; then (remove_com) the ligand centre of mass is
+// subtracted from ligand and pocket x.  Covers sample_normal_zero_com (a = 1: z_lig holds mu),
+// noised_representation (a = alpha_t), sample_p_zt_given_zs (a = alpha_t|s)
+// (conditional_model.py:140-183,420-430).
+__global__ __launch_bounds__(kThreads) void cond_affine_noise_kernel(
+    float* z_lig, float* xh_poc, const float* noise, const int64_t* mask_lig, int n_lig,
+    const int64_t* mask_poc, int n_poc, int dl, int dp, float a, float sigma, int remove_com) {
+  __shared__ float red[kThreads];
+  const int t = threadIdx.x;
+  const SampleRows r = sample_rows(mask_lig, n_lig, mask_poc, n_poc, blockIdx.x);
+  const int nl = r.l1 - r.l0;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int idx = t; idx < nl * dl; idx += kThreads) {
+    const int c = idx % dl;
+    const size_t o = (size_t)(r.l0 + idx / dl) * dl + c;
+    const float v = a * z_lig[o] + sigma * noise[o];
+    z_lig[o] = v;
+    if (c < 3) s[c] += v;
+  }
+  if (!remove_com) return;
+  const float cnt = nl > 0 ? (float)nl : 1.f;
+  float m[3];
+  for (int c = 0; c < 3; ++c) m[c] = block_sum(s[c], red) / cnt;
+  for (int idx = t; idx < nl * 3; idx += kThreads) z_lig[(size_t)(r.l0 + idx / 3) * dl + idx % 3] -= m[idx % 3];
+  for (int idx = t; idx < (r.p1 - r.p0) * 3; idx += kThreads)
+    xh_poc[(size_t)(r.p0 + idx / 3) * dp + idx % 3] -= m[idx % 3];
+}
+
+// Joint model:  z <- a * z + sigma * noise for both node sets, where (center_noise) the x part of the
+// noise is first made COM-free over the sample's ligand + pocket rows
+// (sample_center_gravity_zero_gaussian_batch, en_diffusion.py:932-942) and (remove_com) the joint COM of
+// the result is removed (en_diffusion.py:479-501).  a = 0 / sigma = 1 draws z_T.
+__global__ __launch_bounds__(kThreads) void joint_affine_noise_kernel(
+    float* z_lig, float* z_poc, const float* noise_l, const float* noise_p, const int64_t* mask_lig,
+    int n_lig, const int64_t* mask_poc, int n_poc, int dl, int dp, float a, float sigma,
+    int center_noise, int remove_com) {
+  __shared__ float red[kThreads];
+  const int t = threadIdx.x;
+  const SampleRows r = sample_rows(mask_lig, n_lig, mask_poc, n_poc, blockIdx.x);
+  const int nl = r.l1 - r.l0, np = r.p1 - r.p0;
+  const float cnt = (nl + np) > 0 ? (float)(nl + np) : 1.f;
+  float mn[3] = {0.f, 0.f, 0.f};
+  if (center_noise) {
+    float sl[3], sp[3];
+    rows_sum3(noise_l, dl, r.l0, r.l1, nullptr, red, sl);
+    rows_sum3(noise_p, dp, r.p0, r.p1, nullptr, red, sp);
+    for (int c = 0; c < 3; ++c) mn[c] = (sl[c] + sp[c]) / cnt;
+  }
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int idx = t; idx < nl * dl; idx += kThreads) {
+    const int c = idx % dl;
+    const size_t o = (size_t)(r.l0 + idx / dl) * dl + c;
+    const float nz = c < 3 ? noise_l[o] - mn[c] : noise_l[o];
+    const float v = (a == 0.f ? 0.f : a * z_lig[o]) + sigma * nz;
+    z_lig[o] = v;
+    if (c < 3) s[c] += v;
+  }
+  for (int idx = t; idx < np * dp; idx += kThreads) {
+    const int c = idx % dp;
+    const size_t o = (size_t)(r.p0 + idx / dp) * dp + c;
+    const float nz = c < 3 ? noise_p[o] - mn[c] : noise_p[o];
+    const float v = (a == 0.f ? 0.f : a * z_poc[o]) + sigma * nz;
+    z_poc[o] = v;
+    if (c < 3) s[c] += v;
+  }
+  if (!remove_com) return;
+  float m[3];
+  for (int c = 0; c < 3; ++c) m[c] = block_sum(s[c], red) / cnt;
+  for (int idx = t; idx < nl * 3; idx += kThreads) z_lig[(size_t)(r.l0 + idx / 3) * dl + idx % 3] -= m[idx % 3];
+  for (int idx = t; idx < np * 3; idx += kThreads) z_poc[(size_t)(r.p0 + idx / 3) * dp + idx % 3] -= m[idx % 3];
+}
+
+// One RePaint iteration of the conditional model after the reverse step (conditional_model.py:600-660):
+// on entry z_lig holds the denoised ("unknown") state z_s and xh_poc the pocket moved by that step.
+//   known part : x_known = x0 + (COM(pocket) - com_pocket0);  z_known = alpha_s [x_known | h0] + sigma_s noise1,
+//                ligand COM of z_known removed from z_known and the pocket;
+//   alignment  : dx = COM_fixed(z_unknown) - COM_fixed(z_known);  z_known.x += dx;  pocket.x += dx;
+//   blend      : z = z_known * fixed + z_unknown * (1 - fixed);
+//   resample   : (renoise) z <- alpha_t|s z + sigma_t|s noise2, ligand COM removed from z and the pocket.
+// zk_tmp [n_lig][dl] is scratch.
+struct CondRepaintArgs {
+  float* z_lig; float* xh_poc; float* zk_tmp;
+  const float* xh0_lig;        // [n_lig][dl] the given ligand, normalised
+  const float* com_pocket0;    // [B][3]
+  const float* fixed;          // [n_lig] 1 = known atom
+  const float* noise1; const float* noise2;
+  const int64_t* mask_lig; const int64_t* mask_poc;
+  int n_lig, n_poc, dl, dp;
+  float alpha_s, sigma_s, alpha_ts, sigma_ts;
+  int renoise, remove_com;
+};
+
+__global__ __launch_bounds__(kThreads) void cond_repaint_kernel(CondRepaintArgs p) {
+  __shared__ float red[kThreads];
+  const int t = threadIdx.x, b = blockIdx.x, dl = p.dl, dp = p.dp;
+  const SampleRows r = sample_rows(p.mask_lig, p.n_lig, p.mask_poc, p.n_poc, b);
+  const int nl = r.l1 - r.l0, np = r.p1 - r.p0;
+  float cp[3];
+  rows_sum3(p.xh_poc, dp, r.p0, r.p1, nullptr, red, cp);
+  const float npc = np > 0 ? (float)np : 1.f;
+  float shift[3];
+  for (int c = 0; c < 3; ++c) shift[c] = cp[c] / npc - p.com_pocket0[3 * b + c];
+  // z_known before centring
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int idx = t; idx < nl * dl; idx += kThreads) {
+    const int c = idx % dl;
+    const size_t o = (size_t)(r.l0 + idx / dl) * dl + c;
+    const float base = c < 3 ? p.xh0_lig[o] + shift[c] : p.xh0_lig[o];
+    const float v = p.alpha_s * base + p.sigma_s * p.noise1[o];
+    p.zk_tmp[o] = v;
+    if (c < 3) s[c] += v;
+  }
+  float m1[3] = {0.f, 0.f, 0.f};
+  if (p.remove_com) {
+    const float cnt = nl > 0 ? (float)nl : 1.f;
+    for (int c = 0; c < 3; ++c) m1[c] = block_sum(s[c], red) / cnt;
+  } else {
+    __syncthreads();
+  }
+  for (int idx = t; idx < nl * 3; idx += kThreads) p.zk_tmp[(size_t)(r.l0 + idx / 3) * dl + idx % 3] -= m1[idx % 3];
+  __syncthreads();   // zk_tmp rows of this sample are re-read by other threads below
+  // centres of mass of the fixed atoms of both parts
+  float ck[3], cu[3], nf = 0.f;
+  rows_sum3(p.zk_tmp, dl, r.l0, r.l1, p.fixed, red, ck, &nf);
+  rows_sum3(p.z_lig, dl, r.l0, r.l1, p.fixed, red, cu);
+  const float nfc = nf > 0.f ? nf : 1.f;
+  float dx[3];
+  for (int c = 0; c < 3; ++c) dx[c] = cu[c] / nfc - ck[c] / nfc;
+  // blend (+ optional q(z_t | z_s))
+  float s2[3] = {0.f, 0.f, 0.f};
+  for (int idx = t; idx < nl * dl; idx += kThreads) {
+    const int i = r.l0 + idx / dl, c = idx % dl;
+    const size_t o = (size_t)i * dl + c;
+    const float f = p.fixed[i];
+    float zk = p.zk_tmp[o];
+    if (c < 3) zk += dx[c];
+    float v = zk * f + p.z_lig[o] * (1.f - f);
+    if (p.renoise) {
+      v = p.alpha_ts * v + p.sigma_ts * p.noise2[o];
+      if (c < 3) s2[c] += v;
+    }
+    p.z_lig[o] = v;
+  }
+  float m2[3] = {0.f, 0.f, 0.f};
+  if (p.renoise && p.remove_com) {
+    const float cnt = nl > 0 ? (float)nl : 1.f;
+    for (int c = 0; c < 3; ++c) m2[c] = block_sum(s2[c], red) / cnt;
+    for (int idx = t; idx < nl * 3; idx += kThreads) p.z_lig[(size_t)(r.l0 + idx / 3) * dl + idx % 3] -= m2[idx % 3];
+  }
+  // the pocket follows every translation of the ligand frame, in the reference's order
+  for (int idx = t; idx < np * 3; idx += kThreads) {
+    const int c = idx % 3;
+    float* q = p.xh_poc + (size_t)(r.p0 + idx / 3) * dp + c;
+    float v = (*q - m1[c]) + dx[c];
+    if (p.renoise && p.remove_com) v -= m2[c];
+    *q = v;
+  }
+}
+
+// One RePaint iteration of the joint model after the reverse step (en_diffusion.py:742-809):
+// on entry z_* hold the denoised ("unknown") state.
+//   known part : z_known = alpha_s xh0 + sigma_s noise1   (x part of noise1 made COM-free here)
+//   alignment  : z_known.x += COM_known(z_unknown) - COM_known(z_known)   (known = fixed ligand + pocket nodes)
+//   blend      : z = z_known * fixed + z_unknown * (1 - fixed)
+//   jump back  : (renoise) z <- alpha_t|s z + sigma_t|s noise2 (COM-free), joint COM removed.
+struct JointRepaintArgs {
+  float* z_lig; float* z_poc; float* zk_lig; float* zk_poc;   // zk_*: scratch
+  const float* xh0_lig; const float* xh0_poc;
+  const float* fixed_l; const float* fixed_p;
+  const float* n1_l; const float* n1_p; const float* n2_l; const float* n2_p;
+  const int64_t* mask_lig; const int64_t* mask_poc;
+  int n_lig, n_poc, dl, dp;
+  float alpha_s, sigma_s, alpha_ts, sigma_ts;
+  int renoise;
+};
+
+__global__ __launch_bounds__(kThreads) void joint_repaint_kernel(JointRepaintArgs p) {
+  __shared__ float red[kThreads];
+  const int t = threadIdx.x, dl = p.dl, dp = p.dp;
+  const SampleRows r = sample_rows(p.mask_lig, p.n_lig, p.mask_poc, p.n_poc, blockIdx.x);
+  const int nl = r.l1 - r.l0, np = r.p1 - r.p0;
+  const float cnt = (nl + np) > 0 ? (float)(nl + np) : 1.f;
+  float a3[3], b3[3], mn[3];
+  rows_sum3(p.n1_l, dl, r.l0, r.l1, nullptr, red, a3);
+  rows_sum3(p.n1_p, dp, r.p0, r.p1, nullptr, red, b3);
+  for (int c = 0; c < 3; ++c) mn[c] = (a3[c] + b3[c]) / cnt;
+  for (int idx = t; idx < nl * dl; idx += kThreads) {
+    const int c = idx % dl;
+    const size_t o = (size_t)(r.l0 + idx / dl) * dl + c;
+    const float nz = c < 3 ? p.n1_l[o] - mn[c] : p.n1_l[o];
+    p.zk_lig[o] = p.alpha_s * p.xh0_lig[o] + p.sigma_s * nz;
+  }
+  for (int idx = t; idx < np * dp; idx += kThreads) {
+    const int c = idx % dp;
+    const size_t o = (size_t)(r.p0 + idx / dp) * dp + c;
+    const float nz = c < 3 ? p.n1_p[o] - mn[c] : p.n1_p[o];
+    p.zk_poc[o] = p.alpha_s * p.xh0_poc[o] + p.sigma_s * nz;
+  }
+  __syncthreads();
+  float kl[3], kp[3], ul[3], up[3], nfl = 0.f, nfp = 0.f;
+  rows_sum3(p.zk_lig, dl, r.l0, r.l1, p.fixed_l, red, kl, &nfl);
+  rows_sum3(p.zk_poc, dp, r.p0, r.p1, p.fixed_p, red, kp, &nfp);
+  rows_sum3(p.z_lig, dl, r.l0, r.l1, p.fixed_l, red, ul);
+  rows_sum3(p.z_poc, dp, r.p0, r.p1, p.fixed_p, red, up);
+  const float nk = (nfl + nfp) > 0.f ? (nfl + nfp) : 1.f;
+  float dx[3];
+  for (int c = 0; c < 3; ++c) dx[c] = (ul[c] + up[c]) / nk - (kl[c] + kp[c]) / nk;
+  float mn2[3] = {0.f, 0.f, 0.f};
+  if (p.renoise) {
+    rows_sum3(p.n2_l, dl, r.l0, r.l1, nullptr, red, a3);
+    rows_sum3(p.n2_p, dp, r.p0, r.p1, nullptr, red, b3);
+    for (int c = 0; c < 3; ++c) mn2[c] = (a3[c] + b3[c]) / cnt;
+  }
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int idx = t; idx < nl * dl; idx += kThreads) {
+    const int i = r.l0 + idx / dl, c = idx % dl;
+    const size_t o = (size_t)i * dl + c;
+    const float f = p.fixed_l[i];
+    float zk = p.zk_lig[o];
+    if (c < 3) zk += dx[c];
+    float v = zk * f + p.z_lig[o] * (1.f - f);
+    if (p.renoise) {
+      const float nz = c < 3 ? p.n2_l[o] - mn2[c] : p.n2_l[o];
+      v = p.alpha_ts * v + p.sigma_ts * nz;
+      if (c < 3) s[c] += v;
+    }
+    p.z_lig[o] = v;
+  }
+  for (int idx = t; idx < np * dp; idx += kThreads) {
+    const int i = r.p0 + idx / dp, c = idx % dp;
+    const size_t o = (size_t)i * dp + c;
+    const float f = p.fixed_p[i];
+    float zk = p.zk_poc[o];
+    if (c < 3) zk += dx[c];
+    float v = zk * f + p.z_poc[o] * (1.f - f);
+    if (p.renoise) {
+      const float nz = c < 3 ? p.n2_p[o] - mn2[c] : p.n2_p[o];
+      v = p.alpha_ts * v + p.sigma_ts * nz;
+      if (c < 3) s[c] += v;
+    }
+    p.z_poc[o] = v;
+  }
+  if (!p.renoise) return;
+  float m[3];
+  for (int c = 0; c < 3; ++c) m[c] = block_sum(s[c], red) / cnt;
+  for (int idx = t; idx < nl * 3; idx += kThreads) p.z_lig[(size_t)(r.l0 + idx / 3) * dl + idx % 3] -= m[idx % 3];
+  for (int idx = t; idx < np * 3; idx += kThreads) p.z_poc[(size_t)(r.p0 + idx / 3) * dp + idx % 3] -= m[idx % 3];
 }
 
 // ---- Philox4x32-10 (Salmon et al. 2011) + Box-Muller -----------------------

@@ -9,30 +9,36 @@
 //
 //     a1[e] = SiLU(P[row_e] + Q[col_e] + d_cur[e]*wd + d_0[e]*wd0 + table[type_e])
 //
-// so the per-edge work that is left is ONE H x H matmul per MLP.  That matmul
-// runs here on the fp32 matrix cores: a tile of BM edges is gathered (coalesced
-// 128-B row segments of P/Q), activated and written k-major into LDS, W2^T is
-// streamed from L2 in K slices, and the workgroup's 4 waves (2 along the edge
-// dimension x 2 along the feature dimension) accumulate a BM x H tile with
-// v_mfma_f32_32x32x2_f32.  The epilogue never leaves the chip:
+// so the per-edge work that is left is ONE H x H matmul per MLP, which runs on the
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32) in edge_wave.h.  The epilogue never
+// leaves the chip:
 //
 //   MODE_GCL   (GCL.edge_model + aggregation, egnn_new.py:31-52):
-//       m = SiLU(. + b2); att = sigmoid(w_a . m + b_a); the BM x H message tile
-//       goes to LDS, one thread per feature walks the (row-sorted) edges and
-//       does a segmented sum in edge order -- the reference's scatter_add order
-//       -- issuing one atomic per (row segment, feature); result / norm -> agg.
+//       m = SiLU(. + b2); att = sigmoid(w_a . m + b_a); segmented sums of m * att over
+//       the (row-sorted) edges of a 32-edge wave tile, in edge order -- the reference's
+//       scatter_add order -- scaled by 1 / normalization_factor.
 //   MODE_COORD (EquivariantUpdate.coord_model, egnn_new.py:96-122): the same main
 //       loop once per scalar MLP (coord_mlp, cross_product_mlp), then
 //       phi = tanh(w3 . SiLU(. + b2)) * range, trans = u*phi + cross*phi_x from
-//       the coordinates, segmented sum per row -> xagg.
+//       the coordinates, segmented sum per row.
 //
-// Edges are sorted by (row, col) (dynamics.py:185), so a row's edges are
-// contiguous: a row segment spans at most two tiles unless its degree exceeds
-// BM, and the two partial sums commute -> the aggregation is deterministic.
-// The kernels are persistent over tiles (the edge count lives in device memory:
-// no host sync, fixed launch geometry for graph capture) with an XCD-aware
-// tile order (each XCD walks a contiguous range of tiles = a few samples whose
-// Q rows stay in that XCD's L2).
+// Aggregation protocol (no atomics, no zero-filled accumulators, fixed summation order):
+// edges are sorted by (row, col) (dynamics.py:185), so a row's edges are contiguous.
+// Wave tile T = edges [32T, 32T + 32).  The partial sum of a row's edges inside a tile goes
+//   * to agg[row] (xagg[row])      when the tile holds the row's FIRST edge,
+//   * to agg_head[T] (xagg_head[T]) when the row continues from tile T - 1 (only the first
+//     segment of a tile can),
+// each written by exactly one wave with a plain store.  The consumer (the node MLP's first
+// layer, coord_update_kernel) forms  agg[row] + agg_head[T0 + 1] + ... + agg_head[T1]  in tile
+// order, T0 / T1 = tiles of the row's first / last edge (from row_ptr and deg).  Together with
+// the 32-aligned (sample, node set) segments of the edge list (graph.h) every per-row sum is a
+// pure function of that sample's data: results are bitwise reproducible and independent of the
+// batch composition / sharding.
+//
+// The kernels are persistent over 128-edge workgroup tiles (the edge count lives in device
+// memory: no host sync, fixed launch geometry for graph capture); each XCD owns a contiguous
+// range of tiles (a few samples whose Q rows stay in that XCD's L2) and its workgroups pull
+// tiles from a per-XCD counter, so no workgroup idles while another still has tiles queued.
 #pragma once
 #include "common.h"
 
@@ -63,12 +69,17 @@ struct EdgeArgs {
   EdgeMlpW mlp[2];
   // MODE_GCL
   const float* att_w; const float* att_b; int attention;
-  float* agg;             // [N][H], zero on entry
+  float* agg;             // [N][H]: partial sum of the tile holding the row's first edge
+  float* agg_head;        // [wave tiles][H]: partial sums of rows continuing from the previous tile
   // MODE_COORD
   const float* w3; const int* node_batch; const float* mean;  // mean [B][3]
   float norm_constant; float coords_range; int use_tanh; int n_mlp;
-  float* xagg;            // [N][3], zero on entry
+  float* xagg;            // [n_q][N][3]   (n_q = 2 with pass_split: one copy per MLP population)
+  float* xagg_head;       // [n_q][wave tiles][4]
+  size_t xagg_stride;     // floats between the two copies of xagg / xagg_head
+  size_t xhead_stride;
   float norm_factor;
+  int* tile_ctr;          // work-queue counters, all zero between launches (graph.h: kTileCtrInts)
   // edge_wave_kernel, MODE_COORD with two MLPs: alternate workgroups take the coordinate /
   // cross-product MLP of a tile (twice as many, half as long work items: better balance when
   // the masked edge prefix is only a few tiles per CU); the two terms of trans are linear

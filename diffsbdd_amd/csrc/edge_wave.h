@@ -22,13 +22,17 @@
 //     half-wave (a half-wave holds complete rows), accumulators scaled in place,
 //     segmented row sums walk the rows in edge order with the running sum passed
 //     as a baton between the two half-waves (rows alternate between them in groups
-//     of 4 in the MFMA accumulator layout); one atomic per (row segment, feature).
+//     of 4 in the MFMA accumulator layout); one plain store per (row segment,
+//     feature) following the aggregation protocol of edge_mlp.h (no atomics).
+//   * tiles come from a per-XCD work queue (one atomic per workgroup and tile, issued
+//     two K steps before its result is needed).
 //
 // Workgroup = 4 waves = 128 edges; LDS = 2 x 32 x H x 4 B (64 KB at H = 256) +
 // vectors -> 2 workgroups per CU, which overlap each other's epilogues.
 #pragma once
 #include "common.h"
 #include "edge_mlp.h"
+#include "graph.h"
 
 namespace dsbdd {
 
@@ -40,8 +44,9 @@ struct WaveLayout {
   static constexpr int VEC_PER = 7 * H;
   static constexpr int VEC_OFF = 2 * B_BUF;
   static constexpr int SCR_OFF = VEC_OFF + NV * VEC_PER;
-  static constexpr int SCR_PER = 32 + 32 * 3;              // per wave: phi[32], trans[32][3]
-  static constexpr int TOTAL = SCR_OFF + 4 * SCR_PER;
+  static constexpr int SCR_PER = 32 * 3;                   // per wave: trans[32][3]; phi[32] uses the same words earlier
+  static constexpr int NEXT_OFF = SCR_OFF + 4 * SCR_PER;   // next tile index from the work queue
+  static constexpr int TOTAL = NEXT_OFF + 4;
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, j = lane & 31;
   float* s_phi = smem + L::SCR_OFF + w * L::SCR_PER;   // [32]
-  float* s_tr = s_phi + 32;                             // [32][3]
+  float* s_tr = s_phi;                                  // [32][3] (phi is consumed before trans is written)
   const bool split = MODE == MODE_COORD && p.pass_split && p.n_mlp == 2;
   const int qsel = split ? ((blockIdx.x >> 3) & 1) : 0;   // the MLP this workgroup evaluates when split
   const int n_pass = (MODE == MODE_GCL || split) ? 1 : p.n_mlp;
@@ -115,7 +120,24 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int tq = ntiles / 8, tr = ntiles % 8;
   const int csize = tq + (xcd < tr ? 1 : 0);
   const int cbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  if (kx >= csize) return;
+  // Work queue: the workgroups of XCD x (and MLP population qsel) start with local tiles
+  // 0 .. gx-1 and then pull further local tile indices gx + atomicAdd(counter, 1).  Every
+  // workgroup counts itself out on the completion counter; the last one clears the counters
+  // for the next launch.  DYN needs four K steps per tile to hide the atomic (H >= 128).
+  constexpr bool DYN = NK >= 4;
+  int* q_head = p.tile_ctr + xcd + 8 * qsel;
+  int* q_done = p.tile_ctr + 16;
+  volatile int* s_next = reinterpret_cast<volatile int*>(smem + L::NEXT_OFF);
+  auto check_out = [&]() {
+    if (DYN && t == 0) {
+      __threadfence();
+      if (atomicAdd(q_done, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) p.tile_ctr[i] = 0;
+      }
+    }
+  };
+  if (kx >= csize) { check_out(); return; }
 
   // ---- W2^T slice streaming: direct global -> LDS DMA (global_load_lds, 16 B per lane,
   // LDS destination = wave-uniform base + lane*16), no staging registers.  The DMA is
@@ -138,11 +160,14 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   int my_r = -1, my_c = 0, my_ty = 0;
   float my_d = 0.f, my_d0 = 0.f, xr[3] = {0.f, 0.f, 0.f}, xc[3] = {0.f, 0.f, 0.f};
   int nx_r = -1, nx_c = 0;
+  int my_prev = -1, nx_prev = -1;      // row of the edge just before this wave tile (wave-uniform)
+  int my_wt = 0, nx_wt = 0;            // global wave-tile index
   float nx_d0 = 0.f, nxr[3] = {0.f, 0.f, 0.f}, nxc[3] = {0.f, 0.f, 0.f};
   auto fetch_idx = [&](int tile) {
-    const int e = tile * BMB + w * BMW + j;
-    nx_r = -1; nx_c = 0; nx_d0 = 0.f;
+    const int e0 = tile * BMB + w * BMW, e = e0 + j;
+    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = tile * 4 + w;
     if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
+    if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1];
   };
   auto fetch_x = [&]() {
     if (nx_r >= 0) {
@@ -152,6 +177,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   };
   auto commit_edge = [&]() {
     my_r = nx_r; my_c = nx_c; my_d0 = nx_d0; my_d = 0.f; my_ty = 0;
+    my_prev = nx_prev; my_wt = nx_wt;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { xr[k] = nxr[k]; xc[k] = nxc[k]; }
     if (my_r >= 0) {
@@ -175,16 +201,13 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   float4 pc = ld4(Pp), qc = ld4(Qp), pn = pc, qn4 = qc;
   float phi0 = 0.f, phi1 = 0.f;
 
-  const int my_tiles = (csize - kx + gx - 1) / gx;
-  const int U = my_tiles * n_pass;
-  int li = kx, q = 0;
+  int li = kx, q = 0, next_li = 0, ticket = 0;
+  bool has_next = false;
 #pragma unroll 1
-  for (int u = 0; u < U; ++u) {
+  for (;;) {
     const float* vq = sV + q * L::VEC_PER;
-    const bool last_unit = u + 1 == U;
     const bool tile_ends = q == n_pass - 1;
     const int qn = tile_ends ? 0 : q + 1;                  // MLP pass of the next unit
-    const bool prefetch_next_tile = tile_ends && !last_unit;
 
     f32x16 acc[CT];
 #pragma unroll
@@ -195,12 +218,29 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll 1
     for (int kt = 0; kt < NK; ++kt) {
       const bool more = kt + 1 < NK;
-      if (more) streamB(q, kt + 1, (bslice + 1) & 1);
-      else if (!last_unit) streamB(qn, 0, (bslice + 1) & 1);   // continuous stream across units
-      if (prefetch_next_tile) {                            // next tile's edge, two dependent loads
-        if (kt == 0) fetch_idx(cbase + li + gx);
-        if (kt == 1) fetch_x();
+      // next tile of this workgroup: queue ticket (two K steps of latency budget), then the
+      // tile's edge with two dependent loads, all behind the MFMAs of the current tile
+      const int st = q * NK + kt;
+      if (DYN) {
+        if (st == 0) { has_next = false; if (t == 0) ticket = atomicAdd(q_head, 1); }
+        if (st == 1 && t == 0) *s_next = gx + ticket;       // published by this K step's barrier
+        if (st == 2) {
+          next_li = *s_next;
+          has_next = next_li < csize;
+          if (has_next) fetch_idx(cbase + next_li);
+        }
+        if (st == 3 && has_next) fetch_x();
+      } else {
+        if (st == 0) {
+          next_li = li + gx;
+          has_next = next_li < csize;
+          if (has_next) fetch_idx(cbase + next_li);
+        }
+        if (st == 1 && has_next) fetch_x();
       }
+      const bool last_unit_k = tile_ends && !has_next;     // final from st >= 2 (DYN) / st >= 0
+      if (more) streamB(q, kt + 1, (bslice + 1) & 1);
+      else if (!last_unit_k) streamB(qn, 0, (bslice + 1) & 1);   // continuous stream across units
       const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
@@ -262,6 +302,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #endif
     }
 
+    const bool last_unit = tile_ends && !has_next;
     // first P/Q chunk of the NEXT unit: in flight during the epilogue
     if (!last_unit) {
       const int r_n = tile_ends ? nx_r : my_r, c_n = tile_ends ? nx_c : my_c;
@@ -318,11 +359,19 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) sum[c] = 0.f;
       int cur = -1;
+      // aggregation protocol (edge_mlp.h): the first segment of the tile goes to agg_head[tile]
+      // when its row continues from the previous wave tile, every other segment is the start of
+      // its row and goes to agg[row]; plain stores, each address written by exactly one wave
+      const int row0 = __builtin_amdgcn_readlane(my_r, 0);
+      bool to_head = row0 >= 0 && row0 == my_prev;
       auto flush = [&](int owner) {                        // the owning half holds the full sums
-        if (cur >= 0 && half == owner) {
-          float* dst = p.agg + (size_t)cur * H;
+        if (cur >= 0) {
+          if (half == owner) {
+            float* dst = to_head ? p.agg_head + (size_t)my_wt * H : p.agg + (size_t)cur * H;
 #pragma unroll
-          for (int c = 0; c < CT; ++c) unsafeAtomicAdd(dst + feat(c), sum[c] * inv_norm);
+            for (int c = 0; c < CT; ++c) dst[feat(c)] = sum[c] * inv_norm;
+          }
+          to_head = false;
         }
       };
 #pragma unroll
@@ -405,19 +454,31 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         if (half == 0) { s_tr[3 * j] = tx; s_tr[3 * j + 1] = ty; s_tr[3 * j + 2] = tz; }
         wave_lds_fence();
         if (lane < 3) {
+          const int pop = split ? qsel : 0;
+          float* xa = p.xagg + pop * p.xagg_stride;
+          float* xh = p.xagg_head + pop * p.xhead_stride;
+          const int row0 = __builtin_amdgcn_readlane(my_r, 0);
+          bool to_head = row0 >= 0 && row0 == my_prev;
           int cur = -1;
           float sum = 0.f;
+          auto put = [&]() {
+            if (cur >= 0) {
+              const float v = sum / p.norm_factor;
+              if (to_head) xh[4 * (size_t)my_wt + lane] = v; else xa[(size_t)cur * 3 + lane] = v;
+              to_head = false;
+            }
+          };
 #pragma unroll
           for (int e = 0; e < 32; ++e) {
             const int rn = __builtin_amdgcn_readlane(my_r, e);
             if (rn != cur) {
-              if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + lane], sum / p.norm_factor);
+              put();
               cur = rn;
               sum = 0.f;
             }
             sum += s_tr[3 * e + lane];
           }
-          if (cur >= 0) unsafeAtomicAdd(&p.xagg[(size_t)cur * 3 + lane], sum / p.norm_factor);
+          put();
         }
         wave_lds_fence();   // scratch is reused by the next tile
       }
@@ -425,13 +486,15 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 
     // advance to the next unit
     if (tile_ends) {
-      if (!last_unit) commit_edge();
-      li += gx;
+      if (last_unit) break;
+      commit_edge();
+      li = next_li;
       q = 0;
     } else {
       ++q;
     }
   }  // units
+  check_out();
 }
 
 }  // namespace dsbdd

@@ -44,6 +44,9 @@ struct dsbdd_engine {
   int *node_batch, *lig_off, *poc_off, *deg, *row_ptr, *erow, *ecol;
   int *act_flag, *act_ptr, *act_list;
   float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *pqg, *hout, *w2tp;
+  float *agg_head, *xagg_head;          // partial sums of rows continuing from the previous wave tile
+  int *scan_tmp, *seg_base, *tile_ctr;
+  int64_t cap_tiles = 0;                // wave tiles (32 edges) of the edge capacity
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   bool w2tp_ready = false;   // lane-grouped W2^T copies in the workspace are current
@@ -109,16 +112,19 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
   const int H = c.hidden_nf, JP = pad4(c.joint_nf + 1);
   const int LE = pad4(2 * (c.atom_nf > c.residue_nf ? c.atom_nf : c.residue_nf));
   const int PQ = (c.reflection_equivariant ? 2 : 4) * H;
+  const int64_t T = E / 32 + 2;        // wave tiles
   size_t sizes[] = {
       (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4, (size_t)(N + 1) * 4,  // 0-4
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4,                                                  // 5-7 erow ecol ed0
-      (size_t)N * 12, (size_t)N * 12, (size_t)N * 12, (size_t)B * 12,                               // 8-11 x x_in xagg mean
+      (size_t)N * 12, (size_t)N * 12, (size_t)N * 24, (size_t)B * 12,                               // 8-11 x x_in xagg[2] mean
       (size_t)N * JP * 4, (size_t)N * LE * 4,                                                       // 12 h0, 13 enc_tmp
       (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * PQ * 4,                  // 14 h 15 t1 16 agg 17 pq
       (size_t)N * JP * 4,                                                                           // 18 hout
       (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
       (size_t)N * 2 * H * 4,                                                                        // 22 pqg (GCL P|Q)
-      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 4};                                     // 23 lane-grouped W2^T copies
+      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 4,                                      // 23 lane-grouped W2^T copies
+      (size_t)T * H * 4, (size_t)T * 2 * 16,                                                        // 24 agg_head, 25 xagg_head[2][T][4]
+      (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4};                      // 26 scan_tmp 27 seg_base 28 tile_ctr
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -224,6 +230,9 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->act_flag = (int*)(b + L.off[19]); e->act_ptr = (int*)(b + L.off[20]); e->act_list = (int*)(b + L.off[21]);
   e->pqg = (float*)(b + L.off[22]);
   e->w2tp = (float*)(b + L.off[23]);
+  e->agg_head = (float*)(b + L.off[24]); e->xagg_head = (float*)(b + L.off[25]);
+  e->scan_tmp = (int*)(b + L.off[26]); e->seg_base = (int*)(b + L.off[27]); e->tile_ctr = (int*)(b + L.off[28]);
+  e->cap_tiles = E / 32 + 2;
   e->w2tp_ready = false;
   return DSBDD_OK;
 }
@@ -278,6 +287,7 @@ int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** out) {
     case DSBDD_BUF_H: *out = e->h; break;
     case DSBDD_BUF_X: *out = e->x; break;
     case DSBDD_BUF_NODE_BATCH: *out = e->node_batch; break;
+    case DSBDD_BUF_DEG: *out = e->deg; break;
     default: return fail(DSBDD_ERR_ARG, "unknown buffer id");
   }
   return DSBDD_OK;
@@ -350,21 +360,25 @@ static Cutoffs cutoffs_of(const dsbdd_config& c) {
 static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int B, const dsbdd_config& c,
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
-                            int* act_flag = nullptr) {
+                            int* act_flag = nullptr, int* scan_tmp = nullptr, int* seg_base = nullptr) {
   const int waves_per_block = kThreads / 64;
   int blocks = (N + waves_per_block - 1) / waves_per_block;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   const Cutoffs cut = cutoffs_of(c);
+  // with scan_tmp / seg_base: every (sample, node set) segment of the edge list starts at a wave-tile
+  // boundary (graph.h scan_kernel); without: a compact list (the public dsbdd_build_edges)
+  const int aligned = scan_tmp && seg_base;
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status, act_flag);
+                     (float*)nullptr, 0, status, act_flag, 0);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N);
+  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, aligned ? seg_base : nullptr};
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
-                     (int*)nullptr);
+                     (int*)nullptr, aligned);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -393,7 +407,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   {
     const int work = N > B + 1 ? N : B + 1;
     hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
-                       (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off);
+                       (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off, e->tile_ctr);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(assemble_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xh_lig, dl, xh_pocket, dp,
                        nlig, N, (const int*)e->node_batch, t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
@@ -420,7 +434,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                          ext_col, (int)ext_n_edges, (const float*)e->x, e->erow, e->ecol, e->ed0, e->deg);
       HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->deg, e->row_ptr, N);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->deg, e->row_ptr, N, SegAlign{});
     HIP_TRY(hipGetLastError());
     edge_bound = ext_n_edges > 0 ? ext_n_edges : 1;
     if (subset) {
@@ -435,11 +449,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   } else {
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
                               e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
-                              subset ? e->act_flag : nullptr);
+                              subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base);
     if (rc) return rc;
   }
   if (subset) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N, SegAlign{});
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(compact_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const int*)e->act_flag,
                        (const int*)e->act_ptr, e->act_list, N);
@@ -447,7 +461,6 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   }
   // ---- embedding (egnn_new.py:233) ---------------------------------------------
   HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
-  HIP_TRY(zero_async(e->xagg, (size_t)N * 12, s));
 
   const int n_upd = c.update_pocket_coords ? N : nlig;   // update_coords_mask, dynamics.py:130-132
   const int* e_all = e->row_ptr + N;
@@ -487,7 +500,6 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       // were launched together with the previous block's coordinate projections)
       if (!pqg_ready) HIP_TRY(launch_node_linear(s, gcl_pq(blk, sub)));
       pqg_ready = false;
-      HIP_TRY(zero_async(e->agg, (size_t)N * H * 4, s));
       EdgeArgs ea{};
       ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.e_cap = (int)e->cap_edges; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = 2 * H;
@@ -495,7 +507,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
-      ea.agg = e->agg; ea.norm_factor = c.normalization_factor;
+      ea.agg = e->agg; ea.agg_head = e->agg_head; ea.tile_ctr = e->tile_ctr;
+      ea.norm_factor = c.normalization_factor;
       const bool timed = e->time_now && e->ev_used + 2 <= e->ev.size();
       if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
       HIP_TRY(launch_edge(e, s, MODE_GCL, ea, edge_bound));
@@ -504,7 +517,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         e->ev_used += 2;
       }
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
-      HIP_TRY(nl(s, e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H, N, H, 1));
+      {   // the aggregate is completed in the A-operand loads (AggFix: agg + ordered head partial sums)
+        NodeLinearArgs a1{e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H,
+                          (int)N, H, 1, nullptr, nullptr, AggFix{e->agg_head, e->row_ptr, e->deg, H}};
+        HIP_TRY(launch_node_linear(s, a1));
+      }
       HIP_TRY(nl(s, e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H, N, H, 0));
     }
     {
@@ -543,13 +560,19 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         ea.mlp[1] = ea.mlp[0];
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
       ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
-      ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.norm_factor = c.normalization_factor;
+      ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.xagg_head = e->xagg_head;
+      ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = (size_t)e->cap_tiles * 4;
+      ea.tile_ctr = e->tile_ctr; ea.norm_factor = c.normalization_factor;
       ea.pass_split = e->coord_split;
      
       HIP_TRY(launch_edge(e, s, MODE_COORD, ea, edge_bound));
-      hipLaunchKernelGGL(coord_update_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, s, e->x, e->xagg,
-                         3 * n_upd, 3 * N);
-      HIP_TRY(hipGetLastError());
+      if (n_upd > 0) {
+        const int n_q = (e->coord_split && n_mlp == 2) ? 2 : 1;
+        hipLaunchKernelGGL(coord_update_kernel, dim3((3 * n_upd + 255) / 256), dim3(256), 0, s, e->x,
+                           (const float*)e->xagg, (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride,
+                           (const int*)e->row_ptr, (const int*)e->deg, 3 * n_upd);
+        HIP_TRY(hipGetLastError());
+      }
     }
     if (e->trace_h)
       HIP_TRY(hipMemcpyAsync(e->trace_h + (size_t)blk * N * H, e->h, (size_t)N * H * 4, hipMemcpyDeviceToDevice, s));
@@ -680,13 +703,88 @@ int dsbdd_joint_reverse_update(void* stream, float* z_lig, float* z_pocket, cons
                                const float* eps_pocket, const float* noise_lig, const float* noise_pocket,
                                const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
                                int64_t n_pocket, int64_t batch, int32_t atom_nf, int32_t residue_nf,
-                               float alpha_ts, float c_eps, float sigma) {
+                               float alpha_ts, float c_eps, float sigma, int32_t center_noise) {
   if (!z_lig || !z_pocket || !eps_lig || !eps_pocket || !noise_lig || !noise_pocket || !mask_lig ||
       !mask_pocket || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
   hipLaunchKernelGGL(joint_update_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      z_lig, z_pocket, eps_lig, eps_pocket, noise_lig, noise_pocket, mask_lig, (int)n_lig,
-                     mask_pocket, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, alpha_ts, c_eps, sigma);
+                     mask_pocket, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, alpha_ts, c_eps, sigma, center_noise);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_segment_mean3(void* stream, const float* x, int32_t ld, const int64_t* mask, int64_t n_rows,
+                        int64_t batch, float* out) {
+  if (!x || !mask || !out || batch < 1 || ld < 3 || n_rows < 0) return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(segment_mean3_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     x, ld, mask, (int)n_rows, out);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_cond_affine_noise(void* stream, float* z_lig, float* xh_pocket, const float* noise,
+                            const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
+                            int64_t n_pocket, int64_t batch, int32_t atom_nf, int32_t residue_nf, float a,
+                            float sigma, int32_t remove_com) {
+  if (!z_lig || !xh_pocket || !noise || !mask_lig || !mask_pocket || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(cond_affine_noise_kernel, dim3((int)batch), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), z_lig, xh_pocket, noise, mask_lig, (int)n_lig, mask_pocket,
+                     (int)n_pocket, 3 + atom_nf, 3 + residue_nf, a, sigma, remove_com);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_joint_affine_noise(void* stream, float* z_lig, float* z_pocket, const float* noise_lig,
+                             const float* noise_pocket, const int64_t* mask_lig, const int64_t* mask_pocket,
+                             int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
+                             int32_t residue_nf, float a, float sigma, int32_t center_noise,
+                             int32_t remove_com) {
+  if (!z_lig || !z_pocket || !noise_lig || !noise_pocket || !mask_lig || !mask_pocket || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(joint_affine_noise_kernel, dim3((int)batch), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), z_lig, z_pocket, noise_lig, noise_pocket, mask_lig,
+                     (int)n_lig, mask_pocket, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, a, sigma, center_noise,
+                     remove_com);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_cond_repaint_update(void* stream, float* z_lig, float* xh_pocket, float* scratch_lig,
+                              const float* xh0_lig, const float* com_pocket0, const float* fixed,
+                              const float* noise_known, const float* noise_resample, const int64_t* mask_lig,
+                              const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                              int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
+                              float alpha_ts, float sigma_ts, int32_t resample, int32_t remove_com) {
+  if (!z_lig || !xh_pocket || !scratch_lig || !xh0_lig || !com_pocket0 || !fixed || !noise_known ||
+      (resample && !noise_resample) || !mask_lig || !mask_pocket || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  CondRepaintArgs a{z_lig, xh_pocket, scratch_lig, xh0_lig, com_pocket0, fixed, noise_known, noise_resample,
+                    mask_lig, mask_pocket, (int)n_lig, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, alpha_s,
+                    sigma_s, alpha_ts, sigma_ts, resample, remove_com};
+  hipLaunchKernelGGL(cond_repaint_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, float* scratch_lig,
+                               float* scratch_pocket, const float* xh0_lig, const float* xh0_pocket,
+                               const float* fixed_lig, const float* fixed_pocket, const float* noise_known_lig,
+                               const float* noise_known_pocket, const float* noise_jump_lig,
+                               const float* noise_jump_pocket, const int64_t* mask_lig,
+                               const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                               int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
+                               float alpha_ts, float sigma_ts, int32_t jump) {
+  if (!z_lig || !z_pocket || !scratch_lig || !scratch_pocket || !xh0_lig || !xh0_pocket || !fixed_lig ||
+      !fixed_pocket || !noise_known_lig || !noise_known_pocket || (jump && (!noise_jump_lig || !noise_jump_pocket)) ||
+      !mask_lig || !mask_pocket || batch < 1)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  JointRepaintArgs a{z_lig, z_pocket, scratch_lig, scratch_pocket, xh0_lig, xh0_pocket, fixed_lig, fixed_pocket,
+                     noise_known_lig, noise_known_pocket, noise_jump_lig, noise_jump_pocket, mask_lig, mask_pocket,
+                     (int)n_lig, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, alpha_s, sigma_s, alpha_ts, sigma_ts,
+                     jump};
+  hipLaunchKernelGGL(joint_repaint_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -743,7 +841,7 @@ int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig, con
   const int N = (int)(n_lig + n_pocket), B = (int)batch;
   const int work = N > B + 1 ? N : B + 1;
   hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, (int)n_lig, mask_pocket,
-                     (int)n_pocket, B, node_batch, lig_off, poc_off);
+                     (int)n_pocket, B, node_batch, lig_off, poc_off, (int*)nullptr);
   HIP_TRY(hipGetLastError());
   return build_edges_impl(s, x, (int)n_lig, N, B, *cfg, node_batch, lig_off, poc_off, deg, row_ptr, edge_row,
                           edge_col, edge_d0, edge_capacity, status);

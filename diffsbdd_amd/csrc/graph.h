@@ -12,6 +12,9 @@
 
 namespace dsbdd {
 
+constexpr int kTileCtrInts = 32;   // 16 queue heads (8 XCDs x 2 MLP populations) + completion count
+constexpr int kEdgeAlign = 32;     // edges of one (sample, node set) start at a multiple of a wave tile
+
 struct Cutoffs {
   int has_l, has_p, has_i;
   float cl, cp, ci;
@@ -29,8 +32,9 @@ __device__ __forceinline__ int lower_bound_i64(const int64_t* a, int n, int64_t 
 // node_batch[i] = sample id of node i ([ligand | pocket] numbering);
 // lig_off[b] / poc_off[b] = first ligand / pocket node of sample b (b = 0..B).
 __global__ void prep_kernel(const int64_t* mask_lig, int n_lig, const int64_t* mask_poc, int n_poc,
-                            int B, int* node_batch, int* lig_off, int* poc_off) {
+                            int B, int* node_batch, int* lig_off, int* poc_off, int* tile_ctr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile_ctr && i < kTileCtrInts) tile_ctr[i] = 0;   // work-queue counters of the edge kernels
   if (i < n_lig) node_batch[i] = (int)mask_lig[i];
   else if (i < n_lig + n_poc) node_batch[i] = (int)mask_poc[i - n_lig];
   if (i <= B) {
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const int* __restrict__ lig_off, const int* __restrict__ poc_off, int n_lig, int n_nodes,
     Cutoffs cut, int* __restrict__ deg, const int* __restrict__ row_ptr, int* __restrict__ erow,
     int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status,
-    int* __restrict__ act_flag) {
+    int* __restrict__ act_flag, int pad_rows) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -95,6 +99,16 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
     }
     if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
+    if (FILL && pad_rows) {
+      // the last row of a (sample, node set) segment fills the segment up to the next wave-tile
+      // boundary with inactive entries (row = -1), see scan_kernel
+      const int seg_last = (il ? lig_off[b + 1] : n_lig + poc_off[b + 1]) - 1;
+      if (i == seg_last) {
+        const int from = base + cnt, to = (from + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
+        const int pos = from + lane;
+        if (pos < to && pos < e_cap) { erow[pos] = -1; ecol[pos] = 0; ed0[pos] = 0.f; }
+      }
+    }
   }
 }
 
@@ -102,11 +116,55 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
 // workgroup of 1024 threads (n is tens of thousands) walks tiles of 4096
 // elements: coalesced 16-byte loads, 4-element serial prefix per lane, wave
 // scan by lane shuffles, 16 wave totals through LDS, running carry in a register.
-__global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr, int n) {
+//
+// With `seg` set, the edges of every (sample, node set) segment -- the rows of the ligand
+// nodes of sample b, then the rows of its pocket nodes; 2B segments in node order -- start at
+// a multiple of kEdgeAlign: row_ptr[i] = seg_base[segment of i] + (edges of the earlier rows
+// of that segment), row_ptr[n] = padded total, and the gaps are filled with inactive entries by
+// edges_kernel<true>.  A wave tile of the edge kernels (32 consecutive edges) then never mixes
+// samples and holds the same edges whatever else is in the batch, which makes every per-row sum
+// independent of the batch composition (bitwise identical results for any sharding).
+// A row's edge count stays in deg[]; row i owns [row_ptr[i], row_ptr[i] + deg[i]).
+struct SegAlign {
+  const int* node_batch; const int* lig_off; const int* poc_off;
+  int n_lig; int B;
+  int* scan_tmp;   // [n + 1] plain exclusive scan
+  int* seg_base;   // [2B + 1]
+};
+
+__device__ __forceinline__ int block_scan_1024(int mine, int* s_wave, int* s_total) {
+  // exclusive prefix of `mine` over the 1024 threads of the workgroup; *s_total = sum
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  if (w == 0) {
+    int tot = lane < 16 ? s_wave[lane] : 0;
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane < 16) s_wave[lane] = inc - tot;
+    if (lane == 15) *s_total = inc;
+  }
+  __syncthreads();
+  const int r = s_wave[w] + incl - mine;
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr, int n, SegAlign seg) {
   __shared__ int s_wave[16];
   __shared__ int s_carry;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const bool vec = ((reinterpret_cast<uintptr_t>(deg) | reinterpret_cast<uintptr_t>(row_ptr)) & 15) == 0;
+  const int t = threadIdx.x;
+  int* out = seg.seg_base ? seg.scan_tmp : row_ptr;
+  const bool vec = ((reinterpret_cast<uintptr_t>(deg) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   int carry = 0;
   for (int base = 0; base < n; base += 4096) {
     const int i0 = base + 4 * t;
@@ -119,38 +177,43 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
       for (int k = 0; k < 4; ++k) if (i0 + k < n) v[k] = deg[i0 + k];
     }
     const int mine = v[0] + v[1] + v[2] + v[3];
-    int incl = mine;                                   // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) s_wave[w] = incl;
-    __syncthreads();
-    if (w == 0) {                                      // scan of the 16 wave totals
-      int tot = lane < 16 ? s_wave[lane] : 0;
-      int inc = tot;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const int u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-      }
-      if (lane < 16) s_wave[lane] = inc - tot;         // exclusive offset of each wave
-      if (lane == 15) s_carry = inc;                   // tile total
-    }
-    __syncthreads();
-    int run = carry + s_wave[w] + incl - mine;
+    int run = carry + block_scan_1024(mine, s_wave, &s_carry);
     const int tile_total = s_carry;
     if (vec && i0 + 3 < n) {
       int4 o4;
       o4.x = run; o4.y = run + v[0]; o4.z = o4.y + v[1]; o4.w = o4.z + v[2];
-      *reinterpret_cast<int4*>(row_ptr + i0) = o4;
+      *reinterpret_cast<int4*>(out + i0) = o4;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (i0 + k < n) { row_ptr[i0 + k] = run; run += v[k]; }
+      for (int k = 0; k < 4; ++k) if (i0 + k < n) { out[i0 + k] = run; run += v[k]; }
     }
     carry += tile_total;
     __syncthreads();                                   // s_wave / s_carry are reused by the next tile
+  }
+  if (t == 0) out[n] = carry;
+  if (!seg.seg_base) return;
+  __syncthreads();                                     // the plain scan is visible to the whole workgroup
+  // padded length of every segment -> exclusive scan -> seg_base
+  const int S = 2 * seg.B;
+  auto seg_begin = [&](int k) { return k < seg.B ? seg.lig_off[k] : seg.n_lig + seg.poc_off[k - seg.B]; };
+  auto seg_end = [&](int k) { return k < seg.B ? seg.lig_off[k + 1] : seg.n_lig + seg.poc_off[k - seg.B + 1]; };
+  carry = 0;
+  for (int base = 0; base < S; base += 1024) {
+    const int k = base + t;
+    int len = 0;
+    if (k < S) len = (out[seg_end(k)] - out[seg_begin(k)] + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
+    const int ex = carry + block_scan_1024(len, s_wave, &s_carry);
+    if (k < S) seg.seg_base[k] = ex;
+    carry += s_carry;
+    __syncthreads();
+  }
+  if (t == 0) seg.seg_base[S] = carry;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    const int b = seg.node_batch[i];
+    const bool poc = i >= seg.n_lig;
+    const int k = poc ? seg.B + b : b;
+    row_ptr[i] = seg.seg_base[k] + out[i] - out[seg_begin(k)];
   }
   if (t == 0) row_ptr[n] = carry;
 }
@@ -254,13 +317,27 @@ __global__ __launch_bounds__(kThreads) void sample_mean_kernel(const float* x, c
   }
 }
 
-// x[i] += xagg[i] for the nodes whose coordinates are updated
-// (update_coords_mask, egnn_new.py:118-121), and clear xagg for the next block.
-__global__ void coord_update_kernel(float* x, float* xagg, int n_upd3, int n_all3) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_all3) return;
-  if (i < n_upd3) x[i] += xagg[i];
-  xagg[i] = 0.f;
+// x[i] += (sum over the row's edges of trans) for the nodes whose coordinates are updated
+// (update_coords_mask, egnn_new.py:118-121).  The coordinate edge kernel leaves, per MLP
+// population q, the partial sum of the wave tile that holds the row's first edge in xagg[q][i]
+// and the partial sums of the following tiles of a row that spans several in xhead[q][tile];
+// they are added here in tile order (fixed summation order, no atomics).
+__global__ void coord_update_kernel(float* x, const float* xagg, const float* xhead, int n_q,
+                                    size_t xagg_stride, size_t xhead_stride, const int* row_ptr,
+                                    const int* deg, int n_upd3) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_upd3) return;
+  const int i = idx / 3, c = idx - 3 * i;
+  const int d = deg[i];
+  if (d == 0) return;
+  const int s = row_ptr[i], t0 = s >> 5, t1 = (s + d - 1) >> 5;
+  float tot = 0.f;
+  for (int q = 0; q < n_q; ++q) {
+    float a = xagg[q * xagg_stride + idx];
+    for (int T = t0 + 1; T <= t1; ++T) a += xhead[q * xhead_stride + 4 * (size_t)T + c];
+    tot += a;
+  }
+  x[idx] += tot;
 }
 
 // vel = x_final - x_in (dynamics.py:136), NaN guard (dynamics.py:155-159: flag

@@ -179,6 +179,13 @@ class StepCoefficients:
         self.alpha = torch.sqrt(torch.sigmoid(-gam))            # alpha_t per index
         self.sigma_t = torch.sqrt(torch.sigmoid(gam))
 
+    def pair(self, s, t):
+        """(alpha_{t|s}, sigma_{t|s}) between two level indices s < t (en_diffusion.py:83-107)."""
+        g_s, g_t = self.gamma[s], self.gamma[t]
+        sigma2 = -torch.expm1(F.softplus(g_s) - F.softplus(g_t))
+        alpha_ts = torch.exp(0.5 * (F.logsigmoid(-g_t) - F.logsigmoid(-g_s)))
+        return float(alpha_ts), float(torch.sqrt(sigma2))
+
 
 class EnVariationalDiffusion(nn.Module):
     """The E(n) diffusion module (joint ligand + pocket)."""
@@ -253,6 +260,45 @@ class EnVariationalDiffusion(nn.Module):
     @staticmethod
     def sample_gaussian(size, device):
         return torch.randn(size, device=device)
+
+    # ---- fused per-sample kernels (csrc/ddpm.h): fixed reduction order, in place ----------------
+    @staticmethod
+    def _cs(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def _seg_mean3(self, x, mask, batch):
+        """Per-sample mean of x[:, :3] (scatter_mean semantics) with a fixed summation order
+        (torch's index_add_ uses float atomics: neither reproducible nor sharding-invariant)."""
+        x = x.contiguous()
+        out = torch.zeros((batch, 3), dtype=torch.float32, device=x.device)
+        if x.shape[0] == 0:
+            return out
+        _lib.check(_lib.load().dsbdd_segment_mean3(self._cs(x), x.data_ptr(), x.shape[1], mask.data_ptr(),
+                                                   x.shape[0], batch, out.data_ptr()), "dsbdd_segment_mean3")
+        return out
+
+    def _joint_noise_raw(self, lig_mask, pocket_mask, batch):
+        """Gaussian draws for both node sets, [n][3 + nf] each, x part NOT yet COM-centred (the
+        kernels centre it).  Injected noise keeps the reference's draw order (x of all nodes, h_lig,
+        h_pocket: en_diffusion.py:559-578); the keyed generator draws one block per node set."""
+        nl = lig_mask.numel()
+        if self.noise_source is not None:
+            comb = torch.cat((lig_mask, pocket_mask))
+            zx = self._randn(comb, self.n_dims, batch)
+            zh_l = self._randn(lig_mask, self.atom_nf, batch)
+            zh_p = self._randn(pocket_mask, self.residue_nf, batch)
+            return (torch.cat([zx[:nl], zh_l], dim=1).contiguous(),
+                    torch.cat([zx[nl:], zh_p], dim=1).contiguous())
+        return (self._randn(lig_mask, self.n_dims + self.atom_nf, batch, stream_id=1),
+                self._randn(pocket_mask, self.n_dims + self.residue_nf, batch, stream_id=2))
+
+    def _joint_gauss_(self, z_l, z_p, lig_mask, pocket_mask, batch, a, sigma, remove_com):
+        """In place: z <- a z + sigma eps with COM-free eps (+ joint COM removal of the result)."""
+        n_l, n_p = self._joint_noise_raw(lig_mask, pocket_mask, batch)
+        _lib.check(_lib.load().dsbdd_joint_affine_noise(
+            self._cs(z_l), z_l.data_ptr(), z_p.data_ptr(), n_l.data_ptr(), n_p.data_ptr(), lig_mask.data_ptr(),
+            pocket_mask.data_ptr(), lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf, self.residue_nf,
+            float(a), float(sigma), 1, int(remove_com)), "dsbdd_joint_affine_noise")
 
     # ---- schedule helpers (same names as the reference) --------------------------
     def check_issues_norm_values(self, num_stdevs=8):
@@ -390,30 +436,27 @@ class EnVariationalDiffusion(nn.Module):
         return self._joint_noise(lig_indices, pocket_indices, batch)
 
     def _joint_noise(self, lig_mask, pocket_mask, batch):
-        nl = lig_mask.numel()
+        """COM-free joint noise as tensors (public helpers; the sampling loops centre inside the kernels)."""
+        n_l, n_p = self._joint_noise_raw(lig_mask, pocket_mask, batch)
+        nd = self.n_dims
         comb = torch.cat((lig_mask, pocket_mask))
-        if self.noise_source is not None:
-            zx = self._randn(comb, self.n_dims, batch)
-        else:
-            zx = torch.cat((self._randn(lig_mask, self.n_dims, batch, stream_id=1),
-                            self._randn(pocket_mask, self.n_dims, batch, stream_id=2)))
+        zx = torch.cat((n_l[:, :nd], n_p[:, :nd]))
         zx = zx - seg_mean(zx, comb, batch)[comb]
-        zh_l = self._randn(lig_mask, self.atom_nf, batch, stream_id=3)
-        zh_p = self._randn(pocket_mask, self.residue_nf, batch, stream_id=4)
-        return torch.cat([zx[:nl], zh_l], dim=1), torch.cat([zx[nl:], zh_p], dim=1)
+        nl = lig_mask.numel()
+        return torch.cat([zx[:nl], n_l[:, nd:]], dim=1), torch.cat([zx[nl:], n_p[:, nd:]], dim=1)
 
     # ---- one reverse step, joint model (en_diffusion.py:503-557) ---------------------------
     def _joint_step(self, s, co, z_lig, z_pocket, lig_mask, pocket_mask, batch, status):
         """In place: z_* at level s+1 -> level s."""
         eps_l, eps_p, _ = self._dyn(z_lig, z_pocket, co.t_value[s + 1], lig_mask, pocket_mask, batch,
                                     status, True)
-        n_l, n_p = self._joint_noise(lig_mask, pocket_mask, batch)
+        n_l, n_p = self._joint_noise_raw(lig_mask, pocket_mask, batch)
         lib = _lib.load()
         _lib.check(lib.dsbdd_joint_reverse_update(
             torch.cuda.current_stream(z_lig.device).cuda_stream, z_lig.data_ptr(), z_pocket.data_ptr(),
             eps_l.data_ptr(), eps_p.data_ptr(), n_l.data_ptr(), n_p.data_ptr(), lig_mask.data_ptr(),
             pocket_mask.data_ptr(), lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf,
-            self.residue_nf, float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s])),
+            self.residue_nf, float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s]), 1),
             "dsbdd_joint_reverse_update")
 
     def sample_p_zs_given_zt(self, s, t, zt_lig, zt_pocket, ligand_mask, pocket_mask, fix_noise=False):
@@ -488,11 +531,10 @@ class EnVariationalDiffusion(nn.Module):
         e_l, e_p, _ = self._dyn(z0_lig.contiguous(), z0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
                                 batch_size, status, True)
         self._check_status(status)
-        mu_l = self.compute_x_pred(e_l, z0_lig, gamma_0, lig_mask)
-        mu_p = self.compute_x_pred(e_p, z0_pocket, gamma_0, pocket_mask)
-        n_l, n_p = self._joint_noise(lig_mask, pocket_mask, batch_size)
-        xh_l = mu_l + sigma_x[lig_mask] * n_l
-        xh_p = mu_p + sigma_x[pocket_mask] * n_p
+        xh_l = self.compute_x_pred(e_l, z0_lig, gamma_0, lig_mask).contiguous()
+        xh_p = self.compute_x_pred(e_p, z0_pocket, gamma_0, pocket_mask).contiguous()
+        # xh = mu + sigma_x * eps, eps COM-free (en_diffusion.py:263-288); one t for the whole batch
+        self._joint_gauss_(xh_l, xh_p, lig_mask, pocket_mask, batch_size, 1.0, float(sigma_x.reshape(-1)[0]), False)
         nd = self.n_dims
         x_l, h_l = self.unnormalize(xh_l[:, :nd], z0_lig[:, nd:])
         x_p, h_p = self.unnormalize(xh_p[:, :nd], z0_pocket[:, nd:])
@@ -527,8 +569,9 @@ class EnVariationalDiffusion(nn.Module):
         pocket_mask = num_nodes_to_batch_mask(n_samples, num_nodes_pocket, device).contiguous()
         lig_mask, pocket_mask = self._begin_chain(lig_mask, pocket_mask, n_samples)
         co = self._coefs(timesteps)
-        z_l, z_p = self._joint_noise(lig_mask, pocket_mask, n_samples)
-        z_l, z_p = z_l.contiguous(), z_p.contiguous()
+        z_l = torch.zeros((lig_mask.numel(), self.n_dims + self.atom_nf), device=device)
+        z_p = torch.zeros((pocket_mask.numel(), self.n_dims + self.residue_nf), device=device)
+        self._joint_gauss_(z_l, z_p, lig_mask, pocket_mask, n_samples, 0.0, 1.0, False)     # z_T
         out_lig = torch.zeros((return_frames,) + z_l.size(), device=device)
         out_pocket = torch.zeros((return_frames,) + z_p.size(), device=device)
         status = torch.zeros(1, dtype=torch.int32, device=device)
@@ -583,58 +626,62 @@ class EnVariationalDiffusion(nn.Module):
         n = len(ligand['size'])
         nd = self.n_dims
         lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
-        lig_fixed, pocket_fixed = lig_fixed.to(dev).float(), pocket_fixed.to(dev).float()
-        # row ids of the fixed nodes, found once: boolean-mask indexing inside the loop would cost a
-        # host sync (nonzero) four times per step
-        lfb = torch.nonzero(lig_fixed.view(-1) != 0).view(-1)
-        pfb = torch.nonzero(pocket_fixed.view(-1) != 0).view(-1)
+        lfix = lig_fixed.to(dev).float().reshape(-1).contiguous()
+        pfix = pocket_fixed.to(dev).float().reshape(-1).contiguous()
         comb = torch.cat((lm, pm))
-        known_idx = torch.cat((lm[lfb], pm[pfb]))
-        xh0_l = torch.cat([ligand['x'], ligand['one_hot']], dim=1).to(dev)
-        xh0_p = torch.cat([pocket['x'], pocket['one_hot']], dim=1).to(dev)
-        mean_known = seg_mean(torch.cat((xh0_l[:, :nd][lfb], xh0_p[:, :nd][pfb])), known_idx, n)
+        xh0_l = torch.cat([ligand['x'], ligand['one_hot']], dim=1).to(dev).contiguous()
+        xh0_p = torch.cat([pocket['x'], pocket['one_hot']], dim=1).to(dev).contiguous()
+        # centre the input at the COM of the known nodes (en_diffusion.py:703-709); the row ids of the
+        # known nodes are found once (one host sync per chain), in sample order for the fixed-order mean
+        kx = torch.cat((xh0_l[:, :nd][lfix != 0], xh0_p[:, :nd][pfix != 0]))
+        kid = torch.cat((lm[lfix != 0], pm[pfix != 0]))
+        order = torch.argsort(kid, stable=True)
+        mean_known = self._seg_mean3(kx[order], kid[order].contiguous(), n)
         xh0_l[:, :nd] = xh0_l[:, :nd] - mean_known[lm]
         xh0_p[:, :nd] = xh0_p[:, :nd] - mean_known[pm]
 
         co = self._coefs(timesteps)
-        z_l, z_p = self._joint_noise(lm, pm, n)
-        z_l, z_p = z_l.contiguous(), z_p.contiguous()
+        z_l, z_p = torch.zeros_like(xh0_l), torch.zeros_like(xh0_p)
+        self._joint_gauss_(z_l, z_p, lm, pm, n, 0.0, 1.0, False)                            # z_T
+        zk_l, zk_p = torch.empty_like(z_l), torch.empty_like(z_p)                           # kernel scratch
         out_lig = torch.zeros((return_frames,) + z_l.size(), device=dev)
         out_pocket = torch.zeros((return_frames,) + z_p.size(), device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib = _lib.load()
+
+        def repaint(s, n1, n2, a_ts, s_ts):
+            _lib.check(lib.dsbdd_joint_repaint_update(
+                self._cs(z_l), z_l.data_ptr(), z_p.data_ptr(), zk_l.data_ptr(), zk_p.data_ptr(),
+                xh0_l.data_ptr(), xh0_p.data_ptr(), lfix.data_ptr(), pfix.data_ptr(), n1[0].data_ptr(),
+                n1[1].data_ptr(), n2[0].data_ptr() if n2 else None, n2[1].data_ptr() if n2 else None,
+                lm.data_ptr(), pm.data_ptr(), lm.numel(), pm.numel(), n, self.atom_nf, self.residue_nf,
+                float(co.alpha[s]), float(co.sigma_t[s]), a_ts, s_ts, 1 if n2 else 0),
+                "dsbdd_joint_repaint_update")
 
         schedule = self.get_repaint_schedule(resamplings, jump_length, timesteps)
         s = timesteps - 1
         for i, n_denoise_steps in enumerate(schedule):
             for j in range(n_denoise_steps):
-                # known part: q(z_s | x) with fresh noise (en_diffusion.py:742-746)
-                a_s, sg_s = co.alpha[s], co.sigma_t[s]
-                eps_l, eps_p = self._joint_noise(lm, pm, n)
-                zk_l = a_s * xh0_l + sg_s * eps_l
-                zk_p = a_s * xh0_p + sg_s * eps_p
-                # unknown part: one reverse step of the current state
-                zu_l, zu_p = z_l.clone(), z_p.clone()
-                self._joint_step(s, co, zu_l, zu_p, lm, pm, n, status)
-                # align COMs of the known nodes (en_diffusion.py:752-772)
-                com_n = seg_mean(torch.cat((zk_l[:, :nd][lfb], zk_p[:, :nd][pfb])), known_idx, n)
-                com_d = seg_mean(torch.cat((zu_l[:, :nd][lfb], zu_p[:, :nd][pfb])), known_idx, n)
-                dx = com_d - com_n
-                zk_l[:, :nd] = zk_l[:, :nd] + dx[lm]
-                zk_p[:, :nd] = zk_p[:, :nd] + dx[pm]
-                z_l = (zk_l * lig_fixed + zu_l * (1 - lig_fixed)).contiguous()
-                z_p = (zk_p * pocket_fixed + zu_p * (1 - pocket_fixed)).contiguous()
-                if n_denoise_steps > jump_length or i == len(schedule) - 1:
-                    if (s * return_frames) % timesteps == 0:
+                # the state buffers z_l / z_p are updated in place (stable pointers: the engine replays
+                # its captured graph); per iteration: noise draws, one EGNN call, two small kernels
+                n1 = self._joint_noise_raw(lm, pm, n)           # known part: q(z_s | x), en_diffusion.py:742-746
+                self._joint_step(s, co, z_l, z_p, lm, pm, n, status)    # unknown part: one reverse step
+                jump = j == n_denoise_steps - 1 and i < len(schedule) - 1
+                frame = (n_denoise_steps > jump_length or i == len(schedule) - 1) and \
+                    (s * return_frames) % timesteps == 0
+                a_ts, s_ts = co.pair(s, s + jump_length) if jump else (1.0, 0.0)
+                if jump and not frame:
+                    # COM alignment, blend and the jump back q(z_t | z_s) (en_diffusion.py:752-809) in one kernel
+                    repaint(s, n1, self._joint_noise_raw(lm, pm, n), a_ts, s_ts)
+                else:
+                    repaint(s, n1, None, 1.0, 0.0)
+                    if frame:
                         idx = (s * return_frames) // timesteps
                         out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_l, z_p)
-                if j == n_denoise_steps - 1 and i < len(schedule) - 1:
-                    # jump back jump_length steps: q(z_t | z_s) (en_diffusion.py:793-809)
-                    t = s + jump_length
-                    g_s = co.gamma[s].view(1, 1).expand(n, 1).to(dev)
-                    g_t = co.gamma[t].view(1, 1).expand(n, 1).to(dev)
-                    z_l, z_p = self.sample_p_zt_given_zs(z_l, z_p, lm, pm, g_t, g_s)
-                    z_l, z_p = z_l.contiguous(), z_p.contiguous()
-                    s = t
+                    if jump:
+                        self._joint_gauss_(z_l, z_p, lm, pm, n, a_ts, s_ts, True)
+                if jump:
+                    s = s + jump_length
                 s -= 1
         self._check_status(status)
         self.assert_mean_zero_with_mask(torch.cat((z_l[:, :nd], z_p[:, :nd]), dim=0), comb)

@@ -122,13 +122,16 @@ def pack_weights(sd, cfg, device):
 
 
 def edge_capacity(mask_lig, mask_pocket, batch):
-    """Upper bound on the number of directed edges incl. self loops: the
-    complete graph inside every sample (dynamics.py:170-172).  One host sync;
-    callers cache it per chain."""
-    nl = torch.bincount(mask_lig, minlength=batch)
-    np_ = torch.bincount(mask_pocket, minlength=batch)
-    n = (nl + np_).to(torch.int64)
-    return int((n * n).sum().item())
+    """Upper bound on the length of the engine's edge list: the complete graph
+    inside every sample (dynamics.py:170-172, self loops included), with the edges
+    of each (sample, node set) segment rounded up to a multiple of 32 (the engine
+    starts every segment at a wave-tile boundary, csrc/graph.h).  One host sync;
+    sampling chains compute it once."""
+    nl = torch.bincount(mask_lig, minlength=batch).to(torch.int64)
+    np_ = torch.bincount(mask_pocket, minlength=batch).to(torch.int64)
+    n = nl + np_
+    seg = lambda v: (v + 31) // 32 * 32
+    return int((seg(nl * n) + seg(np_ * n)).sum().item())
 
 
 class HipEngine:
@@ -245,7 +248,14 @@ class HipEngine:
         return r.value, c.value, g.value
 
     def edge_count(self, n_nodes):
-        """Number of edges of the last forward (syncs)."""
+        """Number of edges of the last forward (syncs): the sum of the row degrees.  The edge
+        list itself is longer: every (sample, node set) segment is padded to a multiple of 32."""
+        import numpy as np
+        torch.cuda.synchronize(self.device)
+        return int(self._read(self.buffer_ptr(_lib.BUF_DEG), n_nodes, np.int32).astype(np.int64).sum())
+
+    def edge_slots(self, n_nodes):
+        """Length of the last forward's edge list including the padding entries (syncs)."""
         import numpy as np
         torch.cuda.synchronize(self.device)
         return int(self._read(self.buffer_ptr(_lib.BUF_ROW_PTR) + 4 * n_nodes, 1, np.int32)[0])
@@ -264,7 +274,8 @@ class HipEngine:
         E = int(rp[-1])
         row = self._read(self.buffer_ptr(_lib.BUF_EDGE_ROW), E, np.int32)
         col = self._read(self.buffer_ptr(_lib.BUF_EDGE_COL), E, np.int32)
-        return torch.from_numpy(row.astype("int64")), torch.from_numpy(col.astype("int64"))
+        keep = row >= 0                                   # padding entries carry row = -1
+        return torch.from_numpy(row[keep].astype("int64")), torch.from_numpy(col[keep].astype("int64"))
 
     def _read(self, ptr, count, dtype):
         import numpy as np

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DSBDD_ABI_VERSION 1
+#define DSBDD_ABI_VERSION 2
 
 enum {
   DSBDD_OK = 0,
@@ -170,7 +170,7 @@ int dsbdd_engine_graph_stats(const dsbdd_engine* e, int64_t* replays, int64_t* c
 /* Introspection of the last forward (device pointers into the workspace). */
 enum {
   DSBDD_BUF_EDGE_ROW = 0, DSBDD_BUF_EDGE_COL, DSBDD_BUF_EDGE_D0, DSBDD_BUF_ROW_PTR,
-  DSBDD_BUF_H, DSBDD_BUF_X, DSBDD_BUF_NODE_BATCH
+  DSBDD_BUF_H, DSBDD_BUF_X, DSBDD_BUF_NODE_BATCH, DSBDD_BUF_DEG
 };
 int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** ptr_out);
 
@@ -187,14 +187,68 @@ int dsbdd_cond_reverse_update(void* stream, float* z_lig, float* xh_pocket, cons
                               float c_eps, float sigma, int32_t remove_com);
 
 /* EnVariationalDiffusion.sample_p_zs_given_zt after the dynamics call
- * (en_diffusion.py:530-556): both node sets are updated, noise_* must already
- * be COM-free in x (en_diffusion.py:932-942), and the joint COM is removed. */
+ * (en_diffusion.py:530-556): both node sets are updated and the joint COM is
+ * removed.  center_noise != 0: the x part (first 3 columns) of noise_* is made
+ * COM-free over the sample's ligand + pocket rows inside the kernel
+ * (sample_center_gravity_zero_gaussian_batch, en_diffusion.py:932-942);
+ * center_noise = 0: the caller passes noise that is already COM-free. */
 int dsbdd_joint_reverse_update(void* stream, float* z_lig, float* z_pocket, const float* eps_lig,
                                const float* eps_pocket, const float* noise_lig,
                                const float* noise_pocket, const int64_t* mask_lig,
                                const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket,
                                int64_t batch, int32_t atom_nf, int32_t residue_nf, float alpha_ts,
-                               float c_eps, float sigma);
+                               float c_eps, float sigma, int32_t center_noise);
+
+/* ---- the other per-step pieces of the sampling loops ------------------------
+ * One workgroup per sample, fixed reduction order: every result is a pure function
+ * of that sample's rows (bitwise reproducible, independent of the batch composition).
+ *
+ * out[b][0..2] = mean over the rows of sample b of x[:, 0..2] (x [n_rows][ld], mask sorted);
+ * torch_scatter.scatter_mean semantics (count clamped to >= 1). */
+int dsbdd_segment_mean3(void* stream, const float* x, int32_t ld, const int64_t* mask, int64_t n_rows,
+                        int64_t batch, float* out);
+
+/* ConditionalDDPM.sample_normal_zero_com / noised_representation / sample_p_zt_given_zs
+ * (conditional_model.py:140-183,420-430), in place:
+ *   z_lig <- a * z_lig + sigma * noise ; remove_com: ligand COM subtracted from ligand and pocket x. */
+int dsbdd_cond_affine_noise(void* stream, float* z_lig, float* xh_pocket, const float* noise,
+                            const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
+                            int64_t n_pocket, int64_t batch, int32_t atom_nf, int32_t residue_nf, float a,
+                            float sigma, int32_t remove_com);
+
+/* EnVariationalDiffusion.sample_combined_position_feature_noise / noised_representation /
+ * sample_p_zt_given_zs (en_diffusion.py:302-317,479-501,559-578), in place on both node sets:
+ *   z <- a * z + sigma * noise, noise optionally COM-centred (x part), result optionally COM-free.
+ *   a = 0, sigma = 1 draws z_T. */
+int dsbdd_joint_affine_noise(void* stream, float* z_lig, float* z_pocket, const float* noise_lig,
+                             const float* noise_pocket, const int64_t* mask_lig, const int64_t* mask_pocket,
+                             int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
+                             int32_t residue_nf, float a, float sigma, int32_t center_noise,
+                             int32_t remove_com);
+
+/* One RePaint iteration of ConditionalDDPM.inpaint after the reverse step
+ * (conditional_model.py:600-660).  On entry z_lig = denoised state, xh_pocket = pocket moved by
+ * that step.  Known part noised to level s around the moved pocket, COM of the fixed atoms of both
+ * parts aligned, blend by `fixed`, optional q(z_t | z_s) resampling step; the pocket follows every
+ * translation.  scratch_lig [n_lig][3 + atom_nf]; com_pocket0 [batch][3]; fixed [n_lig]. */
+int dsbdd_cond_repaint_update(void* stream, float* z_lig, float* xh_pocket, float* scratch_lig,
+                              const float* xh0_lig, const float* com_pocket0, const float* fixed,
+                              const float* noise_known, const float* noise_resample, const int64_t* mask_lig,
+                              const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                              int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
+                              float alpha_ts, float sigma_ts, int32_t resample, int32_t remove_com);
+
+/* One RePaint iteration of EnVariationalDiffusion.inpaint after the reverse step
+ * (en_diffusion.py:742-809): known part q(z_s | x) with COM-centred noise, COM alignment over the
+ * fixed ligand + pocket nodes, blend, optional jump back q(z_t | z_s) + joint COM removal. */
+int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, float* scratch_lig,
+                               float* scratch_pocket, const float* xh0_lig, const float* xh0_pocket,
+                               const float* fixed_lig, const float* fixed_pocket, const float* noise_known_lig,
+                               const float* noise_known_pocket, const float* noise_jump_lig,
+                               const float* noise_jump_pocket, const int64_t* mask_lig,
+                               const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                               int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
+                               float alpha_ts, float sigma_ts, int32_t jump);
 
 /* Counter-based Gaussian noise, keyed by (seed, global sample id, row within
  * the sample, column, draw index) so that a chain's noise does not depend on

@@ -240,20 +240,22 @@ def test_se3_equivariance_full_size(arch):
     assert (a_p[:, 3:] - b_p[:, 3:]).abs().max().item() < TOL
 
 
-def test_run_to_run_agreement_and_forced_multi_tile_loop():
-    """Run-to-run agreement of the edge kernels, and the persistent multi-tile path on a
-    golden case: DSBDD_EDGE_MAX_WG caps the persistent grid at 8 (GCL) / 16 (coordinate
-    stage) workgroups, so every workgroup walks many tiles (next-tile prefetch,
-    commit_edge, the continuous W2^T stream across units) -- the path large batches
-    take -- and must reproduce the reference-generated eps."""
+def test_bitwise_reproducible_and_forced_multi_tile_loop():
+    """The edge aggregation has a fixed summation order (csrc/edge_mlp.h: plain stores + ordered
+    head partial sums, no atomics): repeated calls are bitwise equal, and so is a run whose tiles
+    are distributed differently over the workgroups.  DSBDD_EDGE_MAX_WG caps the persistent grid at
+    8 (GCL) / 16 (coordinate stage) workgroups, so every workgroup walks many tiles (work queue,
+    next-tile prefetch, commit_edge, the continuous W2^T stream across units) -- the path large
+    batches take -- and must reproduce the reference-generated eps."""
     import os
     c = Case("dyn_fullatom_cond")
     sd = c.state_dict()
     args = (c.t("xh_lig"), c.t("xh_pocket"), c.t("t"), c.t("mask_lig"), c.t("mask_pocket"))
     m = make_dynamics(c.cfg, sd)
     a, ap, _ = m.forward_async(*args)
-    b, bp, _ = m.forward_async(*args)
-    assert (a - b).abs().max().item() < 1e-6
+    for _ in range(3):
+        b, bp, _ = m.forward_async(*args)
+        assert torch.equal(a, b) and torch.equal(ap, bp)
     os.environ["DSBDD_EDGE_MAX_WG"] = "8"
     try:
         mv = make_dynamics(c.cfg, sd)
@@ -261,10 +263,33 @@ def test_run_to_run_agreement_and_forced_multi_tile_loop():
         d2, p2, _ = mv.forward_async(*args)
     finally:
         del os.environ["DSBDD_EDGE_MAX_WG"]
-    assert (d1 - d2).abs().max().item() < 1e-6
-    assert (a - d1).abs().max().item() < 1e-5 and (ap - p1).abs().max().item() < 1e-5
+    assert torch.equal(d1, d2) and torch.equal(p1, p2)
+    assert torch.equal(a, d1) and torch.equal(ap, p1)        # independent of the tile -> workgroup assignment
     assert (d1.cpu() - c.t("eps_lig")).abs().max().item() < TOL           # 1e-4
     assert (p1.cpu() - c.t("eps_pocket")).abs().max().item() < TOL
+
+
+def test_batch_composition_invariance_bitwise():
+    """a sample's result must not depend on what else is in the batch.  Every
+    (sample, node set) segment of the edge list starts at a wave-tile boundary and all per-row /
+    per-sample sums have a fixed order, so eps of samples 0..1 evaluated alone equals, bit for bit,
+    their rows in the 3-sample batch (device-built edges, both model kinds)."""
+    for name in ("dyn_fullatom_cond", "dyn_fullatom_joint", "dyn_small_variant"):
+        c = Case(name)
+        m = make_dynamics(c.cfg, c.state_dict())
+        d = dev()
+        xl, xp, t, ml, mp = (c.t(k).to(d) for k in ("xh_lig", "xh_pocket", "t", "mask_lig", "mask_pocket"))
+        B = int(max(ml.max(), mp.max())) + 1
+        assert B >= 2
+        full_l, full_p = m(xl, xp, t, ml, mp)
+        keep = B - 1
+        sl, sp = ml < keep, mp < keep
+        sub_l, sub_p = m(xl[sl], xp[sp], t[:keep], ml[sl], mp[sp])
+        assert torch.equal(sub_l, full_l[sl]) and torch.equal(sub_p, full_p[sp]), name
+        # ... and the last sample alone (relabelled 0)
+        sl, sp = ml == keep, mp == keep
+        one_l, one_p = m(xl[sl], xp[sp], t[keep:], ml[sl] - keep, mp[sp] - keep)
+        assert torch.equal(one_l, full_l[sl]) and torch.equal(one_p, full_p[sp]), name
 
 
 # ---------------------------------------------------------------------------
@@ -400,11 +425,11 @@ def test_full_size_chain_properties():
     half = {k: v[: len(v) // 2] for k, v in pocket.items()}
     a_l, _, _, _ = run(half, 32, 0)
     b_l, _, _, _ = run(half, 32, 32)
-    # not bitwise: where a row's edge segment is split between two tiles depends on
-    # the batch composition (fp32 summation order); 5 steps stay well inside 1e-3
+    # bitwise: fixed summation order everywhere + keyed noise (identical for W = 1/2/4/8)
     both = torch.cat([a_l, b_l])
-    assert (both[:, :3] - out_l[:, :3]).abs().max().item() < 1e-3
-    assert (both[:, 3:] != out_l[:, 3:]).any(1).float().mean().item() < 0.01
+    assert torch.equal(both, out_l)
+    again, _, _, _ = run(pocket, 64, 0)
+    assert torch.equal(again, out_l)                           # and run-to-run
 
 
 def test_keyed_noise_statistics_and_sharding():
@@ -541,6 +566,15 @@ def test_joint_full_width_inpaint_runs_at_scale():
     assert torch.all((oh == 0) | (oh == 1)) and torch.all(oh.sum(1) == 1)
     com = torch.zeros(B, 3, device=out_l.device).index_add_(0, torch.cat([lm, pm]), torch.cat([out_l[:, :3], out_p[:, :3]]))
     assert (com / (nl + 286)).abs().max().item() < 5e-2
+    # sharding invariance of the RePaint chain, bitwise: samples 4..7 as their own batch with offset 4
+    _, _, pocket4 = _bench_problem("crossdock_fullatom_cond", 4)
+    lmask4 = torch.repeat_interleave(torch.arange(4), nl)
+    ligand4 = {"x": torch.zeros(4 * nl, 3), "one_hot": torch.zeros(4 * nl, 10), "size": torch.full((4,), nl),
+               "mask": lmask4}
+    model.seed(7, sample_offset=4)
+    h_l, h_p, _, _ = model.inpaint(ligand4, pocket4, torch.zeros(4 * nl), torch.ones(len(pocket4["mask"])),
+                                   resamplings=2, jump_length=1, timesteps=3)
+    assert torch.equal(h_l, out_l[4 * nl:]) and torch.equal(h_p, out_p[4 * 286:])
 
 
 def test_eager_calls_between_graph_replays():
@@ -597,7 +631,7 @@ def test_unsorted_masks_raise_and_manual_seed_controls_noise():
     model._seed, model._draw = None, 0
     torch.manual_seed(12)
     d = run()
-    assert (a - b).abs().max().item() < 1e-4 and (a[:, :3] - d[:, :3]).abs().max().item() > 1e-2
+    assert torch.equal(a, b) and (a[:, :3] - d[:, :3]).abs().max().item() > 1e-2
     bad = c.pocket()
     bad["mask"] = bad["mask"].flip(0)
     with pytest.raises(ValueError, match="sorted"):
