@@ -124,7 +124,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // 0 .. gx-1 and then pull further local tile indices gx + atomicAdd(counter, 1).  Every
   // workgroup counts itself out on the completion counter; the last one clears the counters
   // for the next launch.  DYN needs four K steps per tile to hide the atomic (H >= 128).
+#ifdef DSBDD_STATIC_TILES
+  constexpr bool DYN = false;      // A/B builds: static round-robin tile assignment
+#else
   constexpr bool DYN = NK >= 4;
+#endif
   int* q_head = p.tile_ctr + xcd + 8 * qsel;
   int* q_done = p.tile_ctr + 16;
   volatile int* s_next = reinterpret_cast<volatile int*>(smem + L::NEXT_OFF);

@@ -149,19 +149,26 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
     sstore();
     __syncthreads();
     if (kt + 1 < nk) gload((kt + 1) * BK);  // in flight during the MFMAs
-    const float* pa = sA + (lane >> 5) * LDA + wm * (BM / 2) + (lane & 31);
-    const float* pb = sB + (lane >> 5) * BN + wn * 64 + (lane & 31);
+    // k pairing of one MFMA: (k, k + 4) inside every group of 8 -- the same summation order as
+    // node_gemm_kernel below, so that the choice between the two kernels (made from the problem
+    // size) never changes a result bit
+    const float* pa = sA + 4 * (lane >> 5) * LDA + wm * (BM / 2) + (lane & 31);
+    const float* pb = sB + 4 * (lane >> 5) * BN + wn * 64 + (lane & 31);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[RT], b[2];
+    for (int g = 0; g < BK / 8; ++g) {
 #pragma unroll
-      for (int i = 0; i < RT; ++i) a[i] = pa[kk * LDA + i * 32];
+      for (int q = 0; q < 4; ++q) {
+        const int kk = 8 * g + q;
+        float a[RT], b[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = pb[kk * BN + j * 32];
+        for (int i = 0; i < RT; ++i) a[i] = pa[kk * LDA + i * 32];
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
+        for (int j = 0; j < 2; ++j) b[j] = pb[kk * BN + j * 32];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+      }
     }
     __syncthreads();
   }
