@@ -28,8 +28,8 @@
 //   * to agg[row] (xagg[row])      when the tile holds the row's FIRST edge,
 //   * to agg_head[T] (xagg_head[T]) when the row continues from tile T - 1 (only the first
 //     segment of a tile can),
-// each written by exactly one wave with a plain store.  The consumer (the node MLP's first
-// layer, coord_update_kernel) forms  agg[row] + agg_head[T0 + 1] + ... + agg_head[T1]  in tile
+// each written by exactly one wave with a plain store.  agg_complete_kernel (below) and
+// coord_update_kernel then form  agg[row] + agg_head[T0 + 1] + ... + agg_head[T1]  in tile
 // order, T0 / T1 = tiles of the row's first / last edge (from row_ptr and deg).  Together with
 // the 32-aligned (sample, node set) segments of the edge list (graph.h) every per-row sum is a
 // pure function of that sample's data: results are bitwise reproducible and independent of the
@@ -37,8 +37,8 @@
 //
 // The kernels are persistent over 128-edge workgroup tiles (the edge count lives in device
 // memory: no host sync, fixed launch geometry for graph capture); each XCD owns a contiguous
-// range of tiles (a few samples whose Q rows stay in that XCD's L2) and its workgroups pull
-// tiles from a per-XCD counter, so no workgroup idles while another still has tiles queued.
+// range of tiles (a few samples whose Q rows stay in that XCD's L2), walked round-robin by its
+// workgroups.
 #pragma once
 #include "common.h"
 
@@ -87,5 +87,29 @@ struct EdgeArgs {
 };
 
 enum { MODE_GCL = 0, MODE_COORD = 1 };
+
+// agg[row] <- agg[row] + agg_head[T0 + 1] + ... + agg_head[T1] (tile order); rows without edges
+// become 0.  One wave per row, 16-byte lanes; rows that live in a single tile (about half of them
+// at degree ~17) are left untouched.  Costs what the zero fill of the atomic version cost.
+__global__ __launch_bounds__(kThreads) void agg_complete_kernel(float* agg, const float* agg_head,
+                                                                const int* row_ptr, const int* deg,
+                                                                int n_rows, int H) {
+  const int row = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int d = deg[row], s = row_ptr[row];
+  const int t0 = s >> 5, t1 = (s + d - 1) >> 5;
+  if (d > 0 && t1 == t0) return;
+  for (int k = 4 * lane; k < H; k += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d > 0) {
+      v = ld4(agg + (size_t)row * H + k);
+      for (int T = t0 + 1; T <= t1; ++T) {
+        const float4 h = ld4(agg_head + (size_t)T * H + k);
+        v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+      }
+    }
+    *reinterpret_cast<float4*>(agg + (size_t)row * H + k) = v;
+  }
+}
 
 }  // namespace dsbdd

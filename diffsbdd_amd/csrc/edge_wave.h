@@ -24,8 +24,8 @@
 //     as a baton between the two half-waves (rows alternate between them in groups
 //     of 4 in the MFMA accumulator layout); one plain store per (row segment,
 //     feature) following the aggregation protocol of edge_mlp.h (no atomics).
-//   * tiles come from a per-XCD work queue (one atomic per workgroup and tile, issued
-//     two K steps before its result is needed).
+//   * tiles are assigned round-robin inside each XCD's contiguous tile range (a per-XCD work
+//     queue exists behind -DDSBDD_DYNAMIC_TILES; it measured slower).
 //
 // Workgroup = 4 waves = 128 edges; LDS = 2 x 32 x H x 4 B (64 KB at H = 256) +
 // vectors -> 2 workgroups per CU, which overlap each other's epilogues.
@@ -124,10 +124,14 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // 0 .. gx-1 and then pull further local tile indices gx + atomicAdd(counter, 1).  Every
   // workgroup counts itself out on the completion counter; the last one clears the counters
   // for the next launch.  DYN needs four K steps per tile to hide the atomic (H >= 128).
-#ifdef DSBDD_STATIC_TILES
-  constexpr bool DYN = false;      // A/B builds: static round-robin tile assignment
-#else
+  // (Measured: the queue LOSES 3 % against the static round-robin assignment at the benchmark size --
+  // message stage 0.432 vs 0.427 ms, coordinate stage 127 vs 114 us, profiles/README.md: with two
+  // resident workgroups per CU the static order keeps the (kx, kx + n_CU) pairs of a CU balanced and
+  // costs nothing.  Static is the default; -DDSBDD_DYNAMIC_TILES builds the queue.)
+#ifdef DSBDD_DYNAMIC_TILES
   constexpr bool DYN = NK >= 4;
+#else
+  constexpr bool DYN = false;
 #endif
   int* q_head = p.tile_ctr + xcd + 8 * qsel;
   int* q_done = p.tile_ctr + 16;

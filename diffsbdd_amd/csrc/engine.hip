@@ -369,16 +369,16 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   // with scan_tmp / seg_base: every (sample, node set) segment of the edge list starts at a wave-tile
   // boundary (graph.h scan_kernel); without: a compact list (the public dsbdd_build_edges)
   const int aligned = scan_tmp && seg_base;
+  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, aligned ? seg_base : nullptr};
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status, act_flag, 0);
+                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr);
   HIP_TRY(hipGetLastError());
-  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, aligned ? seg_base : nullptr};
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
-                     (int*)nullptr, aligned);
+                     (int*)nullptr, sg, row_ptr);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -516,12 +516,12 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
         e->ev_used += 2;
       }
+      // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
+      hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
+                         (const float*)e->agg_head, (const int*)e->row_ptr, (const int*)e->deg, N, H);
+      HIP_TRY(hipGetLastError());
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
-      {   // the aggregate is completed in the A-operand loads (AggFix: agg + ordered head partial sums)
-        NodeLinearArgs a1{e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H,
-                          (int)N, H, 1, nullptr, nullptr, AggFix{e->agg_head, e->row_ptr, e->deg, H}};
-        HIP_TRY(launch_node_linear(s, a1));
-      }
+      HIP_TRY(nl(s, e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H, N, H, 1));
       HIP_TRY(nl(s, e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H, N, H, 0));
     }
     {

@@ -43,6 +43,13 @@ __global__ void prep_kernel(const int64_t* mask_lig, int n_lig, const int64_t* m
   }
 }
 
+struct SegAlign {
+  const int* node_batch; const int* lig_off; const int* poc_off;
+  int n_lig; int B;
+  int* scan_tmp;   // [n + 1] plain exclusive scan
+  int* seg_base;   // [2B + 1]
+};
+
 // One wave per row node.  FILL=false counts neighbours (deg), FILL=true writes
 // them at row_ptr[row].  Candidates are visited in index order (ligand nodes of
 // the sample, then its pocket nodes) and compacted with ballot/popcount, so the
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const int* __restrict__ lig_off, const int* __restrict__ poc_off, int n_lig, int n_nodes,
     Cutoffs cut, int* __restrict__ deg, const int* __restrict__ row_ptr, int* __restrict__ erow,
     int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status,
-    int* __restrict__ act_flag, int pad_rows) {
+    int* __restrict__ act_flag, SegAlign seg, int* __restrict__ row_ptr_out) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -62,7 +69,19 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const int b = node_batch[i];
     const bool il = i < n_lig;
     const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
-    const int base = FILL ? row_ptr[i] : 0;
+    // aligned layout: first edge of row i = base of its (sample, node set) segment + the edges of the
+    // segment's earlier rows (plain scan differences); compact layout: the plain scan itself
+    int base = 0;
+    if (FILL) {
+      if (seg.seg_base) {
+        const int k = il ? b : seg.B + b;
+        const int first = il ? lig_off[b] : n_lig + poc_off[b];
+        base = seg.seg_base[k] + seg.scan_tmp[i] - seg.scan_tmp[first];
+        if (lane == 0) row_ptr_out[i] = base;
+      } else {
+        base = row_ptr[i];
+      }
+    }
     int cnt = 0, cnt_lig = 0;
 #pragma unroll 1
     for (int seg = 0; seg < 2; ++seg) {
@@ -99,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
     }
     if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
-    if (FILL && pad_rows) {
+    if (FILL && seg.seg_base) {
       // the last row of a (sample, node set) segment fills the segment up to the next wave-tile
       // boundary with inactive entries (row = -1), see scan_kernel
       const int seg_last = (il ? lig_off[b + 1] : n_lig + poc_off[b + 1]) - 1;
@@ -120,18 +139,12 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
 // With `seg` set, the edges of every (sample, node set) segment -- the rows of the ligand
 // nodes of sample b, then the rows of its pocket nodes; 2B segments in node order -- start at
 // a multiple of kEdgeAlign: row_ptr[i] = seg_base[segment of i] + (edges of the earlier rows
-// of that segment), row_ptr[n] = padded total, and the gaps are filled with inactive entries by
+// of that segment) -- evaluated and stored by edges_kernel<true> from the plain scan and seg_base
+// computed here --, row_ptr[n] = padded total, and the gaps are filled with inactive entries by
 // edges_kernel<true>.  A wave tile of the edge kernels (32 consecutive edges) then never mixes
 // samples and holds the same edges whatever else is in the batch, which makes every per-row sum
 // independent of the batch composition (bitwise identical results for any sharding).
 // A row's edge count stays in deg[]; row i owns [row_ptr[i], row_ptr[i] + deg[i]).
-struct SegAlign {
-  const int* node_batch; const int* lig_off; const int* poc_off;
-  int n_lig; int B;
-  int* scan_tmp;   // [n + 1] plain exclusive scan
-  int* seg_base;   // [2B + 1]
-};
-
 __device__ __forceinline__ int block_scan_1024(int mine, int* s_wave, int* s_total) {
   // exclusive prefix of `mine` over the 1024 threads of the workgroup; *s_total = sum
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -207,15 +220,10 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
     carry += s_carry;
     __syncthreads();
   }
-  if (t == 0) seg.seg_base[S] = carry;
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) {
-    const int b = seg.node_batch[i];
-    const bool poc = i >= seg.n_lig;
-    const int k = poc ? seg.B + b : b;
-    row_ptr[i] = seg.seg_base[k] + out[i] - out[seg_begin(k)];
+  if (t == 0) {
+    seg.seg_base[S] = carry;
+    row_ptr[n] = carry;           // padded total; row_ptr[0 .. n) is written by edges_kernel<true>
   }
-  if (t == 0) row_ptr[n] = carry;
 }
 
 // Zero fill as an ordinary kernel on the caller's stream.  hipMemsetAsync is avoided inside

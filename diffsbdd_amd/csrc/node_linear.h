@@ -19,32 +19,6 @@
 
 namespace dsbdd {
 
-// A2 is an edge aggregate written with the protocol of edge_mlp.h: row r of the operand is
-//   A2[r] + head[T0 + 1] + ... + head[T1]      (tile order; all zero for a row without edges)
-// with T0 / T1 the wave tiles of the row's first / last edge.
-struct AggFix {
-  const float* head;    // [wave tiles][ld]; nullptr = A2 is a plain matrix
-  const int* row_ptr;   // [M] first edge of the row
-  const int* deg;       // [M] number of edges of the row
-  int ld;
-};
-
-// tiles (T0, T1] whose head rows are added to row `row`; T1 < T0 marks a row without edges
-__device__ __forceinline__ void agg_fix_range(const AggFix& f, int row, int& t0, int& t1) {
-  const int d = f.deg[row], s = f.row_ptr[row];
-  t0 = s >> 5;
-  t1 = d > 0 ? (s + d - 1) >> 5 : t0 - 1;
-}
-
-__device__ __forceinline__ float4 agg_fix4(const AggFix& f, int t0, int t1, int kcol, float4 v) {
-  if (t1 < t0) return make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int T = t0 + 1; T <= t1; ++T) {
-    const float4 h = ld4(f.head + (size_t)T * f.ld + kcol);
-    v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
-  }
-  return v;
-}
-
 struct NodeLinearArgs {
   const float* A1; int lda1; int K1;
   const float* A2; int lda2; int K2;
@@ -57,7 +31,6 @@ struct NodeLinearArgs {
   // the number of logical rows read from device memory (min(M, *m_count)); used for
   // the active-node subset of the coordinate-MLP projections
   const int* row_idx; const int* m_count;
-  AggFix fix;            // applies to A2 (needs 16-byte aligned rows: vec_ok)
 };
 
 template <int BM, bool VEC_A>
@@ -99,11 +72,6 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
             const float* src = (k < p.K1) ? p.A1 + (size_t)m * p.lda1 + k
                                           : p.A2 + (size_t)m * p.lda2 + (k - p.K1);
             v = ld4(src);
-            if (p.fix.head && k >= p.K1) {
-              int t0, t1;
-              agg_fix_range(p.fix, m, t0, t1);
-              v = agg_fix4(p.fix, t0, t1, k - p.K1, v);
-            }
           }
         } else {
           float e[4];
@@ -212,8 +180,8 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
 constexpr int kMaxGroup = 3;
 struct NodeGroupArgs { NodeLinearArgs p[kMaxGroup]; };
 
-template <int CT, bool FIX>
-__global__ __launch_bounds__(kThreads, ((CT == 4 || FIX) ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga) {
+template <int CT>
+__global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga) {
   constexpr int BN = 32 * CT, BK = (CT == 1 ? 64 : 128 / CT), NG = BK / 8;
   constexpr int BI = BK * BN / 4 / kThreads;          // float4 DMA pieces per thread per slice
   constexpr int RQ = BN / 4;                          // float4 per slice row
@@ -241,17 +209,11 @@ __global__ __launch_bounds__(kThreads, ((CT == 4 || FIX) ? 3 : 4)) void node_gem
   const int row = rowl < M ? (p.row_idx ? p.row_idx[rowl] : rowl) : 0;
   const float* a1 = p.A1 + (size_t)row * p.lda1 + 4 * half;
   const float* a2 = p.K2 ? p.A2 + (size_t)row * p.lda2 + 4 * half : a1;
-  int fx0 = 0, fx1 = 0;                              // head tiles (fx0, fx1] of this lane's row
-  if (FIX) agg_fix_range(p.fix, row, fx0, fx1);
   auto loadA = [&](int ks, float4 (&dst)[NG]) {
     const int k0 = ks * BK;                          // a K step never straddles A1 | A2
     const float* src = k0 < p.K1 ? a1 + k0 : a2 + (k0 - p.K1);
 #pragma unroll
     for (int g = 0; g < NG; ++g) dst[g] = ld4(src + 8 * g);
-    if (FIX && k0 >= p.K1) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) dst[g] = agg_fix4(p.fix, fx0, fx1, k0 - p.K1 + 4 * half + 8 * g, dst[g]);
-    }
   };
 
   f32x16 acc[CT];
@@ -321,8 +283,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline bool vec_ok(const NodeLinearArgs& a) {
   return aligned16(a.A1) && (a.lda1 % 4 == 0) && (a.K1 % 4 == 0) &&
-         (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0))) &&
-         (!a.fix.head || (aligned16(a.fix.head) && a.fix.ld % 4 == 0));
+         (a.K2 == 0 || (aligned16(a.A2) && (a.lda2 % 4 == 0) && (a.K2 % 4 == 0)));
 }
 
 // column-tile count (1, 2 or 4) of the register-A kernel for this problem, 0 = not eligible
@@ -371,18 +332,9 @@ inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int 
     gy = max(gy, a[i].N / (32 * ct));
   }
   dim3 grid(gx, gy, n), block(kThreads);
-  bool fix = false;
-  for (int i = 0; i < n; ++i) fix = fix || a[i].fix.head != nullptr;
-  if (fix && n != 1) return hipErrorInvalidValue;     // the aggregate fix-up runs alone (node MLP layer 1)
-  if (fix) {
-    if (ct == 4)      hipLaunchKernelGGL((node_gemm_kernel<4, true>), grid, block, 0, s, ga);
-    else if (ct == 2) hipLaunchKernelGGL((node_gemm_kernel<2, true>), grid, block, 0, s, ga);
-    else              hipLaunchKernelGGL((node_gemm_kernel<1, true>), grid, block, 0, s, ga);
-  } else {
-    if (ct == 4)      hipLaunchKernelGGL((node_gemm_kernel<4, false>), grid, block, 0, s, ga);
-    else if (ct == 2) hipLaunchKernelGGL((node_gemm_kernel<2, false>), grid, block, 0, s, ga);
-    else              hipLaunchKernelGGL((node_gemm_kernel<1, false>), grid, block, 0, s, ga);
-  }
+  if (ct == 4)      hipLaunchKernelGGL((node_gemm_kernel<4>), grid, block, 0, s, ga);
+  else if (ct == 2) hipLaunchKernelGGL((node_gemm_kernel<2>), grid, block, 0, s, ga);
+  else              hipLaunchKernelGGL((node_gemm_kernel<1>), grid, block, 0, s, ga);
   return hipGetLastError();
 }
 
@@ -390,7 +342,6 @@ inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int 
 inline hipError_t launch_node_linear(hipStream_t s, const NodeLinearArgs& a) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   const bool vec = vec_ok(a);
-  if (a.fix.head && !vec) return hipErrorInvalidValue;   // the fix-up works on 16-byte row chunks
   // aligned big layers: register-A / LDS-DMA kernel
   if ((long)a.M * a.N >= 64 * 1024 && gemm_ct(a, node_ct_override()) != 0) return launch_node_group(s, &a, 1);
   const int ny = (a.N + 127) / 128;
