@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
         const unsigned long long m = __ballot(pass);
         if (FILL && pass) {
           const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < e_cap) {
+          if (pos >= 0 && pos < e_cap) {   // (pos < 0 only with unsorted masks, which the host rejects)
             erow[pos] = i; ecol[pos] = j; ed0[pos] = d2;
           }
         }
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       if (i == seg_last) {
         const int from = base + cnt, to = (from + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
         const int pos = from + lane;
-        if (pos < to && pos < e_cap) { erow[pos] = -1; ecol[pos] = 0; ed0[pos] = 0.f; }
+        if (pos >= 0 && pos < to && pos < e_cap) { erow[pos] = -1; ecol[pos] = 0; ed0[pos] = 0.f; }
       }
     }
   }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
   for (int base = 0; base < S; base += 1024) {
     const int k = base + t;
     int len = 0;
-    if (k < S) len = (out[seg_end(k)] - out[seg_begin(k)] + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
+    if (k < S) len = (max(out[seg_end(k)] - out[seg_begin(k)], 0) + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
     const int ex = carry + block_scan_1024(len, s_wave, &s_carry);
     if (k < S) seg.seg_base[k] = ex;
     carry += s_carry;

@@ -228,7 +228,7 @@ class EnVariationalDiffusion(nn.Module):
         self._sample_offset = 0
         self._draw = 0
         self._coef_cache = {}
-        self._chain = None          # (edge bound, device flag "masks sorted") of the running chain
+        self._chain = None          # (edge bound,) of the running chain
 
     # ---- noise -----------------------------------------------------------------
     def set_noise_source(self, fn):
@@ -384,9 +384,6 @@ class EnVariationalDiffusion(nn.Module):
 
     # ---- dynamics call ---------------------------------------------------------------
     def _check_status(self, status):
-        if self._chain is not None and not bool(self._chain[1].item()):
-            raise ValueError("batch masks must be sorted ascending with ids in [0, batch): the HIP "
-                             "kernels locate a sample's rows by binary search")
         st = int(status.item())
         if st & _lib.STATUS_EDGE_OVERFLOW:
             raise RuntimeError("edge capacity overflow in the EGNN kernels")
@@ -394,21 +391,14 @@ class EnVariationalDiffusion(nn.Module):
             raise ValueError("NaN detected in EGNN output")
 
     def _begin_chain(self, lig_mask, pocket_mask, batch):
-        """Start of a sampling call: int64 contiguous masks on the device, the edge bound of
-        this batch (one host sync per chain, from the mask CONTENTS) and a device flag
-        'masks are sorted' (the kernels find a sample's rows by binary search) that is
-        read together with the status word at the end of the chain."""
+        """Start of a sampling call: int64 contiguous masks on the device and the edge bound of
+        this batch, from the mask CONTENTS (one host sync per chain, which also rejects unsorted
+        masks before any kernel runs)."""
         from .engine import edge_capacity
         dev = self._hip_device(None)
         lm = lig_mask.to(device=dev, dtype=torch.int64).contiguous()
         pm = pocket_mask.to(device=dev, dtype=torch.int64).contiguous()
-        ok = torch.ones((), dtype=torch.bool, device=dev)
-        for m in (lm, pm):
-            if m.numel() > 1:
-                ok = ok & (m[1:] >= m[:-1]).all()
-            if m.numel():
-                ok = ok & (m[0] >= 0) & (m[-1] < batch)
-        self._chain = (edge_capacity(lm, pm, batch), ok)
+        self._chain = (edge_capacity(lm, pm, batch),)
         return lm, pm
 
     def _dyn(self, z_lig, z_pocket, t_value, lig_mask, pocket_mask, batch, status, want_pocket):

@@ -121,12 +121,25 @@ def pack_weights(sd, cfg, device):
     return slots
 
 
-def edge_capacity(mask_lig, mask_pocket, batch):
+def edge_capacity(mask_lig, mask_pocket, batch, check_sorted=True):
     """Upper bound on the length of the engine's edge list: the complete graph
     inside every sample (dynamics.py:170-172, self loops included), with the edges
     of each (sample, node set) segment rounded up to a multiple of 32 (the engine
     starts every segment at a wave-tile boundary, csrc/graph.h).  One host sync;
-    sampling chains compute it once."""
+    sampling chains compute it once.  The same sync validates the masks: the
+    kernels locate a sample's rows by binary search, so the masks must be sorted
+    ascending with ids in [0, batch) (the reference's scatter ops would accept any
+    order; here it is an error, raised before anything is launched)."""
+    if check_sorted:
+        ok = torch.ones((), dtype=torch.bool, device=mask_lig.device)
+        for m in (mask_lig, mask_pocket):
+            if m.numel() > 1:
+                ok = ok & (m[1:] >= m[:-1]).all()
+            if m.numel():
+                ok = ok & (m[0] >= 0) & (m[-1] < batch)
+        if not bool(ok.item()):
+            raise ValueError("batch masks must be sorted ascending with ids in [0, batch): the HIP kernels "
+                             "locate a sample's rows by binary search")
     nl = torch.bincount(mask_lig, minlength=batch).to(torch.int64)
     np_ = torch.bincount(mask_pocket, minlength=batch).to(torch.int64)
     n = nl + np_
