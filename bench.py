@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the HIP-event timing of the dominant kernel (roofline = null); the engine "
                          "then replays its captured hipGraph instead of launching eagerly")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="concurrent sub-batches per GPU (diffsbdd_amd/streams.py); 0 = automatic: 1 unless the "
+                         "workload is in the latency regime (C-alpha pockets)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -177,6 +180,9 @@ def main():
     n_lig = torch.full((B,), args.n_lig, dtype=torch.int64)
     lo = rank * B                                   # weak scaling: every rank owns B global samples
     eng = model.dynamics.engine()
+    from diffsbdd_amd.streams import StreamReplicas, auto_streams
+    n_streams = args.streams or (1 if joint else auto_streams(B * args.n_lig + pocket0["x"].shape[0], B))
+    replicas = StreamReplicas(model, n_streams) if (n_streams > 1 and not joint) else None
 
     def chain(seed):
         model.seed(seed, sample_offset=lo)
@@ -189,6 +195,9 @@ def main():
             out_l, out_p, lm, pm = model.inpaint(ligand, pocket, torch.zeros(B * args.n_lig, device=device),
                                                  torch.ones(pocket["x"].shape[0], device=device),
                                                  resamplings=2, jump_length=1, timesteps=T)
+        elif replicas is not None:
+            out_l, out_p, lm, pm = replicas.sample_given_pocket(pocket, n_lig, timesteps=T, seed=seed,
+                                                                sample_offset=lo)
         else:
             out_l, out_p, lm, pm = model.sample_given_pocket(pocket, n_lig, timesteps=T)
         return sharding.gather_ligands(out_l, lm, lo)
@@ -225,14 +234,22 @@ def main():
 
     if rank == 0:
         N = B * args.n_lig + pocket0["x"].shape[0]
-        E = eng.edge_count(N)
+        if replicas is None:
+            E = E_timed = eng.edge_count(N)
+        else:   # the timed engine (replica 0) runs the first sub-batch only
+            per = (B + n_streams - 1) // n_streams
+            subs = [min(per, B - i * per) for i in range(n_streams) if B - i * per > 0]
+            n_sub = [b * (args.n_lig + pocket0["x"].shape[0] // B) for b in subs]
+            counts = [r.dynamics.engine().edge_count(n) for r, n in zip(replicas.replicas, n_sub)]
+            E, E_timed = sum(counts), counts[0]
         H = cfg["hidden_nf"]
         A = 2 + (cfg.get("edge_embedding_dim") or 0)
-        flops_per_launch = 2.0 * E * (H * H + (A + 2) * H)
+        flops_per_launch = 2.0 * E_timed * (H * H + (A + 2) * H)
         avg_ms = kern_ms / max(kern_n, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if kern_n else None
         # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
-        bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E + 3 * N + N * H)
+        N_timed = N if replicas is None else n_sub[0]
+        bytes_per_launch = 4.0 * (N_timed * 2 * H + H * H + 3 * E_timed + 3 * N_timed + N_timed * H)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if args.workload == "crossdock_fullatom_cond" and B == 64 and os.path.isfile(tpath):
@@ -245,7 +262,7 @@ def main():
             "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-            "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E,
+            "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E_timed,
             "algorithmic_flops_per_launch": flops_per_launch,
             "kernel_share_of_wall": (kern_ms * 1e-3 / elapsed) * (args.steps * n_calls * cfg["n_layers"]
                                                                  * cfg["inv_sublayers"] / max(kern_n, 1)),
@@ -267,6 +284,7 @@ def main():
                                    f" + final decode = {n_calls} EGNN calls per chain",
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
+                       "streams_per_gpu": n_streams,
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,

@@ -1,0 +1,203 @@
+"""TEST INFRASTRUCTURE ONLY -- import the reference's *callers* of the hot path
+(/root/reference/lightning_modules.py: `LigandPocketDDPM`) unchanged, while
+`equivariant_diffusion` resolves to THIS repository's drop-in package.
+
+Purpose ("called unchanged by lightning_modules.py"): prove the
+boundary against the real caller -- constructor keyword arguments
+(lightning_modules.py:137-173), `state_dict` keys under Lightning's `ddpm.`
+prefix, the exact `type(self.ddpm) == ...` dispatch (:814,837), the argument
+types `generate_ligands` hands to the samplers (:797-852) and the reference's own
+pocket selection / featurisation code (utils.py:103-128,
+lightning_modules.py:714-752).
+
+Third-party modules that are absent from this image get stand-ins here
+(pytorch_lightning, wandb, torch_scatter, rdkit, Bio, openbabel, imageio); so
+do the three reference modules that only wrap those libraries
+(analysis.metrics / docking / visualization).  `constants.py`, `utils.py`,
+`dataset.py` and `lightning_modules.py` are the reference's own files, imported
+from /root/reference (nothing is copied).  /root/reference does not exist on the
+GPU box: only CPU tests that skip without it may import this module.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import ref_shim
+
+REF_ROOT = ref_shim.REF_ROOT
+HERE_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- a minimal Bio.PDB structure model on top of diffsbdd_amd.pocket's reader -------------------
+class _Atom:
+    def __init__(self, name, element, xyz):
+        self.name, self.element, self._xyz = name, element.upper(), np.asarray(xyz, dtype=np.float32)
+
+    def get_coord(self):
+        return self._xyz
+
+
+class _Residue:
+    def __init__(self, rec):
+        self.id = ("H_" + rec["resname"] if rec.get("hetero") else " ", rec["resseq"], rec["icode"])
+        self.resname = rec["resname"]
+        self.atoms = [_Atom(*a) for a in rec["atoms"]]
+
+    def get_atoms(self):
+        return iter(self.atoms)
+
+    def get_resname(self):
+        return self.resname
+
+    def __getitem__(self, name):
+        for a in self.atoms:
+            if a.name == name:
+                return a
+        raise KeyError(name)
+
+
+class _Chain:
+    def __init__(self):
+        self.residues = []
+
+    def get_residues(self):
+        return iter(self.residues)
+
+    def __getitem__(self, key):
+        for r in self.residues:
+            if r.id == key:
+                return r
+        raise KeyError(key)
+
+
+class _Model:
+    def __init__(self, records):
+        self.chains = {}
+        for rec in records:
+            self.chains.setdefault(rec["chain"], _Chain()).residues.append(_Residue(rec))
+
+    def __getitem__(self, chain):
+        return self.chains[chain]
+
+    def get_residues(self):
+        for c in self.chains.values():
+            yield from c.residues
+
+
+class _PDBParser:
+    def __init__(self, QUIET=True):
+        pass
+
+    def get_structure(self, name, path):
+        from diffsbdd_amd.pocket import read_pdb_residues
+        return [_Model(read_pdb_residues(str(path), hetero=True))]
+
+
+class _SDMol:
+    def __init__(self, path):
+        from diffsbdd_amd.pocket import read_sdf_coords
+        self._xyz = read_sdf_coords(path).astype(np.float64)
+
+    def GetConformer(self):
+        return self
+
+    def GetPositions(self):
+        return self._xyz
+
+
+_AA3 = ("ALA CYS ASP GLU PHE GLY HIS ILE LYS LEU MET ASN PRO GLN ARG SER THR VAL TRP TYR").split()
+_AA1 = "ACDEFGHIKLMNPQRSTVWY"
+
+
+def _install_caller_stubs():
+    ref_shim._install_stubs()
+    chem = sys.modules["rdkit.Chem"]
+    chem.SDMolSupplier = lambda path, *a, **k: [_SDMol(path)]
+    if not hasattr(chem, "rdchem"):    # constants.py:71 reads the bond-type enum at import time
+        chem.rdchem = types.SimpleNamespace(BondType=types.SimpleNamespace(SINGLE=1, DOUBLE=2, TRIPLE=3,
+                                                                           AROMATIC=12))
+    pdb = sys.modules["Bio.PDB"]
+    pdb.PDBParser = _PDBParser
+    poly = sys.modules["Bio.PDB.Polypeptide"]
+    poly.three_to_one = lambda x: _AA1[_AA3.index(x)]
+    poly.is_aa = lambda name, standard=False: name in _AA3
+
+    class LightningModule(torch.nn.Module):
+        """pytorch_lightning.LightningModule: only what LigandPocketDDPM touches outside training."""
+
+        def __init__(self):
+            super().__init__()
+            self.current_epoch = 0
+
+        def save_hyperparameters(self):
+            import inspect
+            frame = inspect.currentframe().f_back
+            args = {k: v for k, v in frame.f_locals.items() if k not in ("self", "__class__")}
+            self.hparams = types.SimpleNamespace(**args)
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+        def log(self, *a, **k):
+            pass
+
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    sys.modules.setdefault("openbabel", types.ModuleType("openbabel"))
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    # reference modules that only wrap RDKit / OpenBabel / matplotlib / smina
+    mod("analysis")
+    mod("analysis.visualization", save_xyz_file=lambda *a, **k: None, visualize=lambda *a, **k: None,
+        visualize_chain=lambda *a, **k: None)
+    mod("analysis.metrics", BasicMolecularMetrics=_Dummy, CategoricalDistribution=_Dummy,
+        MoleculeProperties=_Dummy)
+    mod("analysis.docking", smina_score=lambda *a, **k: None)
+    # molecule building needs RDKit/OpenBabel: the test observes what it is handed
+    mod("analysis.molecule_builder",
+        build_molecule=lambda pos, types_, info, add_coords=False: (pos, types_),
+        process_molecule=lambda mol, **k: mol)
+
+
+def import_lightning_modules():
+    """-> the reference's `lightning_modules` module, bound to this repo's
+    `equivariant_diffusion` package."""
+    if not ref_shim.reference_available():
+        raise RuntimeError(f"reference not found under {REF_ROOT}")
+    sys.dont_write_bytecode = True
+    _install_caller_stubs()
+    for name in [n for n in sys.modules if n == "equivariant_diffusion" or n.startswith("equivariant_diffusion.")
+                 or n in ("utils", "constants", "dataset", "lightning_modules")]:
+        del sys.modules[name]
+    # this repo first (the drop-in package), then the reference (constants, utils, dataset, lightning_modules)
+    saved = list(sys.path)
+    sys.path[:] = [HERE_ROOT, REF_ROOT] + [p for p in saved if p not in (HERE_ROOT, REF_ROOT)]
+    try:
+        lm = importlib.import_module("lightning_modules")
+        pkg = sys.modules["equivariant_diffusion"]
+        assert os.path.dirname(os.path.abspath(pkg.__file__)).startswith(HERE_ROOT), pkg.__file__
+    finally:
+        sys.path[:] = saved
+        for name in ("utils", "constants", "dataset", "lightning_modules", "analysis", "analysis.visualization",
+                     "analysis.metrics", "analysis.docking", "analysis.molecule_builder"):
+            if name in sys.modules:
+                sys.modules["_refcaller_" + name] = sys.modules.pop(name)
+    return lm
