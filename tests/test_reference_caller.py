@@ -124,7 +124,7 @@ def test_reference_generate_ligands_drives_the_drop_in_sampler(lm, name, monkeyp
         monkeypatch.setattr(model.ddpm, "sample_given_pocket", rec_sample_given_pocket, raising=True)
     monkeypatch.setattr(model.ddpm, "inpaint", rec_inpaint, raising=True)
     kwargs = dict(resamplings=2, jump_length=1) if CASES[name][0] == "joint" else {}
-    mols = model.generate_ligands(pdb, 3, ref_ligand=sdf, timesteps=50, **kwargs)
+    mols = model.generate_ligands(pdb, 3, ref_ligand=sdf, timesteps=50, n_nodes_min=1, **kwargs)
     assert len(mols) == 3
     assert seen["kind"] == ("inpaint" if CASES[name][0] == "joint" else "sample_given_pocket")
     p = seen["pocket"]
