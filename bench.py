@@ -150,8 +150,8 @@ def main():
                     help="skip the HIP-event timing of the dominant kernel (roofline = null); the engine "
                          "then replays its captured hipGraph instead of launching eagerly")
     ap.add_argument("--streams", type=int, default=0,
-                    help="concurrent sub-batches per GPU (diffsbdd_amd/streams.py); 0 = automatic: 1 unless the "
-                         "workload is in the latency regime (C-alpha pockets)")
+                    help="concurrent sub-batches per GPU (diffsbdd_amd/streams.py); 0 = the default (1: splitting "
+                         "was measured slower, host-bound graph submission)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")

@@ -188,7 +188,9 @@ class HipEngine:
         nbytes = self.lib.dsbdd_engine_workspace_bytes(self.handle, *caps)
         if nbytes == 0:
             raise _lib.HipLibraryError("dsbdd_engine_workspace_bytes rejected the sizes %r" % (caps,))
-        torch.cuda.synchronize(self.device)   # the old workspace may still be in use
+        # the old workspace may still be in use by calls enqueued on this stream (a device-wide
+        # synchronize is not allowed while another thread captures a graph: streams.py)
+        torch.cuda.current_stream(self.device).synchronize()
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         base = (self.workspace.data_ptr() + 255) & ~255
         _lib.check(self.lib.dsbdd_engine_bind_workspace(self.handle, base, nbytes, *caps),

@@ -1,4 +1,4 @@
-"""Intra-GPU replicas: one sampling batch as several concurrent sub-batches.
+"""Intra-GPU replicas: one sampling batch as several concurrent sub-batches (opt-in).
 
 A launch needs far more than 256 workgroups to fill an MI355X (256 CUs in 8 XCDs).
 The C-alpha workloads (BASELINE.json configs[1]: 32 pockets, ~20 k edges per EGNN
@@ -6,12 +6,18 @@ call = 157 edge tiles) cannot do that: every launch of a call is one tile's late
 long and most CUs idle.  Because samples are independent chains and every per-sample
 result of the HIP path is bitwise independent of the batch composition (aligned edge
 segments + fixed summation order, csrc/edge_mlp.h; noise keyed by the global sample
-index), a batch can be cut into S contiguous sub-batches that run *concurrently* on
-S HIP streams -- each with its own engine (workspace, captured graph) but the same
-parameter tensors -- and the concatenated result is identical, bit for bit, to the
-single-batch run.  The latency-bound launches of the S chains overlap on the idle
-CUs; there is no data-path communication, exactly like the multi-GPU sharding of
-`sharding.py` one level up.
+index), a batch can be cut into S contiguous sub-batches that run on S HIP streams
+-- each with its own engine (workspace, captured graph) but the same parameter
+tensors -- and the concatenated result is identical, bit for bit, to the single-batch
+run (tests/test_gpu_parity.py::test_stream_replicas_equal_single_batch_bitwise).
+
+MEASURED (profiles/README.md, round 2): it does NOT pay inside one process.  A
+sub-batch call is as long as the full-batch call (latency-bound), and replaying the
+~70-node captured graph costs ~0.57 ms of host time per call under the runtime's
+process-wide submission lock, so S streams become host-bound: 48.8 / 42.1 / 23.9 /
+13.9 ligands/s for S = 1 / 2 / 4 / 8 on the C-alpha workload.  The facility stays
+opt-in (`bench.py --streams S`); what the latency regime needs is fewer, larger
+launches per call, not more submitters.
 
 The reference has nothing comparable (one batch, one stream:
 /root/reference/lightning_modules.py:797-852).
@@ -27,11 +33,9 @@ __all__ = ["StreamReplicas", "auto_streams"]
 
 
 def auto_streams(n_nodes_total: int, batch: int, max_streams: int = 4) -> int:
-    """Heuristic: split only in the latency regime (a few thousand nodes per call).  Large
-    batches already fill the chip and were measured slower when split (profiles/README.md)."""
-    if n_nodes_total >= 8192 or batch < 2:
-        return 1
-    return max(1, min(max_streams, batch // 4 if batch >= 8 else batch))
+    """Number of concurrent sub-batches to use by default: 1 (see the module docstring: splitting
+    was measured slower for small and for large batches)."""
+    return 1
 
 
 def _replica(ddpm):

@@ -658,4 +658,4 @@ def test_stream_replicas_equal_single_batch_bitwise():
                                       sample_offset=3)
         for a, b in zip(out, ref):
             assert torch.equal(a, b), S
-    assert auto_streams(32 * 59, 32) == 4 and auto_streams(64 * 309, 64) == 1
+    assert auto_streams(32 * 59, 32) == 1 and auto_streams(64 * 309, 64) == 1    # opt-in only (measured slower)
