@@ -406,14 +406,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 // out[i][c] ~ N(0,1), a pure function of (seed, draw_index, stream_id, global
 // sample id, row within sample, column).
 __global__ void randn_keyed_kernel(float* out, const int64_t* mask, int n_rows, int n_cols,
-                                   int64_t sample_offset, uint64_t seed, uint64_t draw_index,
-                                   uint32_t stream_id) {
+                                   int64_t sample_offset, const int64_t* sample_ids, uint64_t seed,
+                                   uint64_t draw_index, uint32_t stream_id) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rows * n_cols) return;
   const int i = idx / n_cols, c = idx % n_cols;
   const int64_t b = mask[i];
   const int first = lower_bound_i64(mask, n_rows, b);
-  const uint64_t gs = (uint64_t)(b + sample_offset);
+  // global sample id: an explicit table (batches packed from several pockets) or offset + local id
+  const uint64_t gs = (uint64_t)(sample_ids ? sample_ids[b] : b + sample_offset);
   uint32_t ctr[4] = {(uint32_t)gs, (uint32_t)((i - first) * n_cols + c), (uint32_t)draw_index,
                      (uint32_t)(draw_index >> 32) ^ (stream_id * 0x9E3779B1u) ^ (uint32_t)(gs >> 32)};
   philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));

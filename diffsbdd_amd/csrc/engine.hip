@@ -790,15 +790,15 @@ int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, floa
 }
 
 int dsbdd_randn_keyed(void* stream, float* out, const int64_t* mask, int64_t n_rows, int32_t n_cols,
-                      int64_t batch, int64_t sample_offset, uint64_t seed, uint64_t draw_index,
-                      uint32_t stream_id) {
+                      int64_t batch, int64_t sample_offset, const int64_t* sample_ids, uint64_t seed,
+                      uint64_t draw_index, uint32_t stream_id) {
   (void)batch;
   if (!out || !mask || n_rows < 0 || n_cols < 1) return fail(DSBDD_ERR_ARG, "bad argument");
   const int64_t n = n_rows * n_cols;
   if (n == 0) return DSBDD_OK;
   hipLaunchKernelGGL(randn_keyed_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), out, mask, (int)n_rows, (int)n_cols, sample_offset, seed,
-                     draw_index, stream_id);
+                     static_cast<hipStream_t>(stream), out, mask, (int)n_rows, (int)n_cols, sample_offset,
+                     sample_ids, seed, draw_index, stream_id);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }

@@ -226,6 +226,7 @@ class EnVariationalDiffusion(nn.Module):
         self.noise_source = None
         self._seed = None           # None: taken from torch's global RNG at the first draw
         self._sample_offset = 0
+        self._sample_ids = None
         self._draw = 0
         self._coef_cache = {}
         self._chain = None          # (edge bound,) of the running chain
@@ -234,13 +235,16 @@ class EnVariationalDiffusion(nn.Module):
     def set_noise_source(self, fn):
         self.noise_source = fn
 
-    def seed(self, seed, sample_offset=0):
+    def seed(self, seed, sample_offset=0, sample_ids=None):
         """Seed the keyed generator.  `sample_offset` = global index of this
-        shard's first sample, so a chain's noise is independent of sharding.
+        shard's first sample, so a chain's noise is independent of sharding;
+        `sample_ids` (int64 [batch]) gives every sample of the batch an explicit
+        global id instead (batches packed from several pockets, testset.py).
         Without a call to seed() the key is drawn from torch's global generator at
         the first use, so `torch.manual_seed` controls the samples and unseeded
         processes differ (the reference draws from the global generator too)."""
         self._seed, self._sample_offset, self._draw = int(seed), int(sample_offset), 0
+        self._sample_ids = None if sample_ids is None else torch.as_tensor(sample_ids, dtype=torch.int64)
 
     def _randn(self, mask, n_cols, batch, stream_id=0):
         n = mask.numel()
@@ -249,11 +253,17 @@ class EnVariationalDiffusion(nn.Module):
         out = torch.empty((n, n_cols), dtype=torch.float32, device=mask.device)
         if self._seed is None:
             self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ids = getattr(self, "_sample_ids", None)
+        if ids is not None:
+            if ids.numel() != batch:
+                raise ValueError(f"seed(sample_ids=...) has {ids.numel()} entries for a batch of {batch}")
+            if ids.device != mask.device:
+                ids = self._sample_ids = ids.to(mask.device).contiguous()
         lib = _lib.load()
         _lib.check(lib.dsbdd_randn_keyed(
             torch.cuda.current_stream(mask.device).cuda_stream, out.data_ptr(), mask.data_ptr(), n,
-            n_cols, batch, self._sample_offset, C.c_uint64(self._seed & (2 ** 64 - 1)),
-            C.c_uint64(self._draw), stream_id), "dsbdd_randn_keyed")
+            n_cols, batch, self._sample_offset, ids.data_ptr() if ids is not None else None,
+            C.c_uint64(self._seed & (2 ** 64 - 1)), C.c_uint64(self._draw), stream_id), "dsbdd_randn_keyed")
         self._draw += 1
         return out
 

@@ -189,7 +189,7 @@ class LigandGenerator:
                           n_nodes_bias=0, n_nodes_min=0, **kwargs):
         """The tensor part of generate_ligands (lightning_modules.py:797-852):
         returns (xh_lig in the pocket's original frame, lig_mask)."""
-        pocket_com_before = seg_mean(pocket["x"], pocket["mask"], n_samples)
+        pocket_com_before = self.ddpm._seg_mean3(pocket["x"].float(), pocket["mask"], n_samples)
         if num_nodes_lig is None:
             num_nodes_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket["size"])
         num_nodes_lig = torch.as_tensor(num_nodes_lig, dtype=torch.int64)
@@ -208,7 +208,7 @@ class LigandGenerator:
                 pocket, num_nodes_lig, timesteps=timesteps)
         else:
             raise NotImplementedError
-        pocket_com_after = seg_mean(xh_pocket[:, :self.x_dims], pocket_mask, n_samples)
+        pocket_com_after = self.ddpm._seg_mean3(xh_pocket[:, :self.x_dims], pocket_mask, n_samples)
         shift = pocket_com_before - pocket_com_after
         xh_lig = xh_lig.clone()
         xh_lig[:, :self.x_dims] += shift[lig_mask]
@@ -218,16 +218,16 @@ class LigandGenerator:
     # -- several different pockets in one batch ---------------------------
     @torch.no_grad()
     def generate_for_pockets(self, jobs, timesteps=None, largest_frag=False, n_nodes_bias=0,
-                             n_nodes_min=0, **kwargs):
+                             n_nodes_min=0, seed=None, sample_ids=None, **kwargs):
         """One sampling batch over several different pockets.
 
         The reference's test driver (test.py:59-176) samples one pocket at a time; the
         graph is block diagonal per sample (dynamics.py:170-172), so pockets of different
         proteins can share a batch and keep the GPU full when a single pocket needs fewer
         samples than fit.  `jobs`: list of (residues, n_samples, num_nodes_lig or None).
-        Returns one list of molecules per job.  With keyed noise (`ddpm.seed`) sample g of
-        the packed batch equals sample g of any other packing that gives it the same
-        global index."""
+        Returns one list of molecules per job.  With keyed noise (`seed`, and `sample_ids` = one
+        global id per slot of the packed batch) a sample is the same molecule in any packing that
+        gives it the same global id."""
         parts, sizes, counts = [], [], []
         base = 0
         for residues, n, n_lig in jobs:
@@ -242,6 +242,8 @@ class LigandGenerator:
             counts.append(n)
             base += n
         pocket = {k: torch.cat([p[k] for p in parts]) for k in ("x", "one_hot", "size", "mask")}
+        if seed is not None:
+            self.ddpm.seed(seed, sample_ids=sample_ids)
         xh_lig, lig_mask = self.sample_for_pocket(pocket, base, torch.cat(sizes), timesteps,
                                                   n_nodes_bias, n_nodes_min, **kwargs)
         mols = build_molecules(xh_lig[:, :self.x_dims], xh_lig[:, self.x_dims:].argmax(1), lig_mask,

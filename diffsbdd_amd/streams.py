@@ -84,7 +84,7 @@ class StreamReplicas:
                     self.streams[i].wait_event(ready)              # inputs were produced on the caller's stream
                     rep = self.replicas[i]
                     rep.noise_source = self.ddpm.noise_source
-                    rep.seed(seed, sample_offset=sample_offset + lo)
+                    rep.seed(seed, sample_offset=sample_offset + lo)   # (explicit id tables are not split here)
                     rep._draw = draw0
                     out[i] = getattr(rep, fn_name)(*args, **kwargs)
             except BaseException as exc:   # re-raised in the caller's thread

@@ -250,15 +250,16 @@ int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, floa
                                int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
                                float alpha_ts, float sigma_ts, int32_t jump);
 
-/* Counter-based Gaussian noise, keyed by (seed, global sample id, row within
- * the sample, column, draw index) so that a chain's noise does not depend on
- * how samples are sharded over GPUs.  out [n_rows][n_cols];
- * sample id of row i = mask[i] + sample_offset.  center_x != 0 additionally
- * removes the per-sample mean of the first 3 columns over (mask, mask2 rows)
- * -- not applied here; see dsbdd_remove_mean. */
+/* Counter-based Gaussian noise (Philox4x32-10 + Box-Muller), a pure function of
+ * (seed, global sample id, row within the sample, column, draw index, stream id), so
+ * that a chain's noise does not depend on how samples are sharded over GPUs or packed
+ * into batches.  out [n_rows][n_cols]; global sample id of row i =
+ * sample_ids[mask[i]] when sample_ids != NULL (int64 [batch], device), else
+ * mask[i] + sample_offset. */
 int dsbdd_randn_keyed(void* stream, float* out, const int64_t* mask, int64_t n_rows,
-                      int32_t n_cols, int64_t batch, int64_t sample_offset, uint64_t seed,
-                      uint64_t draw_index, uint32_t stream_id);
+                      int32_t n_cols, int64_t batch, int64_t sample_offset,
+                      const int64_t* sample_ids, uint64_t seed, uint64_t draw_index,
+                      uint32_t stream_id);
 
 /* ---- individual kernels (unit tests, building blocks) --------------------*/
 /* C[M][N] = act([A1 | A2] @ WT + bias) (+ R);  WT is [K1+K2][ldw]. act: 0 none, 1 SiLU */

@@ -439,7 +439,7 @@ def test_keyed_noise_statistics_and_sharding():
     B, n = 16, 40
     mask = torch.repeat_interleave(torch.arange(B), n).to(d)
     out = torch.empty(B * n, 13, device=d)
-    _lib.check(lib.dsbdd_randn_keyed(None, out.data_ptr(), mask.data_ptr(), B * n, 13, B, 0,
+    _lib.check(lib.dsbdd_randn_keyed(None, out.data_ptr(), mask.data_ptr(), B * n, 13, B, 0, None,
                                      C.c_uint64(7), C.c_uint64(3), 0))
     torch.cuda.synchronize()
     assert abs(out.mean().item()) < 0.05 and abs(out.std().item() - 1.0) < 0.05
@@ -447,15 +447,23 @@ def test_keyed_noise_statistics_and_sharding():
     # second shard of 8 samples with offset 8 == rows of the full draw
     mask2 = torch.repeat_interleave(torch.arange(8), n).to(d)
     out2 = torch.empty(8 * n, 13, device=d)
-    _lib.check(lib.dsbdd_randn_keyed(None, out2.data_ptr(), mask2.data_ptr(), 8 * n, 13, 8, 8,
+    _lib.check(lib.dsbdd_randn_keyed(None, out2.data_ptr(), mask2.data_ptr(), 8 * n, 13, 8, 8, None,
                                      C.c_uint64(7), C.c_uint64(3), 0))
     torch.cuda.synchronize()
     assert torch.equal(out2, out[8 * n:])
     # a different draw index gives different numbers
-    _lib.check(lib.dsbdd_randn_keyed(None, out2.data_ptr(), mask2.data_ptr(), 8 * n, 13, 8, 8,
+    _lib.check(lib.dsbdd_randn_keyed(None, out2.data_ptr(), mask2.data_ptr(), 8 * n, 13, 8, 8, None,
                                      C.c_uint64(7), C.c_uint64(4), 0))
     torch.cuda.synchronize()
     assert not torch.equal(out2, out[8 * n:])
+    # explicit global ids: samples 15, 3, 8 of the full draw, packed in that order
+    ids = torch.tensor([15, 3, 8], device=d)
+    mask3 = torch.repeat_interleave(torch.arange(3), n).to(d)
+    out3 = torch.empty(3 * n, 13, device=d)
+    _lib.check(lib.dsbdd_randn_keyed(None, out3.data_ptr(), mask3.data_ptr(), 3 * n, 13, 3, 0, ids.data_ptr(),
+                                     C.c_uint64(7), C.c_uint64(3), 0))
+    torch.cuda.synchronize()
+    assert torch.equal(out3, torch.cat([out[15 * n:16 * n], out[3 * n:4 * n], out[8 * n:9 * n]]))
 
 
 def test_bench_two_ranks_sharing_the_gpu():

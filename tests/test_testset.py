@@ -1,0 +1,112 @@
+"""Test-set driver (/root/reference/test.py:59-176): the slot scheduler on the CPU with
+a stand-in sampler, and the real packed sampling on the GPU (packing independence, bitwise)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diffsbdd_amd import testset as ts
+
+
+def fake_jobs(sizes, n_samples):
+    return ts.number_jobs([ts.PocketJob(f"p{i}", [], n, n_samples) for i, n in enumerate(sizes)])
+
+
+def test_scheduler_fills_slots_refills_deficits_and_accounts_time():
+    """Slots of a batch are shared by pockets of similar size; molecules rejected by the filter come
+    back as a deficit that is refilled next to new pockets; time is split by slots."""
+    jobs = fake_jobs([300, 36, 280, 40, 310, 290, 35], n_samples=10)
+    calls = []
+    tick = iter(range(1000))
+
+    def sample_batch(plan, batch_no):
+        calls.append([(job.name, n) for job, n in plan])
+        # deterministic "molecules": (job index, running sample number); every 4th one is invalid
+        return [[(job.index, job.n_generated + k) for k in range(n)] for job, n in plan]
+
+    drv = ts.TestSetDriver(sample_batch, batch_size=16, is_valid=lambda m: m[1] % 4 != 3,
+                           clock=lambda: float(next(tick)))
+    done = drv.run(jobs)
+    assert all(len(j.valid) == 10 for j in done)
+    assert all(sum(n for _, n in c) <= 16 for c in calls)
+    assert all(sum(n for _, n in c) == 16 for c in calls[:-1])        # full batches (tail slots are handed out as spares)
+    # pockets of similar size share batches: the small pockets (35 / 36 / 40 nodes) come first, together
+    assert [n for n, _ in calls[0]] == ["p6", "p1"] and [n for n, _ in calls[1]] == ["p6", "p1", "p3"]
+    # a molecule is never sampled twice and never lost
+    for j in done:
+        assert [m[1] for m in j.raw] == list(range(j.n_generated))
+        assert j.valid == [m for m in j.raw if m[1] % 4 != 3][:10]
+    # fewer chains than pocket-at-a-time sampling (the reference: ceil-rounds per pocket, one batch each)
+    assert len(calls) < len(jobs)
+    # every batch took 1 tick; the per-pocket times add up to the total
+    assert abs(sum(j.seconds for j in done) - len(calls)) < 1e-9
+
+
+def test_scheduler_gives_up_like_the_reference():
+    jobs = fake_jobs([50], n_samples=4)
+    drv = ts.TestSetDriver(lambda plan, b: [[None] * n for _, n in plan], batch_size=8, max_rounds=3)
+    with pytest.raises(RuntimeError, match="maximum number of iterations"):
+        drv.run(jobs)
+
+
+def test_rank_partition_balances_cost_and_outputs_follow_the_reference_layout(tmp_path):
+    jobs = fake_jobs([300, 36, 280, 40, 310, 290, 35, 305, 295], n_samples=10)
+    parts = ts.assign_to_ranks(jobs, 2)
+    assert sorted(j.name for p in parts for j in p) == sorted(j.name for j in jobs)
+    cost = [sum(j.n_samples * (j.n_nodes + 30) ** 2 for j in p) for p in parts]
+    assert max(cost) / min(cost) < 1.25
+    assert [j.index for j in jobs] == list(range(9))                   # global ids survive the partition
+    drv = ts.TestSetDriver(lambda plan, b: [[f"{job.name}:{job.n_generated + k}" for k in range(n)]
+                                            for job, n in plan], batch_size=16)
+    done = drv.run(parts[0])
+    written = {}
+    ts.TestSetDriver.write_outputs(done, str(tmp_path), lambda path, mols: written.__setitem__(path, list(mols)))
+    for j in done:
+        assert len(written[os.path.join(str(tmp_path), "processed", f"{j.name}_gen.sdf")]) == 10
+        assert os.path.isfile(tmp_path / "pocket_times" / f"{j.name}.txt")
+    lines = (tmp_path / "pocket_times.txt").read_text().splitlines()
+    assert [l.split()[0] for l in lines] == [j.name for j in done]
+
+
+@pytest.mark.gpu
+def test_packed_sampling_is_independent_of_the_packing():
+    """Two pockets (3rfm, 5ndu; C-alpha model), 6 molecules each, 4 reverse steps: the molecules of a
+    pocket are identical -- coordinates bit for bit -- whether the driver packs 12, 7 or 4 slots per
+    batch, because noise and ligand sizes are keyed by the global sample id."""
+    from oracle import weights as W
+    from diffsbdd_amd import pocket as pk
+    from diffsbdd_amd.generate import LigandGenerator
+    from tests._golden import GOLDEN_DIR
+    cfg, dd = W.arch_cfg("crossdock_ca_cond")
+    egnn = dict(joint_nf=cfg["joint_nf"], hidden_nf=cfg["hidden_nf"], n_layers=cfg["n_layers"], attention=True,
+                tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False, normalization_factor=100,
+                aggregation_method="sum", edge_cutoff_ligand=None, edge_cutoff_pocket=5.0,
+                edge_cutoff_interaction=5.0, reflection_equivariant=False, edge_embedding_dim=None)
+    diff = dict(diffusion_steps=500, diffusion_noise_schedule="polynomial_2", diffusion_noise_precision=5e-4,
+                diffusion_loss_type="l2", normalize_factors=[1, 1])
+    gen = LigandGenerator("crossdock", egnn, diff, "pocket_conditioning", np.ones((40, 400)), "CA", device="cuda:0")
+    gen.ddpm.dynamics.load_state_dict(W.random_state_dict(cfg, 0))
+    residues = {}
+    for name in ("3rfm", "5ndu"):
+        z = np.load(os.path.join(GOLDEN_DIR, f"pocket_{name}.npz"))
+        # rebuild residue records from the fixture: one CA atom per residue
+        inv = {v: k for k, v in pk.AA_ENCODER.items()}
+        one_to_three = {v: k for k, v in pk.AA3_TO_1.items()}
+        residues[name] = [dict(chain="A", resseq=i, icode=" ", resname=one_to_three[inv[int(t)]],
+                               atoms=[("CA", "C", tuple(map(float, xyz)))], hetero=False)
+                          for i, (xyz, t) in enumerate(zip(z["ca_x"], z["ca_types"]))]
+
+    def run(batch_size):
+        jobs = ts.number_jobs([ts.PocketJob(n, residues[n], len(residues[n]), 6) for n in ("3rfm", "5ndu")])
+        drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=4, seed=5, largest_frag=False), batch_size)
+        return {j.name: j.valid for j in drv.run(jobs)}, len(drv.batches)
+
+    a, na = run(12)
+    b, nb = run(7)
+    c, nc = run(4)
+    assert (na, nb, nc) == (1, 2, 3)
+    for name in a:
+        for x, y, z_ in zip(a[name], b[name], c[name]):
+            assert x.symbols == y.symbols == z_.symbols
+            assert np.array_equal(x.positions, y.positions) and np.array_equal(x.positions, z_.positions)
