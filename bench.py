@@ -251,12 +251,12 @@ def main():
         N_timed = N if replicas is None else n_sub[0]
         bytes_per_launch = 4.0 * (N_timed * 2 * H + H * H + 3 * E_timed + 3 * N_timed + N_timed * H)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
         if args.workload == "crossdock_fullatom_cond" and B == 64 and os.path.isfile(tpath):
             # PMC counters cannot be read from inside this process; the figure is the one measured
             # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r2_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
         roofline = {
             "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
             "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
