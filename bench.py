@@ -91,6 +91,7 @@ def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
     sd = synthetic.random_state_dict(cfg, seed=0)
     m = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
                        dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
+    m.exact_dist = False      # torch.cdist for the radius graph, as the reference does (dynamics.py:174-181)
     pocket = load_pocket(key, b_cpu, "cpu")
     _, pocket = do.normalize(m, None, pocket)
     xh_pocket = torch.cat([pocket["x"], pocket["one_hot"]], 1)

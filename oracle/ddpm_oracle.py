@@ -133,6 +133,7 @@ class OracleModel:
         self.simple = simple  # SimpleConditionalDDPM: conditional_model.py:702-746
         self.n_dynamics_calls = 0
         self.edge_hook = None  # optional: fn(call_index) -> edges to teacher-force
+        self.exact_dist = True  # False: torch.cdist like the reference (dynamics.py:174-181)
 
     def g(self, t):
         return gamma_at(self.gamma, t, self.T)
@@ -141,7 +142,7 @@ class OracleModel:
         edges = self.edge_hook(self.n_dynamics_calls) if self.edge_hook else None
         self.n_dynamics_calls += 1
         e_l, e_p, _ = eo.dynamics_forward(self.sd, self.cfg, z_lig, z_pocket, t,
-                                          lig_mask, pocket_mask, edges=edges)
+                                          lig_mask, pocket_mask, edges=edges, exact_dist=self.exact_dist)
         return e_l, e_p
 
 
