@@ -291,11 +291,80 @@ class ConditionalDDPM(EnVariationalDiffusion):
             self.assert_mean_zero_with_mask(x_lig, lm)
         return torch.cat([x_lig, h_lig], dim=1), torch.cat([x_pocket, h_pocket], dim=1), lm, pm
 
-    # ---- training-only API: out of scope ----------------------------------------------------------------
+    # ---- loss terms (conditional_model.py:36-110, 202-330); see EnVariationalDiffusion.forward ---------------
+    def kl_prior(self, xh_lig, mask_lig, num_nodes):
+        """KL(q(z_T | x) || N(0, 1)) over the ligand, conditional_model.py:36-74."""
+        nd = self.n_dims
+        ones = torch.ones((len(num_nodes), 1), device=xh_lig.device)
+        gamma_T = self.gamma(ones)
+        mu = self.alpha(gamma_T, xh_lig)[mask_lig] * xh_lig
+        sigma_T = self.sigma(gamma_T, xh_lig).squeeze()
+        one = torch.ones_like(sigma_T)
+        kl_h = self.gaussian_KL(self.sum_except_batch(mu[:, nd:] ** 2, mask_lig), sigma_T, one, d=1)
+        kl_x = self.gaussian_KL(self.sum_except_batch(mu[:, :nd] ** 2, mask_lig), sigma_T, one,
+                                self.subspace_dimensionality(num_nodes))
+        return kl_x + kl_h
+
     def forward(self, ligand, pocket, return_info=False):
-        raise NotImplementedError(
-            "the training loss (conditional_model.py:202-330) is outside the MI355X sampling hot path "
-            "(SURVEY.md §2 row 4)")
+        """The reference's loss terms for the pocket-conditioned model (conditional_model.py:202-330):
+        same 12-tuple as the joint model with error_t_pocket = loss_0_x_pocket = 0."""
+        self._loss_guard()
+        with torch.no_grad():
+            dev = self._hip_device(None)
+            ligand, pocket = self._to_device(ligand, dev), self._to_device(pocket, dev)
+            ligand, pocket = self.normalize(ligand, pocket)
+            lm, pm = ligand['mask'], pocket['mask']
+            n = ligand['size'].size(0)
+            nd = self.n_dims
+            delta_log_px = self.delta_log_px(ligand['size'])
+            t_int = self._draw_t_int(n, dev)
+            s_int = t_int - 1
+            t_is_zero = (t_int == 0).float()
+            s, t = s_int / self.T, t_int / self.T
+            gamma_s = self.inflate_batch_array(self.gamma(s), ligand['x'])
+            gamma_t = self.inflate_batch_array(self.gamma(t), ligand['x'])
+            xh0_lig = torch.cat([ligand['x'], ligand['one_hot']], dim=1)
+            xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+            xl, xp = self._remove_lig_com(xh0_lig[:, :nd], xh0_pocket[:, :nd], lm, pm, n)         # :232-236
+            xh0_lig = torch.cat([xl, xh0_lig[:, nd:]], dim=1)
+            xh0_pocket = torch.cat([xp, xh0_pocket[:, nd:]], dim=1)
+            z_t, xh_pocket, eps_t = self.noised_representation(xh0_lig, xh0_pocket, lm, pm, gamma_t)
+            net, _ = self.dynamics(z_t, xh_pocket, t, lm, pm)
+            xh_lig_hat = self.xh_given_zt_and_epsilon(z_t, net, gamma_t, lm)
+            squared_error = (eps_t - net) ** 2
+            if self.vnode_idx is not None:       # coordinates of virtual atoms do not contribute (:253-255)
+                squared_error[ligand['one_hot'][:, self.vnode_idx].bool(), :nd] = 0
+            error_t_lig = self.sum_except_batch(squared_error, lm)
+            SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
+            neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=ligand['size'], device=dev)
+            kl_prior = self.kl_prior(xh0_lig, lm, ligand['size'])
+
+            def loss0(z0, e0, n0, g):
+                sq = (e0[:, :nd] - n0[:, :nd]) ** 2
+                if self.vnode_idx is not None:
+                    sq[ligand['one_hot'][:, self.vnode_idx].bool(), :nd] = 0
+                return 0.5 * self.sum_except_batch(sq, lm), -self._log_ph_given_z0(ligand['one_hot'], z0[:, nd:], lm, g)
+
+            if self.training:
+                tz = t_is_zero.squeeze()
+                l0_x, l0_h = loss0(z_t, eps_t, net, gamma_t)
+                l0_x, l0_h = l0_x * tz, l0_h * tz
+                error_t_lig = error_t_lig * (1 - tz)
+            else:                                   # separate pass at t = 0 (:285-302)
+                t_zeros = torch.zeros_like(s)
+                gamma_0 = self.inflate_batch_array(self.gamma(t_zeros), ligand['x'])
+                z_0, xh_pocket0, eps_0 = self.noised_representation(xh0_lig, xh0_pocket, lm, pm, gamma_0)
+                net_0, _ = self.dynamics(z_0, xh_pocket0, t_zeros, lm, pm)
+                l0_x, l0_h = loss0(z_0, eps_0, net_0, gamma_0)
+            log_pN = self.log_pN(ligand['size'], pocket['size'])
+            info = {
+                'eps_hat_lig_x': seg_mean(net[:, :nd].abs().mean(1), lm, n).mean(),
+                'eps_hat_lig_h': seg_mean(net[:, nd:].abs().mean(1), lm, n).mean(),
+            }
+            zero = torch.tensor(0.0)
+            loss_terms = (delta_log_px, error_t_lig, zero, SNR_weight, l0_x, zero.clone(), l0_h,
+                          neg_log_constants, kl_prior, log_pN, t_int.squeeze(), xh_lig_hat)
+        return (*loss_terms, info) if return_info else loss_terms
 
     def log_pN(self, N_lig, N_pocket):
         return self.size_distribution.log_prob_n1_given_n2(N_lig, N_pocket)

@@ -386,11 +386,132 @@ class EnVariationalDiffusion(nn.Module):
         x = torch.randn(size, device=lig_indices.device)
         return EnVariationalDiffusion.remove_mean_batch(x, torch.cat((lig_indices, pocket_indices)))
 
-    # ---- training-only API: out of scope ------------------------------------------
+    # ---- loss terms (en_diffusion.py:109-262, 336-469) --------------------------------------
+    # The network evaluations run on the HIP kernels, which have no backward pass: the loss can be
+    # EVALUATED (validation_step, likelihood estimates) but not differentiated.  Calling forward()
+    # in training mode with autograd enabled raises instead of returning a loss that silently
+    # carries no gradient.
+    t_int_source = None          # optional callable(batch) -> [B,1] float tensor (tests); default torch.randint
+
+    def _draw_t_int(self, batch, device):
+        lowest_t = 0 if self.training else 1                               # en_diffusion.py:349-352
+        if self.t_int_source is not None:
+            return self.t_int_source(batch).to(device=device, dtype=torch.float32).view(batch, 1)
+        return torch.randint(lowest_t, self.T + 1, size=(batch, 1), device=device).float()
+
+    def _loss_guard(self):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError(
+                "forward() evaluates the loss terms on the HIP kernels, which have no backward pass "
+                "(SURVEY.md 8f-3): call it in eval mode or under torch.no_grad(); training needs the "
+                "reference implementation")
+
+    @staticmethod
+    def gaussian_KL(q_mu_minus_p_mu_squared, q_sigma, p_sigma, d):
+        """en_diffusion.py:838-853."""
+        return d * torch.log(p_sigma / q_sigma) + \
+            0.5 * (d * q_sigma ** 2 + q_mu_minus_p_mu_squared) / (p_sigma ** 2) - 0.5 * d
+
+    def log_constants_p_x_given_z0(self, n_nodes, device):
+        """en_diffusion.py:171-184."""
+        batch_size = len(n_nodes)
+        dof = self.subspace_dimensionality(n_nodes)
+        gamma_0 = self.gamma(torch.zeros((batch_size, 1), device=device))
+        log_sigma_x = 0.5 * gamma_0.view(batch_size)
+        return dof * (-log_sigma_x - 0.5 * np.log(2 * np.pi))
+
+    def _log_ph_given_z0(self, one_hot, z_h, mask, gamma_0, epsilon=1e-10):
+        """Categorical part of log_pxh_given_z0_without_constants (en_diffusion.py:214-260)."""
+        nv, nb = self.norm_values[1], self.norm_biases[1]
+        sigma_0_cat = self.sigma(gamma_0, target_tensor=z_h) * nv
+        onehot = one_hot * nv + nb
+        centered = (z_h * nv + nb) - 1
+        logp = torch.log(self.cdf_standard_gaussian((centered + 0.5) / sigma_0_cat[mask])
+                         - self.cdf_standard_gaussian((centered - 0.5) / sigma_0_cat[mask]) + epsilon)
+        logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+        return self.sum_except_batch(logp * onehot, mask)
+
+    def kl_prior_with_pocket(self, xh_lig, xh_pocket, mask_lig, mask_pocket, num_nodes):
+        """KL(q(z_T | x) || N(0, 1)), en_diffusion.py:109-155."""
+        nd = self.n_dims
+        ones = torch.ones((len(num_nodes), 1), device=xh_lig.device)
+        gamma_T = self.gamma(ones)
+        alpha_T = self.alpha(gamma_T, xh_lig)
+        sigma_T = self.sigma(gamma_T, xh_lig).squeeze()
+        mu_l, mu_p = alpha_T[mask_lig] * xh_lig, alpha_T[mask_pocket] * xh_pocket
+        one = torch.ones_like(sigma_T)
+        mu2_h = self.sum_except_batch(mu_l[:, nd:] ** 2, mask_lig) + self.sum_except_batch(mu_p[:, nd:] ** 2, mask_pocket)
+        mu2_x = self.sum_except_batch(mu_l[:, :nd] ** 2, mask_lig) + self.sum_except_batch(mu_p[:, :nd] ** 2, mask_pocket)
+        return self.gaussian_KL(mu2_x, sigma_T, one, self.subspace_dimensionality(num_nodes)) + \
+            self.gaussian_KL(mu2_h, sigma_T, one, d=1)
+
+    def _to_device(self, d, dev):
+        for k in ('x', 'one_hot', 'size', 'mask'):
+            d[k] = d[k].to(dev)
+        d['mask'] = d['mask'].to(torch.int64).contiguous()
+        return d
+
     def forward(self, ligand, pocket, return_info=False):
-        raise NotImplementedError(
-            "the training loss (en_diffusion.py:336-469) is outside the MI355X sampling hot path "
-            "(SURVEY.md §2 row 3)")
+        """The reference's loss terms (en_diffusion.py:336-469), same 12-tuple (+ info):
+        (delta_log_px, error_t_lig, error_t_pocket, SNR_weight, loss_0_x_ligand, loss_0_x_pocket,
+         loss_0_h, neg_log_constants, kl_prior, log_pN, t_int, xh_lig_hat)."""
+        self._loss_guard()
+        with torch.no_grad():
+            dev = self._hip_device(None)
+            ligand, pocket = self._to_device(ligand, dev), self._to_device(pocket, dev)
+            ligand, pocket = self.normalize(ligand, pocket)
+            lm, pm = ligand['mask'], pocket['mask']
+            n = ligand['size'].size(0)
+            nd = self.n_dims
+            n_nodes = ligand['size'] + pocket['size']
+            delta_log_px = self.delta_log_px(n_nodes)
+            t_int = self._draw_t_int(n, dev)
+            s_int = t_int - 1
+            t_is_zero = (t_int == 0).float()
+            t_is_not_zero = 1 - t_is_zero
+            s, t = s_int / self.T, t_int / self.T
+            gamma_s = self.inflate_batch_array(self.gamma(s), ligand['x'])
+            gamma_t = self.inflate_batch_array(self.gamma(t), ligand['x'])
+            xh_lig = torch.cat([ligand['x'], ligand['one_hot']], dim=1)
+            xh_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
+            z_l, z_p, eps_l, eps_p = self.noised_representation(xh_lig, xh_pocket, lm, pm, gamma_t)
+            net_l, net_p = self.dynamics(z_l.contiguous(), z_p.contiguous(), t, lm, pm)
+            xh_lig_hat = self.xh_given_zt_and_epsilon(z_l, net_l, gamma_t, lm)
+            error_t_lig = self.sum_except_batch((eps_l - net_l) ** 2, lm)
+            error_t_pocket = self.sum_except_batch((eps_p - net_p) ** 2, pm)
+            SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
+            neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=n_nodes, device=dev)
+            kl_prior = self.kl_prior_with_pocket(xh_lig, xh_pocket, lm, pm, n_nodes)
+
+            def loss0(zl, zp, el, ep, nl, np_, g):
+                lx_l = 0.5 * self.sum_except_batch((el[:, :nd] - nl[:, :nd]) ** 2, lm)
+                lx_p = 0.5 * self.sum_except_batch((ep[:, :nd] - np_[:, :nd]) ** 2, pm)
+                lh = -(self._log_ph_given_z0(ligand['one_hot'], zl[:, nd:], lm, g)
+                       + self._log_ph_given_z0(pocket['one_hot'], zp[:, nd:], pm, g))
+                return lx_l, lx_p, lh
+
+            if self.training:
+                tz = t_is_zero.squeeze()
+                l0_xl, l0_xp, l0_h = loss0(z_l, z_p, eps_l, eps_p, net_l, net_p, gamma_t)
+                l0_xl, l0_xp, l0_h = l0_xl * tz, l0_xp * tz, l0_h * tz
+                error_t_lig = error_t_lig * t_is_not_zero.squeeze()
+                error_t_pocket = error_t_pocket * t_is_not_zero.squeeze()
+            else:                                   # separate pass at t = 0 (en_diffusion.py:426-446)
+                t_zeros = torch.zeros_like(s)
+                gamma_0 = self.inflate_batch_array(self.gamma(t_zeros), ligand['x'])
+                z0_l, z0_p, e0_l, e0_p = self.noised_representation(xh_lig, xh_pocket, lm, pm, gamma_0)
+                n0_l, n0_p = self.dynamics(z0_l.contiguous(), z0_p.contiguous(), t_zeros, lm, pm)
+                l0_xl, l0_xp, l0_h = loss0(z0_l, z0_p, e0_l, e0_p, n0_l, n0_p, gamma_0)
+            log_pN = self.log_pN(ligand['size'], pocket['size'])
+            info = {
+                'eps_hat_lig_x': seg_mean(net_l[:, :nd].abs().mean(1), lm, n).mean(),
+                'eps_hat_lig_h': seg_mean(net_l[:, nd:].abs().mean(1), lm, n).mean(),
+                'eps_hat_pocket_x': seg_mean(net_p[:, :nd].abs().mean(1), pm, n).mean(),
+                'eps_hat_pocket_h': seg_mean(net_p[:, nd:].abs().mean(1), pm, n).mean(),
+            }
+            loss_terms = (delta_log_px, error_t_lig, error_t_pocket, SNR_weight, l0_xl, l0_xp, l0_h,
+                          neg_log_constants, kl_prior, log_pN, t_int.squeeze(), xh_lig_hat)
+        return (*loss_terms, info) if return_info else loss_terms
 
     # ---- dynamics call ---------------------------------------------------------------
     def _check_status(self, status):

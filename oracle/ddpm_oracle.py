@@ -519,3 +519,119 @@ class NoiseReplay:
         self.i += 1
         assert tuple(x.shape) == tuple(shape), (x.shape, shape)
         return x
+
+
+# ---------------------------------------------------------------------------
+# training / validation loss terms: conditional_model.py:202-330,
+# en_diffusion.py:336-469 with the random draws injected (t_int and the Gaussian noise)
+# ---------------------------------------------------------------------------
+def _sum_except_batch(x, idx, n):
+    """en_diffusion.py:944-946."""
+    return eo.segment_sum(x.sum(-1, keepdim=True), idx, n).squeeze(1)
+
+
+def _gaussian_kl(mu_norm2, q_sigma, p_sigma, d):
+    """en_diffusion.py:838-853."""
+    return d * torch.log(p_sigma / q_sigma) + 0.5 * (d * q_sigma ** 2 + mu_norm2) / (p_sigma ** 2) - 0.5 * d
+
+
+def _cdf(x):
+    return 0.5 * (1.0 + torch.erf(x / np.sqrt(2)))
+
+
+def _subspace_dim(m, n_nodes):
+    """en_diffusion.py:914-917; SimpleConditionalDDPM: conditional_model.py:713-715."""
+    return n_nodes * m.n_dims if m.simple else (n_nodes - 1) * m.n_dims
+
+
+def _log_ph_given_z0(m, one_hot, z_h, mask, g0, n, epsilon=1e-10):
+    """The categorical part of log_pxh_given_z0_without_constants (en_diffusion.py:214-260,
+    conditional_model.py:76-110): integral of N(z_h, sigma_0) over [0.5, 1.5] per class, normalised."""
+    nv, nb = m.norm_values[1], m.norm_biases[1]
+    sigma_0_cat = sigma(g0) * nv
+    onehot = one_hot * nv + nb
+    centered = (z_h * nv + nb) - 1
+    logp = torch.log(_cdf((centered + 0.5) / sigma_0_cat[mask]) - _cdf((centered - 0.5) / sigma_0_cat[mask]) + epsilon)
+    logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+    return _sum_except_batch(logp * onehot, mask, n)
+
+
+def loss_terms(m, ligand, pocket, t_int, noise, training, size_log_prob=None):
+    """`forward(ligand, pocket)` of ConditionalDDPM (conditional_model.py:202-330) or
+    EnVariationalDiffusion (en_diffusion.py:336-469) -> the reference's 12-tuple
+    (delta_log_px, error_t_lig, error_t_pocket, SNR_weight, loss_0_x_ligand, loss_0_x_pocket,
+     loss_0_h, neg_log_constants, kl_prior, log_pN, t_int, xh_lig_hat).
+    `ligand` / `pocket`: un-normalised dicts (not modified); t_int [B,1] float (the reference draws
+    torch.randint(lowest_t, T+1)); noise: callable(shape)."""
+    nd, T = m.n_dims, m.T
+    ligand = {k: v.clone() for k, v in ligand.items()}
+    pocket = {k: v.clone() for k, v in pocket.items()}
+    ligand, pocket = normalize(m, ligand, pocket)
+    lm, pm = ligand["mask"], pocket["mask"]
+    n = len(ligand["size"])
+    cond = m.conditional
+    n_nodes = ligand["size"] if cond else ligand["size"] + pocket["size"]
+    delta_log_px = -_subspace_dim(m, n_nodes) * np.log(m.norm_values[0])          # :198-200 / :332-334
+    s_int = t_int - 1
+    t_is_zero = (t_int == 0).float()
+    s, t = s_int / T, t_int / T
+    g_s, g_t = m.g(s), m.g(t)
+    xh_l = torch.cat([ligand["x"], ligand["one_hot"]], 1)
+    xh_p = torch.cat([pocket["x"], pocket["one_hot"]], 1)
+
+    def noised(g):
+        if cond:
+            z, xp, eps = cond_noised_representation(m, xh_l, xh_p, lm, pm, g, noise, n)
+            return z, xp, eps, None
+        n_l, n_p = joint_noise(m, lm, pm, noise)                                     # en_diffusion.py:302-317
+        return (alpha(g)[lm] * xh_l + sigma(g)[lm] * n_l, alpha(g)[pm] * xh_p + sigma(g)[pm] * n_p, n_l, n_p)
+
+    if cond:                                                                         # :232-236
+        xl, xp = cond_remove_mean(m, xh_l[:, :nd], xh_p[:, :nd], lm, pm, n)
+        xh_l = torch.cat([xl, xh_l[:, nd:]], 1)
+        xh_p = torch.cat([xp, xh_p[:, nd:]], 1)
+    z_l, z_p, eps_l, eps_p = noised(g_t)
+    net_l, net_p = m.dynamics(z_l, z_p, t, lm, pm)
+    a_t, s_t = alpha(g_t), sigma(g_t)
+    xh_lig_hat = z_l / a_t[lm] - net_l * s_t[lm] / a_t[lm]                           # xh_given_zt_and_epsilon
+    error_t_lig = _sum_except_batch((eps_l - net_l) ** 2, lm, n)
+    error_t_pocket = torch.tensor(0.0) if cond else _sum_except_batch((eps_p - net_p) ** 2, pm, n)
+    snr_weight = (1 - torch.exp(-(g_s - g_t))).squeeze(1)
+    g0 = m.g(torch.zeros((n, 1)))
+    neg_log_constants = -(_subspace_dim(m, n_nodes) * (-0.5 * g0.view(n) - 0.5 * np.log(2 * np.pi)))
+    # KL(q(z_T | x) || N(0, 1))  (conditional_model.py:36-74, en_diffusion.py:109-155)
+    g_T = m.g(torch.ones((n, 1)))
+    a_T, s_T = alpha(g_T), sigma(g_T).squeeze()
+    mu_l = a_T[lm] * xh_l
+    mu2_h = _sum_except_batch(mu_l[:, nd:] ** 2, lm, n)
+    mu2_x = _sum_except_batch(mu_l[:, :nd] ** 2, lm, n)
+    if not cond:
+        mu_p = a_T[pm] * xh_p
+        mu2_h = mu2_h + _sum_except_batch(mu_p[:, nd:] ** 2, pm, n)
+        mu2_x = mu2_x + _sum_except_batch(mu_p[:, :nd] ** 2, pm, n)
+    ones = torch.ones_like(s_T)
+    kl_prior = _gaussian_kl(mu2_x, s_T, ones, _subspace_dim(m, n_nodes)) + _gaussian_kl(mu2_h, s_T, ones, 1)
+
+    def loss0(z_l0, z_p0, e_l0, e_p0, n_l0, n_p0, g):
+        lx_l = 0.5 * _sum_except_batch((e_l0[:, :nd] - n_l0[:, :nd]) ** 2, lm, n)
+        lh = -_log_ph_given_z0(m, ligand["one_hot"], z_l0[:, nd:], lm, g, n)
+        if cond:
+            return lx_l, torch.tensor(0.0), lh
+        lx_p = 0.5 * _sum_except_batch((e_p0[:, :nd] - n_p0[:, :nd]) ** 2, pm, n)
+        lh = lh - _log_ph_given_z0(m, pocket["one_hot"], z_p0[:, nd:], pm, g, n)
+        return lx_l, lx_p, lh
+
+    if training:
+        l0_xl, l0_xp, l0_h = loss0(z_l, z_p, eps_l, eps_p, net_l, net_p, g_t)
+        tz = t_is_zero.squeeze()
+        l0_xl, l0_h = l0_xl * tz, l0_h * tz
+        l0_xp = l0_xp if cond else l0_xp * tz
+        error_t_lig = error_t_lig * (1 - tz)
+        error_t_pocket = error_t_pocket if cond else error_t_pocket * (1 - tz)
+    else:
+        z_l0, z_p0, e_l0, e_p0 = noised(g0)
+        n_l0, n_p0 = m.dynamics(z_l0, z_p0, torch.zeros_like(s), lm, pm)
+        l0_xl, l0_xp, l0_h = loss0(z_l0, z_p0, e_l0, e_p0, n_l0, n_p0, g0)
+    log_pN = size_log_prob(ligand["size"], pocket["size"]) if size_log_prob is not None else None
+    return (delta_log_px, error_t_lig, error_t_pocket, snr_weight, l0_xl, l0_xp, l0_h, neg_log_constants,
+            kl_prior, log_pN, t_int.squeeze(), xh_lig_hat)

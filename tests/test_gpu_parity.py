@@ -667,3 +667,43 @@ def test_stream_replicas_equal_single_batch_bitwise():
         for a, b in zip(out, ref):
             assert torch.equal(a, b), S
     assert auto_streams(32 * 59, 32) == 1 and auto_streams(64 * 309, 64) == 1    # opt-in only (measured slower)
+
+
+@pytest.mark.parametrize("name", ["loss_small_cond_eval", "loss_small_cond_train", "loss_small_joint_eval",
+                                  "loss_small_joint_train"])
+def test_loss_terms_vs_oracle_and_reference_golden(name):
+    """SURVEY.md 8f-3 (evaluation half): `forward()` -- the 12 loss terms of conditional_model.py:202-330 /
+    en_diffusion.py:336-469 -- with the network passes on the HIP kernels, against the oracle on the same
+    t_int / noise (1e-4 relative to each term's scale) and against the values the real reference returned."""
+    from tests.test_oracle_golden import LOSS_NAMES, loss_inputs
+    c = Case(name)
+    cfg, dd = c.cfg, c.ddpm
+    training = bool(int(c.z["training"]))
+    model = make_ddpm(c)
+    model.size_distribution = type(model.size_distribution)(np.ones((12, 60)))      # the golden's histogram
+    model.train(training)
+    model.set_noise_source(do.NoiseReplay(c.noise()))
+    model.t_int_source = lambda b: c.t("t_int")
+    ligand, pocket = loss_inputs(c)
+    with torch.no_grad():
+        out = model(ligand, pocket, return_info=True)
+    terms, info = out[:12], out[12]
+    om = do.OracleModel(c.state_dict(), cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
+                        dd["noise_precision"], norm_values=dd["norm_values"], conditional=dd["conditional"])
+    ligand, pocket = loss_inputs(c)
+    ref = do.loss_terms(om, ligand, pocket, c.t("t_int"), do.NoiseReplay(c.noise()), training)
+    for nme, v, r in zip(LOSS_NAMES, terms, ref):
+        v = torch.as_tensor(v).float().cpu()
+        gold = c.t("out_" + nme)
+        assert v.shape == gold.shape, (nme, v.shape, gold.shape)
+        scale = max(1.0, gold.abs().max().item())
+        if r is not None:
+            assert (v - torch.as_tensor(r).float()).abs().max().item() <= 1e-4 * scale, (name, nme)   # vs oracle
+        # vs the reference's own numbers (its radius graph uses torch.cdist: an edge at the cutoff may differ)
+        assert (v - gold).abs().max().item() <= 5e-3 * scale, (name, nme, (v - gold).abs().max().item())
+    for k, v in info.items():
+        assert abs(float(v) - float(c.t("info_" + k))) <= 5e-3 * max(1.0, abs(float(c.t("info_" + k)))), k
+    # the training step itself needs a backward pass, which the HIP kernels do not have: refuse loudly
+    model.train(True)
+    with pytest.raises(NotImplementedError, match="no backward pass"):
+        model(*loss_inputs(c))

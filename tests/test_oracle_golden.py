@@ -173,3 +173,37 @@ def test_joint_sampling_and_inpaint_match_golden():
     assert (o_l[:, :3] - c.t("inp_out_lig")[:, :3]).abs().max() < 1e-4
     assert torch.equal(o_l[:, 3:].long(), c.t("inp_out_lig")[:, 3:].long())
     assert (o_p[:, :3] - c.t("inp_out_pocket")[:, :3]).abs().max() < 1e-4
+
+
+LOSS_CASES = ["loss_small_cond_eval", "loss_small_cond_train", "loss_small_joint_eval", "loss_small_joint_train"]
+LOSS_NAMES = ("delta_log_px", "error_t_lig", "error_t_pocket", "SNR_weight", "loss_0_x_ligand", "loss_0_x_pocket",
+              "loss_0_h", "neg_log_constants", "kl_prior", "log_pN", "t_int_out", "xh_lig_hat")
+
+
+def loss_inputs(c):
+    ligand = {k: c.t("ligand_" + k) for k in ("x", "one_hot", "size", "mask")}
+    pocket = {k: c.t("pocket_" + k) for k in ("x", "one_hot", "size", "mask")}
+    return ligand, pocket
+
+
+@pytest.mark.parametrize("name", LOSS_CASES)
+def test_loss_terms_match_reference_golden(name):
+    """the oracle's restatement of `forward()` (conditional_model.py:202-330,
+    en_diffusion.py:336-469) against the 12 loss terms the real reference returned for the same
+    t_int and noise tape (tests/golden/make_golden_loss.py)."""
+    c = Case(name)
+    cfg, dd = c.cfg, c.ddpm
+    m = do.OracleModel(c.state_dict(), cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"],
+                       dd["noise_schedule"], dd["noise_precision"], norm_values=dd["norm_values"],
+                       conditional=dd["conditional"])
+    m.exact_dist = False           # torch.cdist, as the reference run that produced the golden
+    ligand, pocket = loss_inputs(c)
+    out = do.loss_terms(m, ligand, pocket, c.t("t_int"), do.NoiseReplay(c.noise()), bool(int(c.z["training"])))
+    for nme, v in zip(LOSS_NAMES, out):
+        if nme == "log_pN":
+            continue                # needs the size histogram object: checked on the module level (host logic)
+        ref = c.t("out_" + nme)
+        v = torch.as_tensor(v).float()
+        assert v.shape == ref.shape, (nme, v.shape, ref.shape)
+        tol = 2e-5 * max(1.0, ref.abs().max().item())
+        assert (v - ref).abs().max().item() <= tol, (name, nme, (v - ref).abs().max().item())
