@@ -153,9 +153,6 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="concurrent sub-batches per GPU (diffsbdd_amd/streams.py); 0 = the default (1: splitting "
                          "was measured slower, host-bound graph submission)")
-    ap.add_argument("--csplit", type=int, default=0, choices=[0, 1, 2, 4],
-                    help="column split of the edge kernels (EGNNDynamics.set_latency_mode); 0 = automatic: 4 for "
-                         "workloads in the latency regime (< 8192 nodes per call), else 1")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -183,8 +180,6 @@ def main():
     pocket0 = load_pocket(key, B, device)
     n_lig = torch.full((B,), args.n_lig, dtype=torch.int64)
     lo = rank * B                                   # weak scaling: every rank owns B global samples
-    csplit = args.csplit or (4 if B * args.n_lig + pocket0["x"].shape[0] < 8192 else 1)
-    model.dynamics.set_latency_mode(csplit)
     eng = model.dynamics.engine()
     from diffsbdd_amd.streams import StreamReplicas, auto_streams
     n_streams = args.streams or (1 if joint else auto_streams(B * args.n_lig + pocket0["x"].shape[0], B))
@@ -290,7 +285,7 @@ def main():
                                    f" + final decode = {n_calls} EGNN calls per chain",
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
-                       "streams_per_gpu": n_streams, "edge_csplit": csplit,
+                       "streams_per_gpu": n_streams,
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,

@@ -58,7 +58,6 @@ SIGNATURES = {
     "dsbdd_engine_workspace_bytes": (C.c_size_t, [_P, _I64, _I64, _I64, _I64]),
     "dsbdd_engine_bind_workspace": (C.c_int, [_P, _P, C.c_size_t, _I64, _I64, _I64, _I64]),
     "dsbdd_engine_set_trace": (C.c_int, [_P, _P, _P]),
-    "dsbdd_engine_set_option": (C.c_int, [_P, C.c_char_p, _I32]),
     "dsbdd_dynamics_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64,
                                          _P, _P, _I64, _P, _P, _P]),
     "dsbdd_engine_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),

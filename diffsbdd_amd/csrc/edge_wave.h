@@ -58,25 +58,15 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// CS ("column split", latency regime): the features of a 32-edge tile are divided over CS waves
-// (CT / CS column tiles each), so a workgroup covers 128 / CS edges and a tile's dependent MFMA
-// chain is CS times shorter.  For small graphs (C-alpha pockets: ~150 tiles of 128 edges, one per
-// workgroup, most CUs idle) the launch is as long as ONE tile's chain; CS = 2 / 4 puts 2 / 4 times
-// as many, shorter workgroups on the chip.  The waves of a tile build the same A operand
-// (redundantly, it is cheap) and exchange only the per-row partial sums of the attention /
-// scalar-head dot products through LDS.  CS = 1 is the throughput configuration (large batches).
-template <int H, int MODE, bool BPERM, int CS>
+template <int H, int MODE, bool BPERM>
 __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   using L = WaveLayout<H, MODE>;
   constexpr int BK = L::BK;
-  constexpr int CT = H / 32;            // 32-col MFMA tiles of a 32-edge tile (all features)
-  constexpr int CTW = CT / CS;          // ... of which this wave computes CTW
+  constexpr int CT = H / 32;            // 32-col MFMA tiles per wave (all features)
   constexpr int NK = H / BK;            // K slices per unit
   constexpr int NQ = H / 4;
   constexpr int BI = BK * NQ / kThreads;   // float4 of a W2^T slice per thread
-  constexpr int BMW = 32, BMB = 128 / CS;  // edges per wave tile / per workgroup
-  constexpr int TPW = 4 / CS;           // 32-edge tiles per workgroup
-  static_assert(CT % CS == 0 && (CS == 1 || CS == 2 || CS == 4), "column split must divide the column tiles");
+  constexpr int BMW = 32, BMB = 128;    // edges per wave / per workgroup
   static_assert(H % 64 == 0 && H <= 256, "hidden_nf must be 64,128,192 or 256");
   static_assert((BK * NQ) % kThreads == 0, "B slice split");
   // s_setprio 1 around every MFMA cluster: the two workgroups sharing a CU are in different
@@ -95,10 +85,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   float* sV = smem + L::VEC_OFF;            // per MLP: wd, wd0, tab0..2, b2, w-out
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, j = lane & 31;
-  const int tw = w / CS, cp = w % CS;                   // tile of the workgroup / column part of the tile
   float* s_phi = smem + L::SCR_OFF + w * L::SCR_PER;   // [32]
-  // scratch of the CS waves that share this wave's tile (cross-wave partial sums)
-  auto s_part = [&](int cq) { return smem + L::SCR_OFF + (tw * CS + cq) * L::SCR_PER; };
   float* s_tr = s_phi;                                  // [32][3] (phi is consumed before trans is written)
   const bool split = MODE == MODE_COORD && p.pass_split && p.n_mlp == 2;
   const int qsel = split ? ((blockIdx.x >> 3) & 1) : 0;   // the MLP this workgroup evaluates when split
@@ -123,8 +110,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const float inv_norm = 1.0f / p.norm_factor;
 
   const int swb = (bperm && CT == 8) ? ((j >> 3) & 1) : 0;          // this lane reads its halves swapped
-  // feature held by this wave's accumulator tile c (tile cp * CTW + c of the edge tile)
-  auto feat = [&](int c) { return (((cp * CTW + c) ^ (4 * swb)) * 32) + j; };
+  auto feat = [&](int c) { return ((c ^ (4 * swb)) * 32) + j; };    // feature held by accumulator tile c
 
   const int E = min(*p.e_count, p.e_cap);
   const int ntiles = (E + BMB - 1) / BMB;
@@ -186,8 +172,8 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   int my_wt = 0, nx_wt = 0;            // global wave-tile index
   float nx_d0 = 0.f, nxr[3] = {0.f, 0.f, 0.f}, nxc[3] = {0.f, 0.f, 0.f};
   auto fetch_idx = [&](int tile) {
-    const int e0 = tile * BMB + tw * BMW, e = e0 + j;
-    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = tile * TPW + tw;
+    const int e0 = tile * BMB + w * BMW, e = e0 + j;
+    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = tile * 4 + w;
     if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
     if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1];
   };
@@ -231,9 +217,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     const bool tile_ends = q == n_pass - 1;
     const int qn = tile_ends ? 0 : q + 1;                  // MLP pass of the next unit
 
-    f32x16 acc[CTW];
+    f32x16 acc[CT];
 #pragma unroll
-    for (int c = 0; c < CTW; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
@@ -263,10 +249,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       const bool last_unit_k = tile_ends && !has_next;     // final from st >= 2 (DYN) / st >= 0
       if (more) streamB(q, kt + 1, (bslice + 1) & 1);
       else if (!last_unit_k) streamB(qn, 0, (bslice + 1) & 1);   // continuous stream across units
-      // B operand of this lane: column j of every column tile (plain layout), or the lane-grouped
-      // copy where its CT values are consecutive words (CS > 1: the CTW words of this wave's part)
-      const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H +
-                          (bperm ? j * CT + (CS == 1 ? 4 * swb : ((cp * CTW) ^ (4 * swb))) : j + cp * CTW * 32);
+      const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
@@ -298,9 +281,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           const float* brow = bcur + (8 * g + i) * H;
 #ifdef DSBDD_DIAG_NOBREAD
 #pragma unroll
-          for (int c = 0; c < CTW; ++c) acc[c] = mfma32(a[i], a[(i + c) & 3], acc[c]);   // DIAGNOSTIC ONLY
+          for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], a[(i + c) & 3], acc[c]);   // DIAGNOSTIC ONLY
 #else
-          if constexpr (BPERM && CS == 1) {
+          if constexpr (BPERM) {
             float bv[CT];
             const float4 lo = *reinterpret_cast<const float4*>(brow);
             bv[0] = lo.x; bv[1] = lo.y; bv[2] = lo.z; bv[3] = lo.w;
@@ -310,22 +293,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
             }
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], bv[c], acc[c]);
-          } else if constexpr (BPERM) {
-            float bv[CTW];
-            if constexpr (CTW == 4) {
-              const float4 v4 = *reinterpret_cast<const float4*>(brow);
-              bv[0] = v4.x; bv[1] = v4.y; bv[2] = v4.z; bv[3] = v4.w;
-            } else if constexpr (CTW == 2) {
-              const float2 v2 = *reinterpret_cast<const float2*>(brow);
-              bv[0] = v2.x; bv[1] = v2.y;
-            } else {
-              bv[0] = brow[0];
-            }
-#pragma unroll
-            for (int c = 0; c < CTW; ++c) acc[c] = mfma32(a[i], bv[c], acc[c]);
           } else {
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
+            for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
           }
 #endif
         }
@@ -354,7 +324,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     if (MODE == MODE_GCL) {   // DIAGNOSTIC ONLY: consume the accumulators with 127 adds
       float tot = 0.f;
 #pragma unroll
-      for (int c = 0; c < CTW; ++c)
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tot += acc[c][r];
       if (tot == 12345.678f) p.agg[lane] = tot;
@@ -363,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     if (MODE == MODE_GCL) {
       // messages m = SiLU(acc + b2)   (egnn_new.py:18-19)
 #pragma unroll
-      for (int c = 0; c < CTW; ++c) {
+      for (int c = 0; c < CT; ++c) {
         const float bv = vq[5 * H + feat(c)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = silu(acc[c][r] + bv);
@@ -373,7 +343,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < CTW; ++c) {
+        for (int c = 0; c < CT; ++c) {
           const float aw = vq[6 * H + feat(c)];
 #pragma unroll
           for (int r = 0; r < 16; ++r) part[r] += acc[c][r] * aw;
@@ -382,24 +352,10 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         for (int o = 1; o < 32; o <<= 1)
 #pragma unroll
           for (int r = 0; r < 16; ++r) part[r] += __shfl_xor(part[r], o);
-        if constexpr (CS > 1) {   // the dot product runs over all features: add the other waves' parts
-          if (j == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_phi[mfma_row(r, lane)] = part[r];
-          }
-          __syncthreads();
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float tot = 0.f;
-#pragma unroll
-            for (int cq = 0; cq < CS; ++cq) tot += s_part(cq)[mfma_row(r, lane)];
-            part[r] = tot;
-          }
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[r] = sigmoidf_fast(part[r] + att_b);
 #pragma unroll
-        for (int c = 0; c < CTW; ++c)
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[c][r] *= part[r];       // mij * att, egnn_new.py:40
       }
@@ -407,9 +363,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       // 8*(rr>>2) + 4*h + (rr&3): rows alternate between the halves in groups of 4
       // Walk the 32 rows once (row ids are wave-uniform scalars), carrying the CT
       // column sums of this lane; sub-block gb (rows 4gb..4gb+3) lives in half gb&1.
-      float sum[CTW];
+      float sum[CT];
 #pragma unroll
-      for (int c = 0; c < CTW; ++c) sum[c] = 0.f;
+      for (int c = 0; c < CT; ++c) sum[c] = 0.f;
       int cur = -1;
       // aggregation protocol (edge_mlp.h): the first segment of the tile goes to agg_head[tile]
       // when its row continues from the previous wave tile, every other segment is the start of
@@ -421,7 +377,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           if (half == owner) {
             float* dst = to_head ? p.agg_head + (size_t)my_wt * H : p.agg + (size_t)cur * H;
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) dst[feat(c)] = sum[c] * inv_norm;
+            for (int c = 0; c < CT; ++c) dst[feat(c)] = sum[c] * inv_norm;
           }
           to_head = false;
         }
@@ -431,7 +387,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         const int hh = gb & 1;
         if (gb > 0) {                                      // baton: running sums move to the owning half
 #pragma unroll
-          for (int c = 0; c < CTW; ++c) {
+          for (int c = 0; c < CT; ++c) {
             const float other = __shfl_xor(sum[c], 32);
             if (half == hh) sum[c] = other;
           }
@@ -443,11 +399,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
             flush(hh);
             cur = rn;
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) sum[c] = 0.f;
+            for (int c = 0; c < CT; ++c) sum[c] = 0.f;
           }
           if (half == hh) {
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) sum[c] += acc[c][4 * (gb >> 1) + i];
+            for (int c = 0; c < CT; ++c) sum[c] += acc[c][4 * (gb >> 1) + i];
           }
         }
       }
@@ -458,7 +414,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
-      for (int c = 0; c < CTW; ++c) {
+      for (int c = 0; c < CT; ++c) {
         const float bv = vq[5 * H + feat(c)], wv = vq[6 * H + feat(c)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[r] += silu(acc[c][r] + bv) * wv;
@@ -471,21 +427,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_phi[mfma_row(r, lane)] = part[r];
       }
-      float ph;
-      if constexpr (CS > 1) {   // sum the column parts of the CS waves of this tile
-        __syncthreads();
-        ph = 0.f;
-#pragma unroll
-        for (int cq = 0; cq < CS; ++cq) ph += s_part(cq)[j];
-        __syncthreads();        // the scratch is rewritten below (trans) / by the next unit
-      } else {
-        wave_lds_fence();
-        ph = s_phi[j];                                      // this lane's edge
-        wave_lds_fence();
-      }
+      wave_lds_fence();
+      const float ph = s_phi[j];                            // this lane's edge
+      wave_lds_fence();
       if (qsel + q == 0) phi0 = ph; else phi1 = ph;
 
-      if (tile_ends && cp == 0) {   // one wave per tile turns phi into translations and sums them per row
+      if (tile_ends) {
         // trans = u*phi + cross*phi_x   (egnn_new.py:100-109, 296-316); lane = edge
         float tx = 0.f, ty = 0.f, tz = 0.f;
         if (my_r >= 0) {

@@ -70,8 +70,6 @@ struct dsbdd_engine {
   int use_graph = 1;
   int coord_split = 1; // edge_wave MODE_COORD: one workgroup per (tile, MLP) (DSBDD_COORD_SPLIT=0: per tile)
   int node_group = 1;  // coordinate projections + next block's P|Q in one launch (DSBDD_NODE_GROUP=0: separate)
-  int edge_csplit = 1;  // column split of the edge kernels: 1 = throughput, 2 / 4 = latency regime (DSBDD_EDGE_CSPLIT,
-                        // dsbdd_engine_set_option "edge_csplit")
   int edge_max_wg = 0;  // test hook (DSBDD_EDGE_MAX_WG): cap on the persistent edge grid, so that small problems
                         // run several tiles per workgroup (the path large batches take)
   int64_t n_replay = 0, n_capture = 0, n_eager = 0;
@@ -165,8 +163,6 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (csp && atoi(csp) == 0) e->coord_split = 0;
   const char* ngp = getenv("DSBDD_NODE_GROUP");
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
-  const char* ecs = getenv("DSBDD_EDGE_CSPLIT");
-  if (ecs && (atoi(ecs) == 2 || atoi(ecs) == 4)) e->edge_csplit = atoi(ecs);
   const char* mwg = getenv("DSBDD_EDGE_MAX_WG");
   if (mwg && atoi(mwg) > 0) e->edge_max_wg = atoi(mwg);
   *out = e;
@@ -238,18 +234,6 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->scan_tmp = (int*)(b + L.off[26]); e->seg_base = (int*)(b + L.off[27]); e->tile_ctr = (int*)(b + L.off[28]);
   e->cap_tiles = E / 32 + 2;
   e->w2tp_ready = false;
-  return DSBDD_OK;
-}
-
-int dsbdd_engine_set_option(dsbdd_engine* e, const char* name, int32_t value) {
-  if (!e || !name) return fail(DSBDD_ERR_ARG, "null argument");
-  if (!strcmp(name, "edge_csplit")) {
-    if (value != 1 && value != 2 && value != 4) return fail(DSBDD_ERR_ARG, "edge_csplit must be 1, 2 or 4");
-    e->edge_csplit = value;
-  } else {
-    return fail(DSBDD_ERR_ARG, std::string("unknown option ") + name);
-  }
-  e->drop_graphs();          // captured launch sequences froze the previous choice
   return DSBDD_OK;
 }
 
@@ -326,49 +310,31 @@ static hipError_t nl_rows(hipStream_t s, const float* A1, int lda1, int K1, cons
   return launch_node_linear(s, a);
 }
 
-template <int H, int CS>
-static hipError_t launch_wave_cs(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+template <int H>
+static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
   // lane-grouped W2^T copies present (EdgeMlpW::W2TP): 16-byte B-operand reads
   constexpr bool can_perm = (H == 256 || H == 128);
   if constexpr (can_perm) {
     if (a.mlp[0].W2TP && a.mlp[1].W2TP) {
       if (mode == MODE_GCL)
-        hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, true, CS>), dim3(grid), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, true>), dim3(grid), dim3(kThreads), 0, s, a);
       else
-        hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, true, CS>), dim3(grid), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, true>), dim3(grid), dim3(kThreads), 0, s, a);
       return hipGetLastError();
     }
   }
   if (mode == MODE_GCL)
-    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, false, CS>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, false>), dim3(grid), dim3(kThreads), 0, s, a);
   else
-    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, false, CS>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, false>), dim3(grid), dim3(kThreads), 0, s, a);
   return hipGetLastError();
-}
-
-// column split (latency regime) is built for the widths that have 4 / 8 column tiles
-static int effective_csplit(int H, int cs) {
-  if (cs != 2 && cs != 4) return 1;
-  return (H == 256 || H == 128) ? cs : 1;
-}
-
-template <int H>
-static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid, int cs) {
-  if constexpr (H == 256 || H == 128) {
-    if (cs == 4) return launch_wave_cs<H, 4>(s, mode, a, grid);
-    if (cs == 2) return launch_wave_cs<H, 2>(s, mode, a, grid);
-  }
-  return launch_wave_cs<H, 1>(s, mode, a, grid);
 }
 
 static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
                               int64_t edge_bound) {
   const int H = e->cfg.hidden_nf;
-  // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU, persistent over tiles;
-  // latency regime: 128 / cs edges per workgroup (edge_wave.h, column split)
-  const int cs = effective_csplit(H, e->edge_csplit);
-  const int bmb = 128 / cs;
-  int64_t tiles = (edge_bound + bmb - 1) / bmb;
+  // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU, persistent over tiles
+  int64_t tiles = (edge_bound + 127) / 128;
   int64_t resident = 2LL * e->n_cu;
   if (e->edge_max_wg > 0 && e->edge_max_wg < resident) resident = e->edge_max_wg;
   const bool split = mode == MODE_COORD && a.pass_split && a.n_mlp == 2;
@@ -378,10 +344,10 @@ static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, co
   int grid = (int)((g + q8 - 1) / q8 * q8);
   if (grid < q8) grid = q8;
   switch (H) {
-    case 64: return launch_wave_t<64>(s, mode, a, grid, cs);
-    case 128: return launch_wave_t<128>(s, mode, a, grid, cs);
-    case 192: return launch_wave_t<192>(s, mode, a, grid, cs);
-    case 256: return launch_wave_t<256>(s, mode, a, grid, cs);
+    case 64: return launch_wave_t<64>(s, mode, a, grid);
+    case 128: return launch_wave_t<128>(s, mode, a, grid);
+    case 192: return launch_wave_t<192>(s, mode, a, grid);
+    case 256: return launch_wave_t<256>(s, mode, a, grid);
   }
   return hipErrorInvalidValue;
 }

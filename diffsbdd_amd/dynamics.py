@@ -148,7 +148,6 @@ class EGNNDynamics(nn.Module):
                         norm_constant=norm_constant, normalization_factor=normalization_factor,
                         coords_range=15.0)   # egnn_new.py:190,218: the un-divided range reaches the layer
         self._engine = None
-        self._edge_csplit = 1
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_engine())
         self.to(device)
 
@@ -163,18 +162,6 @@ class EGNNDynamics(nn.Module):
         self._engine = None
         return out
 
-    def set_latency_mode(self, csplit=4):
-        """Edge kernels for graphs too small to fill the chip (C-alpha pockets, small batches): the
-        features of every 32-edge tile are divided over `csplit` (2 or 4) waves, so a launch has
-        `csplit` times as many, `csplit` times shorter workgroups (csrc/edge_wave.h).  1 restores the
-        throughput configuration.  A property of the deployment, not of a batch: results are
-        deterministic for a given value, but differ in the last bits between values."""
-        if csplit not in (1, 2, 4):
-            raise ValueError("csplit must be 1, 2 or 4")
-        self._edge_csplit = csplit
-        if self._engine is not None:
-            self._engine.set_option("edge_csplit", csplit)
-
     def engine(self) -> HipEngine:
         p = self.egnn.embedding.weight
         if self._engine is None or self._engine.device != p.device:
@@ -183,8 +170,6 @@ class EGNNDynamics(nn.Module):
                     "EGNNDynamics runs on the HIP kernels only: move the module to a GPU "
                     f"(parameters are on {p.device}); there is no CPU fallback")
             self._engine = HipEngine(make_config(**self._hp), self.state_dict(), p.device)
-            if self._edge_csplit != 1:
-                self._engine.set_option("edge_csplit", self._edge_csplit)
         return self._engine
 
     # ---- the reference API -------------------------------------------------

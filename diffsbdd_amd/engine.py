@@ -197,11 +197,6 @@ class HipEngine:
                    "dsbdd_engine_bind_workspace")
         self.caps = caps
 
-    def set_option(self, name, value):
-        """dsbdd_engine_set_option: e.g. ("edge_csplit", 4) for the latency regime (small graphs)."""
-        _lib.check(self.lib.dsbdd_engine_set_option(self.handle, name.encode(), int(value)),
-                   "dsbdd_engine_set_option")
-
     def set_trace(self, n_nodes):
         """Allocate per-block trace buffers (debug / parity tests)."""
         L, H = self.cfg.n_layers, self.cfg.hidden_nf

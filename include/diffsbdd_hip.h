@@ -130,14 +130,6 @@ size_t dsbdd_engine_workspace_bytes(const dsbdd_engine* e, int64_t n_lig, int64_
 int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* workspace, size_t bytes, int64_t n_lig,
                                 int64_t n_pocket, int64_t batch, int64_t edge_capacity);
 
-/* Engine options (integers by name).
- *   "edge_csplit" = 1 | 2 | 4 : column split of the fused edge kernels.  1 (default) is the
- *       throughput configuration; 2 / 4 divide the features of every 32-edge tile over 2 / 4 waves
- *       (workgroups of 64 / 32 edges) for graphs too small to fill the chip -- the latency regime of
- *       the C-alpha models.  Results are deterministic for a given value; the attention / scalar-head
- *       dot products are summed in a different (fixed) order for different values. */
-int dsbdd_engine_set_option(dsbdd_engine* e, const char* name, int32_t value);
-
 /* Optional per-block trace (debug / parity tests): after every EquivariantBlock
  * the node features h [N][H] and coordinates x [N][3] are copied to
  * trace_h + b*N*H / trace_x + b*N*3.  NULL disables. */

@@ -91,13 +91,12 @@ def edge_flips(ours, ref, n):
     return int(np.setxor1d(a.numpy(), b.numpy()).size)
 
 
-@pytest.mark.parametrize("arch,B,saturated,csplit", [
-    ("crossdock_fullatom_cond", 64, True, 1),     # BASELINE configs[2]: the bench line
-    ("moad_fullatom_joint", 64, True, 1),         # configs[4]: H = 192, edge-type table, all rows updated
-    ("crossdock_ca_cond", 32, False, 1),          # configs[1]: the latency regime ...
-    ("crossdock_ca_cond", 32, False, 4),          # ... with the kernels bench.py uses for it (column split)
+@pytest.mark.parametrize("arch,B,saturated", [
+    ("crossdock_fullatom_cond", 64, True),     # BASELINE configs[2]: the bench line
+    ("moad_fullatom_joint", 64, True),         # configs[4]: H = 192, edge-type table, all rows updated
+    ("crossdock_ca_cond", 32, False),          # configs[1]: the latency regime
 ])
-def test_bench_problem_forward_vs_oracle(arch, B, saturated, csplit):
+def test_bench_problem_forward_vs_oracle(arch, B, saturated):
     """One EGNNDynamics.forward of the benchmark problem: eps and every block's
     (h, x) against the oracle, through (i) the public call that builds the radius
     graph on the device and (ii) the teacher-forced edge list."""
@@ -105,7 +104,6 @@ def test_bench_problem_forward_vs_oracle(arch, B, saturated, csplit):
     sd = W.random_state_dict(cfg, 0)
     N = len(ml) + len(mp)
     m = make_dynamics(cfg, sd)
-    m.set_latency_mode(csplit)
     d = dev()
     # (i) public API, device-built edges (second and third call: captured graph / replay)
     args_d = [v.to(d) for v in (xl, xp, t, ml, mp)]

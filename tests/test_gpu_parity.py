@@ -707,44 +707,3 @@ def test_loss_terms_vs_oracle_and_reference_golden(name):
     model.train(True)
     with pytest.raises(NotImplementedError, match="no backward pass"):
         model(*loss_inputs(c))
-
-
-@pytest.mark.parametrize("csplit", [2, 4])
-@pytest.mark.parametrize("name", ["dyn_ca_cond", "dyn_fullatom_cond", "dyn_small_variant"])
-def test_latency_mode_column_split_parity(name, csplit):
-    """EGNNDynamics.set_latency_mode: the edge kernels with the features of a 32-edge tile divided
-    over 2 / 4 waves (csrc/edge_wave.h, CS) -- H = 256 (lane-grouped B reads) and H = 128 (two
-    invariant sub-layers, no attention, E(3) variant) -- against the reference-generated eps and
-    every block's (h, x) of the oracle, teacher-forced and device-built edges, forced multi-tile loop."""
-    import os
-    c = Case(name)
-    sd = c.state_dict()
-    edges = c.t("edges", torch.int64)
-    n = len(c.t("mask_lig")) + len(c.t("mask_pocket"))
-    args = (c.t("xh_lig"), c.t("xh_pocket"), c.t("t"), c.t("mask_lig"), c.t("mask_pocket"))
-    trace = []
-    eo.dynamics_forward(sd, c.cfg, *args, edges=edges, trace=trace)
-    for max_wg in ("0", "8"):
-        os.environ["DSBDD_EDGE_MAX_WG"] = max_wg
-        try:
-            m = make_dynamics(c.cfg, sd)
-            m.set_latency_mode(csplit)
-            th, tx = m.engine().set_trace(n)
-            e_l, e_p, status = m.forward_async(*args, edges=edges)
-            torch.cuda.synchronize()
-            m.engine().clear_trace()
-            f_l, f_p, _ = m.forward_async(*args)              # device-built edges
-            g_l, g_p, _ = m.forward_async(*args)
-        finally:
-            del os.environ["DSBDD_EDGE_MAX_WG"]
-        assert int(status.item()) == 0
-        for i, (h, x) in enumerate(trace):
-            assert (tx[i].cpu() - x).abs().max().item() < TOL, (name, csplit, i)                       # 1e-4
-            assert (th[i].cpu() - h).abs().max().item() < TOL * max(1.0, h.abs().max().item()), (name, csplit, i)
-        assert (e_l.cpu() - c.t("eps_lig")).abs().max().item() < TOL
-        assert (e_p.cpu() - c.t("eps_pocket")).abs().max().item() < TOL
-        assert torch.equal(f_l, g_l) and torch.equal(f_p, g_p)            # deterministic
-        assert (f_l - e_l).abs().max().item() < 1e-4
-    m.set_latency_mode(1)                                                   # back to the throughput kernels
-    b_l, _, _ = m.forward_async(*args, edges=edges)
-    assert (b_l.cpu() - c.t("eps_lig")).abs().max().item() < TOL
