@@ -203,10 +203,17 @@ def main():
             out_l, out_p, lm, pm = model.sample_given_pocket(pocket, n_lig, timesteps=T)
         return sharding.gather_ligands(out_l, lm, lo)
 
+    def barrier():
+        # RCCL's barrier is a collective on a device: name it (one rank per GPU), gloo needs none
+        if torch.distributed.get_backend() == "nccl":
+            torch.distributed.barrier(device_ids=[local_rank])
+        else:
+            torch.distributed.barrier()
+
     def sync():
         torch.cuda.synchronize(device)
         if world > 1:
-            torch.distributed.barrier()
+            barrier()
             torch.cuda.synchronize(device)
 
     red_dev = device if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
@@ -296,7 +303,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        barrier()
         torch.distributed.destroy_process_group()
 
 
