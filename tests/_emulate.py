@@ -232,3 +232,82 @@ def emulate_tile_gemm(Atile, Btile, BM, BN_half_tiles, wave_rows, lda):
                         assert np.isnan(C[rowl, col])
                         C[rowl, col] = acc[i][j][l, r]
     return C
+
+
+# ---------------------------------------------------------------------------
+# aligned edge layout + atomic-free aggregation protocol (csrc/graph.h scan_kernel /
+# edges_kernel<true>, csrc/edge_mlp.h): a host model of the index arithmetic
+# ---------------------------------------------------------------------------
+EDGE_ALIGN = 32
+
+
+def aligned_layout(deg, node_batch, n_lig, B):
+    """row_ptr of the padded layout: the edges of every (sample, node set) segment -- ligand rows of
+    sample b, then (after all ligand segments) pocket rows of sample b -- start at a multiple of 32.
+    deg [N] edges per row; node numbering [ligand | pocket], samples contiguous in each part.
+    Returns (row_ptr [N+1] with row_ptr[N] = padded total, pad_mask [total] True where a slot is padding)."""
+    deg = np.asarray(deg, np.int64)
+    nb = np.asarray(node_batch, np.int64)
+    N = len(deg)
+    scan = np.concatenate([[0], np.cumsum(deg)])
+    seg_of = np.where(np.arange(N) < n_lig, nb, B + nb)                      # segment id of every node
+    seg_len = np.zeros(2 * B, np.int64)
+    np.add.at(seg_len, seg_of, deg)
+    padded = (seg_len + EDGE_ALIGN - 1) // EDGE_ALIGN * EDGE_ALIGN
+    seg_base = np.concatenate([[0], np.cumsum(padded)])
+    first = {}
+    for i in range(N):
+        first.setdefault(int(seg_of[i]), i)
+    row_ptr = np.zeros(N + 1, np.int64)
+    for i in range(N):
+        k = int(seg_of[i])
+        row_ptr[i] = seg_base[k] + scan[i] - scan[first[k]]
+    row_ptr[N] = seg_base[-1]
+    pad = np.ones(int(seg_base[-1]), bool)
+    for i in range(N):
+        pad[row_ptr[i]:row_ptr[i] + deg[i]] = False
+    return row_ptr, pad
+
+
+def tile_protocol_aggregate(values, erow, row_ptr, deg):
+    """The kernels' aggregation: per 32-slot wave tile, segmented sums in slot order; the segment that
+    holds a row's first edge goes to agg[row], a first segment that continues the previous tile's row
+    goes to head[tile]; completion adds head[T0+1 .. T1] in tile order.  values [slots, F] float32
+    (padding slots have erow = -1).  Returns agg [N, F] float32."""
+    values = np.asarray(values, np.float32)
+    n_slots, F = values.shape
+    N = len(deg)
+    n_tiles = (n_slots + 31) // 32
+    agg = np.zeros((N, F), np.float32)
+    head = np.zeros((n_tiles + 1, F), np.float32)
+    for T in range(n_tiles):
+        lo, hi = 32 * T, min(32 * T + 32, n_slots)
+        prev = erow[lo - 1] if lo > 0 else -1
+        cur, acc, first_seg = -1, None, True
+
+        def flush():
+            nonlocal first_seg
+            if cur >= 0:
+                if first_seg and cur == prev:
+                    head[T] = acc
+                else:
+                    agg[cur] = acc
+                first_seg = False
+        for s in range(lo, hi):
+            r = int(erow[s])
+            if r != cur:
+                flush()
+                cur, acc = r, np.zeros(F, np.float32)
+            if r >= 0:
+                acc = (acc + values[s]).astype(np.float32)
+        flush()
+    out = np.zeros((N, F), np.float32)
+    for i in range(N):
+        if deg[i] == 0:
+            continue
+        t0, t1 = row_ptr[i] // 32, (row_ptr[i] + deg[i] - 1) // 32
+        v = agg[i].copy()
+        for T in range(t0 + 1, t1 + 1):
+            v = (v + head[T]).astype(np.float32)
+        out[i] = v
+    return out

@@ -277,3 +277,70 @@ def test_training_forward_refuses_autograd_and_needs_a_gpu():
     ddpm.eval()
     with pytest.raises(_lib.HipLibraryError):
         ddpm(lig, poc)
+
+
+def test_aligned_edge_layout_and_atomic_free_aggregation_protocol():
+    """Host model of csrc/graph.h (segment-aligned row offsets) and csrc/edge_mlp.h (tile partial sums
+    + ordered head sums): every row's edges are found at [row_ptr, row_ptr + deg), segments start at
+    multiples of 32, the protocol reproduces the plain per-row sum exactly on integer-valued data, and a
+    sample's rows get bit-identical sums whatever else is in the batch (the tile cut of a row depends only
+    on its own sample)."""
+    rng = np.random.default_rng(0)
+
+    def problem(n_lig_per, n_poc_per):
+        B = len(n_lig_per)
+        nb = np.concatenate([np.repeat(np.arange(B), n_lig_per), np.repeat(np.arange(B), n_poc_per)])
+        n_lig = int(np.sum(n_lig_per))
+        return B, nb, n_lig
+
+    def degrees(seed, n):
+        return np.random.default_rng(seed).integers(0, 90, size=n)          # rows of up to 3 tiles, some empty
+
+    sizes_l, sizes_p = [5, 0, 9, 7], [40, 33, 0, 51]
+    B, nb, n_lig = problem(sizes_l, sizes_p)
+    # per-node degrees / per-edge values drawn from the node's (sample, local index): independent of the batch
+    local = np.concatenate([np.arange(n) for n in sizes_l] + [np.arange(n) for n in sizes_p])
+    part = np.concatenate([np.zeros(n_lig, int), np.ones(len(nb) - n_lig, int)])
+
+    def node_deg(b, p, i):
+        return int(np.random.default_rng(1000 * b + 500 * p + i).integers(0, 90))
+
+    def node_vals(b, p, i, d):
+        return np.random.default_rng(77 + 1000 * b + 500 * p + i).normal(size=(d, 4)).astype(np.float32)
+
+    def run(samples):
+        keep = np.isin(nb, samples)
+        nbs = np.searchsorted(np.asarray(samples), nb[keep])                 # relabel 0..len-1
+        nl = int((keep[:n_lig]).sum())
+        idx = np.nonzero(keep)[0]
+        deg = np.array([node_deg(nb[i], part[i], local[i]) for i in idx])
+        row_ptr, pad = em.aligned_layout(deg, nbs, nl, len(samples))
+        assert row_ptr[-1] % 32 == 0 and len(pad) == row_ptr[-1]
+        erow = np.full(int(row_ptr[-1]), -1, np.int64)
+        vals = np.zeros((int(row_ptr[-1]), 4), np.float32)
+        for r, i in enumerate(idx):
+            erow[row_ptr[r]:row_ptr[r] + deg[r]] = r
+            vals[row_ptr[r]:row_ptr[r] + deg[r]] = node_vals(nb[i], part[i], local[i], deg[r])
+        assert np.array_equal(erow < 0, pad)
+        # every (sample, node set) segment starts at a tile boundary
+        seg_first = {}
+        for r, i in enumerate(idx):
+            seg_first.setdefault((int(part[i]), int(nbs[r])), int(row_ptr[r]))
+        assert all(v % 32 == 0 for v in seg_first.values())
+        out = em.tile_protocol_aggregate(vals, erow, row_ptr, deg)
+        return idx, deg, vals, erow, out
+
+    idx, deg, vals, erow, out = run([0, 1, 2, 3])
+    # exact on integers: protocol == plain scatter add
+    ivals = np.round(vals * 8).astype(np.float32)
+    rp, _ = em.aligned_layout(deg, np.searchsorted([0, 1, 2, 3], nb), n_lig, 4)
+    ref = np.zeros((len(deg), 4), np.float32)
+    for s in range(len(erow)):
+        if erow[s] >= 0:
+            ref[erow[s]] += ivals[s]
+    assert np.array_equal(em.tile_protocol_aggregate(ivals, erow, rp, deg), ref)
+    # batch invariance, bitwise: samples {0, 2} alone, and sample 3 alone
+    for sub in ([0, 2], [3], [1, 3]):
+        idx_s, _, _, _, out_s = run(sub)
+        pos = {int(i): r for r, i in enumerate(idx)}
+        assert np.array_equal(out_s, np.stack([out[pos[int(i)]] for i in idx_s])), sub
