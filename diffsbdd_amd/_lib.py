@@ -98,6 +98,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own copy of the HIP runtime (libamdhip64); loading our library before it
+    # would pull in /opt/rocm's copy as well, and kernels launched through one runtime do not see the
+    # device the other one initialised ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "

@@ -195,6 +195,9 @@ __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(
   if (m0 >= M || n0 >= p.N) return;   // uniform per workgroup
 
   auto streamB = [&](int ks, int buf) {
+#ifdef DSBDD_DIAG_NODE_NODMA
+    return;   // DIAGNOSTIC ONLY (wrong results): the weight slices are never streamed
+#endif
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int f = t + kThreads * i;                // float4 index: row f/RQ, column chunk f%RQ
@@ -212,8 +215,14 @@ __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(
   auto loadA = [&](int ks, float4 (&dst)[NG]) {
     const int k0 = ks * BK;                          // a K step never straddles A1 | A2
     const float* src = k0 < p.K1 ? a1 + k0 : a2 + (k0 - p.K1);
+#ifdef DSBDD_DIAG_NODE_NOA
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dst[g] = make_float4(0.1f, 0.2f, 0.3f, (float)ks);   // DIAGNOSTIC ONLY (wrong results)
+    (void)src;
+#else
 #pragma unroll
     for (int g = 0; g < NG; ++g) dst[g] = ld4(src + 8 * g);
+#endif
   };
 
   f32x16 acc[CT];
@@ -250,7 +259,11 @@ __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
+#ifdef DSBDD_DIAG_NODE_NOBARRIER
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // DIAGNOSTIC ONLY (racy): vmcnt(0) without the workgroup barrier
+#else
     __syncthreads();
+#endif
   }
 
   // epilogue.  C may alias R (the node MLP's residual is updated in place), so the compiler
