@@ -711,3 +711,67 @@ def test_loss_terms_vs_oracle_and_reference_golden(name):
     model.train(True)
     with pytest.raises(NotImplementedError, match="no backward pass"):
         model(*loss_inputs(c))
+
+
+def _replay(c, prefix):
+    n = int(c.z["n_" + prefix])
+    return do.NoiseReplay([torch.from_numpy(c.z[f"{prefix}_{i}"]) for i in range(n)])
+
+
+def _dict(c, prefix):
+    return {k: c.t(prefix + k) for k in ("x", "one_hot", "size", "mask")}
+
+
+def test_cond_api_variants_vs_reference_golden():
+    """Reference-generated vectors (tests/golden/make_golden_variants.py) for the conditional API variants:
+    chain frames (return_frames = timesteps, conditional_model.py:518-555), RePaint centred at the pocket with
+    frames (:557-686, center='pocket'), and SimpleConditionalDDPM (:702-746: no COM projection)."""
+    from diffsbdd_amd.conditional_model import SimpleConditionalDDPM
+    c = Case("ddpm_variants_cond")
+    T = int(c.z["timesteps"])
+    model = make_ddpm(c)
+    model.set_noise_source(_replay(c, "fnoise"))
+    fl, fp, _, _ = model.sample_given_pocket(_dict(c, "pocket_"), c.t("num_nodes_lig"), return_frames=T, timesteps=T)
+    assert fl.shape == c.t("frames_lig").shape and fp.shape == c.t("frames_pocket").shape
+    assert excess(fl[..., :3], c.t("frames_lig")[..., :3], atol=1e-3, rtol=1e-4) <= 0         # 4 free-running steps
+    assert excess(fp[..., :3], c.t("frames_pocket")[..., :3], atol=1e-3, rtol=1e-4) <= 0
+    assert torch.equal(fl[0].cpu()[:, 3:].long(), c.t("frames_lig")[0][:, 3:].long())        # final frame: one-hot
+    assert excess(fl[1:, :, 3:], c.t("frames_lig")[1:, :, 3:], atol=1e-3, rtol=1e-4) <= 0     # intermediate z_h
+    model.set_noise_source(_replay(c, "pnoise"))
+    pl, pp, _, _ = model.inpaint(_dict(c, "ligand_"), _dict(c, "pocket_"), c.t("lig_fixed"), resamplings=2,
+                                 return_frames=T, timesteps=T, center="pocket")
+    assert excess(pl[..., :3], c.t("pocketc_lig")[..., :3], atol=1e-3, rtol=1e-4) <= 0
+    assert excess(pp[..., :3], c.t("pocketc_pocket")[..., :3], atol=1e-3, rtol=1e-4) <= 0
+    assert torch.equal(pl[0].cpu()[:, 3:].long(), c.t("pocketc_lig")[0][:, 3:].long())
+    cfg, dd = c.cfg, c.ddpm
+    simple = SimpleConditionalDDPM(dynamics=make_dynamics(cfg, c.state_dict()), atom_nf=cfg["atom_nf"],
+                                   residue_nf=cfg["residue_nf"], n_dims=3, size_histogram=np.ones((4, 8)),
+                                   timesteps=dd["timesteps"], noise_schedule=dd["noise_schedule"],
+                                   noise_precision=dd["noise_precision"], loss_type="l2",
+                                   norm_values=dd["norm_values"]).to(dev())
+    simple.set_noise_source(_replay(c, "snoise"))
+    sl, sp, _, _ = simple.sample_given_pocket(_dict(c, "pocket_"), c.t("num_nodes_lig"), timesteps=T)
+    assert excess(sl[:, :3], c.t("simple_lig")[:, :3], atol=1e-3, rtol=1e-4) <= 0
+    assert torch.equal(sl.cpu()[:, 3:].long(), c.t("simple_lig")[:, 3:].long())
+    assert excess(sp[:, :3], c.t("simple_pocket")[:, :3], atol=1e-3, rtol=1e-4) <= 0
+
+
+def test_joint_api_variants_vs_reference_golden():
+    """Joint model: chain frames of sample() (en_diffusion.py:618-651) and RePaint with jump_length = 2,
+    resamplings = 2, some ligand atoms and one sample's pocket fixed (en_diffusion.py:676-837)."""
+    c = Case("ddpm_variants_joint")
+    model = make_ddpm(c)
+    T = int(c.z["timesteps"])
+    model.set_noise_source(_replay(c, "fnoise"))
+    fl, fp, _, _ = model.sample(2, c.t("num_nodes_lig"), c.t("num_nodes_pocket"), return_frames=T, timesteps=T)
+    assert fl.shape == c.t("frames_lig").shape
+    assert excess(fl[..., :3], c.t("frames_lig")[..., :3], atol=1e-3, rtol=1e-4) <= 0
+    assert excess(fp[..., :3], c.t("frames_pocket")[..., :3], atol=1e-3, rtol=1e-4) <= 0
+    assert torch.equal(fl[0].cpu()[:, 3:].long(), c.t("frames_lig")[0][:, 3:].long())
+    model.set_noise_source(_replay(c, "jnoise"))
+    jl, jp, _, _ = model.inpaint(_dict(c, "ligand_"), _dict(c, "inp_pocket_"), c.t("lig_fixed"), c.t("pocket_fixed"),
+                                 resamplings=2, jump_length=2, timesteps=int(c.z["jump_timesteps"]))
+    assert excess(jl[:, :3], c.t("jump_lig")[:, :3], atol=1e-3, rtol=1e-4) <= 0
+    assert torch.equal(jl.cpu()[:, 3:].long(), c.t("jump_lig")[:, 3:].long())
+    assert excess(jp[:, :3], c.t("jump_pocket")[:, :3], atol=1e-3, rtol=1e-4) <= 0
+    assert torch.equal(jp.cpu()[:, 3:].long(), c.t("jump_pocket")[:, 3:].long())
