@@ -80,6 +80,8 @@ struct EdgeArgs {
   size_t xhead_stride;
   float norm_factor;
   int* tile_ctr;          // work-queue counters, all zero between launches (graph.h: kTileCtrInts)
+  // -DDSBDD_TIMESTAMPS builds only: [64 workgroups][16 marks] of wall_clock64() (100 MHz) for this launch
+  unsigned long long* ts;
   // edge_wave_kernel, MODE_COORD with two MLPs: alternate workgroups take the coordinate /
   // cross-product MLP of a tile (twice as many, half as long work items: better balance when
   // the masked edge prefix is only a few tiles per CU); the two terms of trans are linear

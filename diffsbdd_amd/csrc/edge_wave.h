@@ -112,6 +112,13 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int swb = (bperm && CT == 8) ? ((j >> 3) & 1) : 0;          // this lane reads its halves swapped
   auto feat = [&](int c) { return ((c ^ (4 * swb)) * 32) + j; };    // feature held by accumulator tile c
 
+#ifdef DSBDD_TIMESTAMPS
+  int ts_n = 0;
+#define DSBDD_TS() do { if (p.ts && t == 0 && blockIdx.x < 64 && ts_n < 16) p.ts[blockIdx.x * 16 + ts_n++] = wall_clock64(); } while (0)
+#else
+#define DSBDD_TS() do { } while (0)
+#endif
+  DSBDD_TS();                                            // mark 0: kernel entry (after the vector loads were issued)
   const int E = min(*p.e_count, p.e_cap);
   const int ntiles = (E + BMB - 1) / BMB;
   const int xcd = blockIdx.x & 7;
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   fetch_x();
   commit_edge();
   __syncthreads();          // sV + slice 0 visible
+  DSBDD_TS();               // mark 1: prologue done (vectors, first W2^T slice, first edge)
   int bslice = 0;           // running slice counter (buffer = bslice & 1)
 
   const float* Pp = p.mlp[qsel].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + 4 * half;
@@ -308,6 +316,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #else
       __syncthreads();
 #endif
+      DSBDD_TS();           // marks 2 .. NK+1: end of every K step
     }
 
     const bool last_unit = tile_ends && !has_next;
@@ -492,6 +501,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       }
     }
 
+    DSBDD_TS();             // epilogue of this unit done
     // advance to the next unit
     if (tile_ends) {
       if (last_unit) break;

@@ -73,6 +73,8 @@ struct dsbdd_engine {
   int edge_max_wg = 0;  // test hook (DSBDD_EDGE_MAX_WG): cap on the persistent edge grid, so that small problems
                         // run several tiles per workgroup (the path large batches take)
   int64_t n_replay = 0, n_capture = 0, n_eager = 0;
+  unsigned long long* ts_buf = nullptr;   // -DDSBDD_TIMESTAMPS builds: [launches][64][16] marks of the edge kernels
+  int ts_cap = 0, ts_next = 0;
   hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
                                       // legacy default stream, which cannot be captured)
   // captured graphs hold the raw weight / workspace pointers of the moment they were captured
@@ -236,6 +238,15 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->w2tp_ready = false;
   return DSBDD_OK;
 }
+
+#ifdef DSBDD_TIMESTAMPS
+// debug builds only (not part of the ABI header): device buffer of [capacity][64][16] uint64 marks
+int dsbdd_debug_set_timestamps(dsbdd_engine* e, unsigned long long* buf, int capacity) {
+  if (!e) return DSBDD_ERR_ARG;
+  e->ts_buf = buf; e->ts_cap = capacity; e->ts_next = 0;
+  return DSBDD_OK;
+}
+#endif
 
 int dsbdd_engine_set_trace(dsbdd_engine* e, float* th, float* tx) {
   if (!e) return DSBDD_ERR_ARG;
@@ -509,6 +520,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
       ea.agg = e->agg; ea.agg_head = e->agg_head; ea.tile_ctr = e->tile_ctr;
       ea.norm_factor = c.normalization_factor;
+      if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
       const bool timed = e->time_now && e->ev_used + 2 <= e->ev.size();
       if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
       HIP_TRY(launch_edge(e, s, MODE_GCL, ea, edge_bound));
@@ -564,6 +576,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = (size_t)e->cap_tiles * 4;
       ea.tile_ctr = e->tile_ctr; ea.norm_factor = c.normalization_factor;
       ea.pass_split = e->coord_split;
+      if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
      
       HIP_TRY(launch_edge(e, s, MODE_COORD, ea, edge_bound));
       if (n_upd > 0) {
