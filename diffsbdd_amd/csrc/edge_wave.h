@@ -203,6 +203,22 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     }
   };
 
+  // B values of one MFMA step: column j of every column tile (plain layout: CT 4-byte reads at stride 32) or
+  // the lane-grouped copy (one or two 16-byte reads)
+  auto read_b = [&](const float* brow, float (&bv)[CT]) {
+    if constexpr (BPERM) {
+      const float4 lo = *reinterpret_cast<const float4*>(brow);
+      bv[0] = lo.x; bv[1] = lo.y; bv[2] = lo.z; bv[3] = lo.w;
+      if constexpr (CT == 8) {
+        const float4 hi = *reinterpret_cast<const float4*>(brow + 4 - 8 * swb);
+        bv[4] = hi.x; bv[5] = hi.y; bv[6] = hi.z; bv[7] = hi.w;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bv[c] = brow[c * 32];
+    }
+  };
+
   // prologue: first W2^T slice, first edge, first P/Q chunk
   streamB(0, 0, 0);
   fetch_idx(cbase + kx);
@@ -291,20 +307,10 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
           for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], a[(i + c) & 3], acc[c]);   // DIAGNOSTIC ONLY
 #else
-          if constexpr (BPERM) {
-            float bv[CT];
-            const float4 lo = *reinterpret_cast<const float4*>(brow);
-            bv[0] = lo.x; bv[1] = lo.y; bv[2] = lo.z; bv[3] = lo.w;
-            if constexpr (CT == 8) {
-              const float4 hi = *reinterpret_cast<const float4*>(brow + 4 - 8 * swb);
-              bv[4] = hi.x; bv[5] = hi.y; bv[6] = hi.z; bv[7] = hi.w;
-            }
+          float bv[CT];
+          read_b(brow, bv);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], bv[c], acc[c]);
-          } else {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], brow[c * 32], acc[c]);
-          }
+          for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], bv[c], acc[c]);
 #endif
         }
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
