@@ -20,6 +20,19 @@ from .en_diffusion import EnVariationalDiffusion, num_nodes_to_batch_mask, seg_m
 __all__ = ["ConditionalDDPM", "SimpleConditionalDDPM"]
 
 
+def _chain(fn):
+    """Sampling entry point: whatever happens, the engine's pocket frame of this chain is released."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            self._end_chain()
+    return wrapped
+
+
 class ConditionalDDPM(EnVariationalDiffusion):
     """Conditional diffusion module."""
 
@@ -141,6 +154,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         return pocket
 
     @torch.no_grad()
+    @_chain
     def sample_given_pocket(self, pocket, num_nodes_lig, return_frames=1, timesteps=None):
         timesteps = self.T if timesteps is None else timesteps
         assert 0 < return_frames <= timesteps
@@ -153,7 +167,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         pm = pocket['mask']
         xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
         lig_mask = num_nodes_to_batch_mask(n, num_nodes_lig, dev).contiguous()
-        lig_mask, pm = self._begin_chain(lig_mask, pm, n)
+        lig_mask, pm = self._begin_chain(lig_mask, pm, n, pocket=pocket)
 
         # z_T ~ N(pocket COM, I), then ligand-COM-free (conditional_model.py:501-508)
         mu_x = self._seg_mean3(pocket['x'], pm, n)
@@ -189,6 +203,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
 
     # ---- RePaint-style inpainting (conditional_model.py:557-686) ---------------------------------------
     @torch.no_grad()
+    @_chain
     def inpaint(self, ligand, pocket, lig_fixed, resamplings=1, return_frames=1, timesteps=None,
                 center='ligand'):
         timesteps = self.T if timesteps is None else timesteps
@@ -202,7 +217,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         fixed_f = lig_fixed.to(dev).float().reshape(-1).contiguous()
         n = len(ligand['size'])
         ligand, pocket = self.normalize(ligand, pocket)
-        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
+        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n, pocket=pocket)
 
         xh0_pocket = torch.cat([pocket['x'], pocket['one_hot']], dim=1)
         com_pocket_0 = self._seg_mean3(pocket['x'], pm, n)
@@ -265,13 +280,14 @@ class ConditionalDDPM(EnVariationalDiffusion):
         return self.noised_representation(xh0_lig, xh0_pocket, ligand['mask'], pocket['mask'], gamma_t)
 
     @torch.no_grad()
+    @_chain
     def diversify(self, ligand, pocket, noising_steps):
         dev = self._hip_device(None)
         pocket = self._prepare_pocket(pocket, dev)
         ligand = self._prepare_pocket(ligand, dev)
         ligand, pocket = self.normalize(ligand, pocket)
         n = len(pocket['size'])
-        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n)
+        lm, pm = self._begin_chain(ligand['mask'], pocket['mask'], n, pocket=pocket)
         ligand['mask'], pocket['mask'] = lm, pm
         # partially_noised_ligand (conditional_model.py:332-362) with the fused kernels: centre at the
         # ligand COM (a = 1, sigma = 0), then q(z_t | x) at t = noising_steps / T

@@ -114,4 +114,47 @@ __global__ __launch_bounds__(kThreads) void agg_complete_kernel(float* agg, cons
   }
 }
 
+
+// Block 0 of a pocket-conditioned chain ("pocket frame", engine.hip): the aggregate of a node is
+//     [ A: sum over its edges with a ligand endpoint ]  +  [ B: sum over its pocket-pocket edges ]
+// A comes from the message stage on the ligand-endpoint list (agg / head_a, rows indexed by node),
+// B from the message stage on the static pocket-pocket list of the node's TWIN -- itself, or the same
+// pocket atom of the sample that represents a group of identical pockets (agg_b rows indexed by the
+// twin's node id, row_ptr_b / deg_b by the twin's index in the pocket-pocket problem).  Both parts are
+// completed in tile order; ligand nodes have no B part.
+__global__ __launch_bounds__(kThreads) void agg_complete2_kernel(
+    float* agg, const float* head_a, const int* row_ptr_a, const int* deg_a, const float* agg_b,
+    const float* head_b, const int* row_ptr_b, const int* deg_b, const int* twin_local, int twin_base,
+    int n_lig, int n_rows, int H) {
+  const int row = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int da = deg_a[row], sa = row_ptr_a[row];
+  const int a0 = sa >> 5, a1 = (sa + da - 1) >> 5;
+  int db = 0, sb = 0, tw = 0;
+  if (row >= n_lig) {
+    const int tl = twin_local[row - n_lig];
+    db = deg_b[tl]; sb = row_ptr_b[tl]; tw = twin_base + tl;
+  }
+  const int b0 = sb >> 5, b1 = (sb + db - 1) >> 5;
+  for (int k = 4 * lane; k < H; k += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (da > 0) {
+      v = ld4(agg + (size_t)row * H + k);
+      for (int T = a0 + 1; T <= a1; ++T) {
+        const float4 h = ld4(head_a + (size_t)T * H + k);
+        v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+      }
+    }
+    if (db > 0) {
+      float4 u = ld4(agg_b + (size_t)tw * H + k);
+      for (int T = b0 + 1; T <= b1; ++T) {
+        const float4 h = ld4(head_b + (size_t)T * H + k);
+        u.x += h.x; u.y += h.y; u.z += h.z; u.w += h.w;
+      }
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(agg + (size_t)row * H + k) = v;
+  }
+}
+
 }  // namespace dsbdd

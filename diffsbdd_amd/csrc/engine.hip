@@ -46,6 +46,15 @@ struct dsbdd_engine {
   float *ed0, *x, *x_in, *xagg, *mean, *h0, *enc_tmp, *h, *t1, *agg, *pq, *pqg, *hout, *w2tp;
   float *agg_head, *xagg_head;          // partial sums of rows continuing from the previous wave tile
   int *scan_tmp, *seg_base, *tile_ctr;
+  // second per-call list (edges with a ligand endpoint) and the static pocket-pocket list of the pocket frame
+  int *erow2, *ecol2, *row_ptr2, *deg2, *scan_tmp2, *seg_base2;
+  int *erow3, *ecol3, *row_ptr3, *deg3, *scan_tmp3, *seg_base3, *node_batch3, *lig_off3, *poc_off3, *twin;
+  float *ed02, *ed03, *xcanon, *aggB, *agg_headB;
+  // pocket frame of the running chain (dsbdd_engine_set_pocket_frame): raw pocket coordinates are rigid in
+  // pocket-conditioning mode, so block 0's pocket-pocket messages are evaluated on them, separately
+  bool frame = false;
+  int64_t frame_nlig = 0, frame_npoc = 0, frame_batch = 0, frame_n3 = 0, frame_cap3 = 0;
+  int frame_shared = 0;
   int64_t cap_tiles = 0;                // wave tiles (32 edges) of the edge capacity
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
@@ -105,7 +114,7 @@ static int eq_slot(const dsbdd_config& c, int block, int which) {
 }
 
 struct WsLayout {
-  size_t off[32];
+  size_t off[64];
   size_t total;
 };
 
@@ -126,7 +135,13 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * 2 * H * 4,                                                                        // 22 pqg (GCL P|Q)
       (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 4,                                      // 23 lane-grouped W2^T copies
       (size_t)T * H * 4, (size_t)T * 2 * 16,                                                        // 24 agg_head, 25 xagg_head[2][T][4]
-      (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4};                      // 26 scan_tmp 27 seg_base 28 tile_ctr
+      (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4,                       // 26 scan_tmp 27 seg_base 28 tile_ctr
+      (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 29-33 list 2: erow ecol ed0 row_ptr deg
+      (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4,                                                 // 34 scan_tmp2 35 seg_base2
+      (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 36-40 list 3
+      (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4,                                                 // 41 scan_tmp3 42 seg_base3
+      (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4,                       // 43 node_batch3 44 lig_off3 45 poc_off3 46 twin
+      (size_t)N * 12, (size_t)N * H * 4, (size_t)T * H * 4};                                        // 47 xcanon 48 aggB 49 agg_headB
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -134,6 +149,12 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
   L.total = o;
   return L;
 }
+
+static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int B, const dsbdd_config& c,
+                            const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
+                            int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
+                            int* act_flag = nullptr, int* scan_tmp = nullptr, int* seg_base = nullptr,
+                            const EdgeList2* list2 = nullptr, int id_offset = 0);
 
 extern "C" {
 
@@ -235,6 +256,16 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->agg_head = (float*)(b + L.off[24]); e->xagg_head = (float*)(b + L.off[25]);
   e->scan_tmp = (int*)(b + L.off[26]); e->seg_base = (int*)(b + L.off[27]); e->tile_ctr = (int*)(b + L.off[28]);
   e->cap_tiles = E / 32 + 2;
+  e->erow2 = (int*)(b + L.off[29]); e->ecol2 = (int*)(b + L.off[30]); e->ed02 = (float*)(b + L.off[31]);
+  e->row_ptr2 = (int*)(b + L.off[32]); e->deg2 = (int*)(b + L.off[33]);
+  e->scan_tmp2 = (int*)(b + L.off[34]); e->seg_base2 = (int*)(b + L.off[35]);
+  e->erow3 = (int*)(b + L.off[36]); e->ecol3 = (int*)(b + L.off[37]); e->ed03 = (float*)(b + L.off[38]);
+  e->row_ptr3 = (int*)(b + L.off[39]); e->deg3 = (int*)(b + L.off[40]);
+  e->scan_tmp3 = (int*)(b + L.off[41]); e->seg_base3 = (int*)(b + L.off[42]);
+  e->node_batch3 = (int*)(b + L.off[43]); e->lig_off3 = (int*)(b + L.off[44]); e->poc_off3 = (int*)(b + L.off[45]);
+  e->twin = (int*)(b + L.off[46]);
+  e->xcanon = (float*)(b + L.off[47]); e->aggB = (float*)(b + L.off[48]); e->agg_headB = (float*)(b + L.off[49]);
+  e->frame = false;               // a pocket frame lives in the workspace
   e->w2tp_ready = false;
   return DSBDD_OK;
 }
@@ -247,6 +278,45 @@ int dsbdd_debug_set_timestamps(dsbdd_engine* e, unsigned long long* buf, int cap
   return DSBDD_OK;
 }
 #endif
+
+int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_pocket, const int64_t* mask_frame,
+                                  const int32_t* twin_local, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                                  int64_t n_frame, int64_t batch_frame, int64_t edge_bound_frame) {
+  if (!e || !x_pocket || !mask_frame || !twin_local) return fail(DSBDD_ERR_ARG, "null argument");
+  if (!e->ws) return fail(DSBDD_ERR_STATE, "workspace not bound");
+  if (e->cfg.update_pocket_coords) return fail(DSBDD_ERR_STATE, "a pocket frame needs rigid pocket coordinates");
+  if (n_lig < 0 || n_lig > e->cap_lig || n_pocket < 1 || n_pocket > e->cap_poc || batch < 1 || batch > e->cap_batch ||
+      n_frame < 1 || n_frame > n_pocket || batch_frame < 1 || batch_frame > batch || edge_bound_frame < 1 ||
+      edge_bound_frame > e->cap_edges)
+    return fail(DSBDD_ERR_CAPACITY, "pocket frame exceeds the bound workspace");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  e->drop_graphs();
+  e->frame = false;
+  const int n3 = (int)n_frame, b3 = (int)batch_frame;
+  // raw pocket coordinates at the pocket rows of an [N][3] array (node ids of the edge kernels are global)
+  HIP_TRY(hipMemcpyAsync(e->xcanon + 3 * n_lig, x_pocket, (size_t)n_pocket * 12, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->twin, twin_local, (size_t)n_pocket * 4, hipMemcpyDeviceToDevice, s));
+  // the pocket-pocket radius graph of the frame: a pocket-only problem (no ligand nodes), node ids + n_lig
+  const int work = n3 > b3 + 1 ? n3 : b3 + 1;
+  hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, (const int64_t*)nullptr, 0, mask_frame,
+                     n3, b3, e->node_batch3, e->lig_off3, e->poc_off3, (int*)nullptr);
+  HIP_TRY(hipGetLastError());
+  int rc = build_edges_impl(s, x_pocket, 0, n3, b3, e->cfg, e->node_batch3, e->lig_off3, e->poc_off3, e->deg3,
+                            e->row_ptr3, e->erow3, e->ecol3, e->ed03, e->cap_edges, e->tile_ctr + 24, nullptr,
+                            e->scan_tmp3, e->seg_base3, nullptr, (int)n_lig);
+  if (rc) return rc;
+  e->frame_nlig = n_lig; e->frame_npoc = n_pocket; e->frame_batch = batch;
+  e->frame_n3 = n3; e->frame_cap3 = edge_bound_frame;
+  e->frame = true;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_clear_pocket_frame(dsbdd_engine* e) {
+  if (!e) return fail(DSBDD_ERR_ARG, "null argument");
+  if (e->frame) e->drop_graphs();
+  e->frame = false;
+  return DSBDD_OK;
+}
 
 int dsbdd_engine_set_trace(dsbdd_engine* e, float* th, float* tx) {
   if (!e) return DSBDD_ERR_ARG;
@@ -371,7 +441,7 @@ static Cutoffs cutoffs_of(const dsbdd_config& c) {
 static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int B, const dsbdd_config& c,
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
-                            int* act_flag = nullptr, int* scan_tmp = nullptr, int* seg_base = nullptr) {
+                            int* act_flag, int* scan_tmp, int* seg_base, const EdgeList2* list2, int id_offset) {
   const int waves_per_block = kThreads / 64;
   int blocks = (N + waves_per_block - 1) / waves_per_block;
   if (blocks > 4096) blocks = 4096;
@@ -381,15 +451,18 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   // boundary (graph.h scan_kernel); without: a compact list (the public dsbdd_build_edges)
   const int aligned = scan_tmp && seg_base;
   SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, aligned ? seg_base : nullptr};
+  EdgeList2 l2{};
+  if (list2 && aligned) l2 = *list2;
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr);
+                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr, l2, 0);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg,
+                     (const int*)l2.deg, l2.row_ptr, l2.seg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
-                     (int*)nullptr, sg, row_ptr);
+                     (int*)nullptr, sg, row_ptr, l2, id_offset);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -414,6 +487,10 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // node, so their first-layer projections are needed for a subset of the nodes only
   const bool subset = !c.update_pocket_coords;
 
+  // Pocket frame (pocket-conditioning chains): block 0's first message stage runs on the edges with a
+  // ligand endpoint; the pocket-pocket part comes from the static list built by set_pocket_frame.
+  const bool split0 = e->frame && subset && !ext && n_lig == e->frame_nlig && n_pocket == e->frame_npoc &&
+                      batch == e->frame_batch;
   // ---- masks -> offsets, split inputs ---------------------------------------
   {
     const int work = N > B + 1 ? N : B + 1;
@@ -445,7 +522,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                          ext_col, (int)ext_n_edges, (const float*)e->x, e->erow, e->ecol, e->ed0, e->deg);
       HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->deg, e->row_ptr, N, SegAlign{});
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->deg, e->row_ptr, N, SegAlign{},
+                       (const int*)nullptr, (int*)nullptr, SegAlign{});
     HIP_TRY(hipGetLastError());
     edge_bound = ext_n_edges > 0 ? ext_n_edges : 1;
     if (subset) {
@@ -458,13 +536,17 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       }
     }
   } else {
+    EdgeList2 l2{e->deg2, e->row_ptr2, e->erow2, e->ecol2, e->ed02, (int)e->cap_edges,
+                 SegAlign{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->scan_tmp2, e->seg_base2}};
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
                               e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
-                              subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base);
+                              subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base,
+                              split0 ? &l2 : nullptr);
     if (rc) return rc;
   }
   if (subset) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N, SegAlign{});
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N, SegAlign{},
+                       (const int*)nullptr, (int*)nullptr, SegAlign{});
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(compact_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const int*)e->act_flag,
                        (const int*)e->act_ptr, e->act_list, N);
@@ -520,18 +602,35 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
       ea.agg = e->agg; ea.agg_head = e->agg_head; ea.tile_ctr = e->tile_ctr;
       ea.norm_factor = c.normalization_factor;
-      if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
-      const bool timed = e->time_now && e->ev_used + 2 <= e->ev.size();
-      if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
-      HIP_TRY(launch_edge(e, s, MODE_GCL, ea, edge_bound));
-      if (timed) {
-        HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
-        e->ev_used += 2;
+      if (split0 && blk == 0 && sub == 0) {
+        // (A) edges with a ligand endpoint, current coordinates -> agg / agg_head
+        EdgeArgs a2 = ea;
+        a2.erow = e->erow2; a2.ecol = e->ecol2; a2.ed0 = e->ed02; a2.e_count = e->row_ptr2 + N;
+        HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
+        // (B) pocket-pocket edges of the frame (all samples, or the representative of identical pockets),
+        //     raw pocket coordinates -> aggB / agg_headB
+        EdgeArgs a3 = ea;
+        a3.erow = e->erow3; a3.ecol = e->ecol3; a3.ed0 = e->ed03; a3.e_count = e->row_ptr3 + e->frame_n3;
+        a3.x = e->xcanon; a3.agg = e->aggB; a3.agg_head = e->agg_headB;
+        HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
+        hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
+                           (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
+                           (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,
+                           (const int*)e->deg3, (const int*)e->twin, nlig, nlig, N, H);
+        HIP_TRY(hipGetLastError());
+      } else {
+        const bool timed = e->time_now && e->ev_used + 2 <= e->ev.size();
+        if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
+        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, edge_bound));
+        if (timed) {
+          HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
+          e->ev_used += 2;
+        }
+        // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
+        hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
+                           (const float*)e->agg_head, (const int*)e->row_ptr, (const int*)e->deg, N, H);
+        HIP_TRY(hipGetLastError());
       }
-      // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
-      hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
-                         (const float*)e->agg_head, (const int*)e->row_ptr, (const int*)e->deg, N, H);
-      HIP_TRY(hipGetLastError());
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
       HIP_TRY(nl(s, e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H, N, H, 1));
       HIP_TRY(nl(s, e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H, N, H, 0));
@@ -648,7 +747,7 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
                                (uint64_t)n_lig, (uint64_t)n_pocket, (uint64_t)batch, (uint64_t)(uintptr_t)eps_lig,
                                (uint64_t)(uintptr_t)eps_pocket, (uint64_t)(uintptr_t)status,
                                (uint64_t)(uintptr_t)e->ws, (uint64_t)(uintptr_t)e->slots.data()[0],
-                               (uint64_t)(uintptr_t)s};
+                               (uint64_t)(uintptr_t)s, (uint64_t)e->frame};
   dsbdd_engine::GraphEntry* g = nullptr;
   for (auto& ge : e->graphs)
     if (ge.key == key) { g = &ge; break; }

@@ -50,6 +50,15 @@ struct SegAlign {
   int* seg_base;   // [2B + 1]
 };
 
+// Optional second output of the radius graph: the edges that have a LIGAND endpoint (all edges of
+// ligand rows + the ligand columns of pocket rows), in the same aligned layout with its own
+// row_ptr / deg.  Block 0 of a pocket-conditioned chain evaluates the pocket-pocket messages
+// separately (engine.hip, "pocket frame"), so its message stage runs on this list.
+struct EdgeList2 {
+  int* deg; int* row_ptr; int* erow; int* ecol; float* ed0; int e_cap;
+  SegAlign seg;      // scan_tmp / seg_base of this list
+};
+
 // One wave per row node.  FILL=false counts neighbours (deg), FILL=true writes
 // them at row_ptr[row].  Candidates are visited in index order (ligand nodes of
 // the sample, then its pocket nodes) and compacted with ballot/popcount, so the
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const int* __restrict__ lig_off, const int* __restrict__ poc_off, int n_lig, int n_nodes,
     Cutoffs cut, int* __restrict__ deg, const int* __restrict__ row_ptr, int* __restrict__ erow,
     int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status,
-    int* __restrict__ act_flag, SegAlign seg, int* __restrict__ row_ptr_out) {
+    int* __restrict__ act_flag, SegAlign seg, int* __restrict__ row_ptr_out, EdgeList2 l2, int id_offset) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -81,6 +90,13 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       } else {
         base = row_ptr[i];
       }
+    }
+    int base2 = 0;
+    if (FILL && l2.deg) {
+      const int k = il ? b : l2.seg.B + b;
+      const int first = il ? lig_off[b] : n_lig + poc_off[b];
+      base2 = l2.seg.seg_base[k] + l2.seg.scan_tmp[i] - l2.seg.scan_tmp[first];
+      if (lane == 0) l2.row_ptr[i] = base2;
     }
     int cnt = 0, cnt_lig = 0;
 #pragma unroll 1
@@ -104,7 +120,11 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
         if (FILL && pass) {
           const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
           if (pos >= 0 && pos < e_cap) {   // (pos < 0 only with unsorted masks, which the host rejects)
-            erow[pos] = i; ecol[pos] = j; ed0[pos] = d2;
+            erow[pos] = i + id_offset; ecol[pos] = j + id_offset; ed0[pos] = d2;
+          }
+          if (l2.deg && (il || jl)) {     // ligand columns come first in a row: same running position
+            const int pos2 = base2 + cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos2 >= 0 && pos2 < l2.e_cap) { l2.erow[pos2] = i; l2.ecol[pos2] = j; l2.ed0[pos2] = d2; }
           }
         }
         cnt += __popcll(m);
@@ -113,6 +133,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     }
     if (!FILL && lane == 0) {
       deg[i] = cnt;
+      if (l2.deg) l2.deg[i] = il ? cnt : cnt_lig;
       // "active" for the coordinate MLPs in pocket-conditioning mode: ligand nodes and
       // pocket nodes that are a column of some ligand-row edge (graph is symmetric)
       if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
@@ -126,6 +147,11 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
         const int from = base + cnt, to = (from + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
         const int pos = from + lane;
         if (pos >= 0 && pos < to && pos < e_cap) { erow[pos] = -1; ecol[pos] = 0; ed0[pos] = 0.f; }
+        if (l2.deg) {
+          const int from2 = base2 + (il ? cnt : cnt_lig), to2 = (from2 + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
+          const int p2 = from2 + lane;
+          if (p2 >= 0 && p2 < to2 && p2 < l2.e_cap) { l2.erow[p2] = -1; l2.ecol[p2] = 0; l2.ed0[p2] = 0.f; }
+        }
       }
     }
   }
@@ -172,9 +198,21 @@ __device__ __forceinline__ int block_scan_1024(int mine, int* s_wave, int* s_tot
   return r;
 }
 
-__global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr, int n, SegAlign seg) {
+__device__ void scan_one(const int* deg, int* row_ptr, int n, SegAlign seg, int* s_wave, int* s_carry_p);
+
+__global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr, int n, SegAlign seg,
+                                                    const int* deg_b, int* row_ptr_b, SegAlign seg_b) {
   __shared__ int s_wave[16];
   __shared__ int s_carry;
+  scan_one(deg, row_ptr, n, seg, s_wave, &s_carry);
+  if (deg_b) {                     // second list of the same launch (EdgeList2)
+    __syncthreads();
+    scan_one(deg_b, row_ptr_b, n, seg_b, s_wave, &s_carry);
+  }
+}
+
+__device__ void scan_one(const int* deg, int* row_ptr, int n, SegAlign seg, int* s_wave, int* s_carry_p) {
+  int& s_carry = *s_carry_p;
   const int t = threadIdx.x;
   int* out = seg.seg_base ? seg.scan_tmp : row_ptr;
   const bool vec = ((reinterpret_cast<uintptr_t>(deg) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
@@ -190,7 +228,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
       for (int k = 0; k < 4; ++k) if (i0 + k < n) v[k] = deg[i0 + k];
     }
     const int mine = v[0] + v[1] + v[2] + v[3];
-    int run = carry + block_scan_1024(mine, s_wave, &s_carry);
+    int run = carry + block_scan_1024(mine, s_wave, s_carry_p);
     const int tile_total = s_carry;
     if (vec && i0 + 3 < n) {
       int4 o4;
@@ -215,7 +253,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* deg, int* row_ptr
     const int k = base + t;
     int len = 0;
     if (k < S) len = (max(out[seg_end(k)] - out[seg_begin(k)], 0) + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
-    const int ex = carry + block_scan_1024(len, s_wave, &s_carry);
+    const int ex = carry + block_scan_1024(len, s_wave, s_carry_p);
     if (k < S) seg.seg_base[k] = ex;
     carry += s_carry;
     __syncthreads();

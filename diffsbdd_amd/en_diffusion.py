@@ -521,16 +521,41 @@ class EnVariationalDiffusion(nn.Module):
         if st & _lib.STATUS_NAN:
             raise ValueError("NaN detected in EGNN output")
 
-    def _begin_chain(self, lig_mask, pocket_mask, batch):
+    share_identical_pockets = True   # evaluate block 0's pocket-pocket messages once for a batch of identical pockets
+
+    def _begin_chain(self, lig_mask, pocket_mask, batch, pocket=None):
         """Start of a sampling call: int64 contiguous masks on the device and the edge bound of
         this batch, from the mask CONTENTS (one host sync per chain, which also rejects unsorted
-        masks before any kernel runs)."""
+        masks before any kernel runs).  `pocket` (normalised dict, pocket-conditioned models): the
+        pocket only translates during the chain, so the engine gets its raw coordinates as a frame
+        (csrc/engine.hip, dsbdd_engine_set_pocket_frame) -- and, when all samples carry the same
+        pocket (prepare_pocket(repeats=n), lightning_modules.py:738-750), block 0's pocket-pocket
+        messages are evaluated for one sample only; results are bit-identical either way."""
         from .engine import edge_capacity
         dev = self._hip_device(None)
         lm = lig_mask.to(device=dev, dtype=torch.int64).contiguous()
         pm = pocket_mask.to(device=dev, dtype=torch.int64).contiguous()
-        self._chain = (edge_capacity(lm, pm, batch),)
+        cap = edge_capacity(lm, pm, batch)
+        self._chain = (cap,)
+        self._framed = False
+        if pocket is not None and not self.dynamics.update_pocket_coords and pm.numel() > 0:
+            sizes = pocket['size'].to(dev).to(torch.int64)
+            x = pocket['x'].to(device=dev, dtype=torch.float32)
+            shared = False
+            if self.share_identical_pockets and batch > 1 and bool((sizes == sizes[0]).all()) \
+                    and int(sizes[0]) * batch == x.shape[0]:
+                n0 = int(sizes[0])
+                h = pocket['one_hot'].to(dev)
+                shared = bool((x.view(batch, n0, -1) == x[:n0]).all()) and \
+                    bool((h.view(batch, n0, -1) == h[:n0]).all())
+            self.dynamics.engine().set_pocket_frame(x, pm, sizes, lm.numel(), batch, cap, shared)
+            self._framed = True
         return lm, pm
+
+    def _end_chain(self):
+        if getattr(self, "_framed", False):
+            self.dynamics.engine().clear_pocket_frame()
+            self._framed = False
 
     def _dyn(self, z_lig, z_pocket, t_value, lig_mask, pocket_mask, batch, status, want_pocket):
         """One denoiser call.  t and the eps outputs live in persistent buffers keyed by the

@@ -197,6 +197,34 @@ class HipEngine:
                    "dsbdd_engine_bind_workspace")
         self.caps = caps
 
+    def set_pocket_frame(self, x_pocket, mask_pocket, sizes_pocket, n_lig, batch, edge_cap, shared):
+        """dsbdd_engine_set_pocket_frame: raw pocket coordinates x_pocket [n_pocket, 3] (fp32, device) of a
+        pocket-conditioned chain.  shared=True: every sample has the same pocket -> the frame problem is
+        sample 0's pocket alone and all samples read its block-0 pocket-pocket messages."""
+        dev = self.device
+        n_pocket = x_pocket.shape[0]
+        self.ensure_workspace(n_lig, n_pocket, batch, edge_cap)
+        x_pocket = x_pocket.to(device=dev, dtype=torch.float32).contiguous()
+        if shared:
+            n0 = n_pocket // batch
+            twin = torch.arange(n0, dtype=torch.int32, device=dev).repeat(batch)
+            mask3, n3, b3 = mask_pocket[:n0].contiguous(), n0, 1
+            bound = (n0 * n0 + 31) // 32 * 32 + 32
+        else:
+            twin = torch.arange(n_pocket, dtype=torch.int32, device=dev)
+            mask3, n3, b3 = mask_pocket, n_pocket, batch
+            sz = sizes_pocket.to(torch.int64)
+            bound = int((((sz * sz) + 31) // 32 * 32).sum().item()) + 32
+        self._frame_keep = (x_pocket, twin, mask3)
+        _lib.check(self.lib.dsbdd_engine_set_pocket_frame(
+            self.handle, torch.cuda.current_stream(dev).cuda_stream, x_pocket.data_ptr(), mask3.data_ptr(),
+            twin.data_ptr(), n_lig, n_pocket, batch, n3, b3, min(bound, self.caps[3])),
+            "dsbdd_engine_set_pocket_frame")
+
+    def clear_pocket_frame(self):
+        _lib.check(self.lib.dsbdd_engine_clear_pocket_frame(self.handle), "dsbdd_engine_clear_pocket_frame")
+        self._frame_keep = None
+
     def set_trace(self, n_nodes):
         """Allocate per-block trace buffers (debug / parity tests)."""
         L, H = self.cfg.n_layers, self.cfg.hidden_nf

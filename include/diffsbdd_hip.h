@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DSBDD_ABI_VERSION 2
+#define DSBDD_ABI_VERSION 3
 
 enum {
   DSBDD_OK = 0,
@@ -129,6 +129,27 @@ size_t dsbdd_engine_workspace_bytes(const dsbdd_engine* e, int64_t n_lig, int64_
                                     int64_t batch, int64_t edge_capacity);
 int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* workspace, size_t bytes, int64_t n_lig,
                                 int64_t n_pocket, int64_t batch, int64_t edge_capacity);
+
+/* Pocket frame of a pocket-conditioned sampling chain (update_pocket_coords = 0).
+ * During such a chain the pocket moves rigidly (the reverse step only translates it with the ligand's
+ * centre of mass, conditional_model.py:688-696), so its pocket-pocket radius graph and distances are
+ * constants of the chain.  With a frame set, block 0 of dsbdd_dynamics_forward evaluates
+ *     agg[node] = [sum over the node's edges with a ligand endpoint] + [sum over its pocket-pocket edges]
+ * with the second part taken from the frame: a static edge list built here ONCE from the raw pocket
+ * coordinates x_pocket [n_pocket][3].  twin_local [n_pocket] maps every pocket node to its index in the
+ * frame problem -- the first n_frame rows of x_pocket / mask_frame (batch_frame samples): either the whole
+ * pocket array (twin = identity) or one representative sample of a batch of IDENTICAL pockets
+ * (prepare_pocket(repeats = n_samples), lightning_modules.py:738-750), whose pocket-pocket messages of
+ * block 0 are the same in every sample (same atom features, same time step, same distances) and are then
+ * evaluated once -- 82 % of that stage's edges at the benchmark batch.  Both variants give bit-identical
+ * results: the association A + B and the raw-coordinate distances are the same.
+ * The frame lives in the workspace; it is dropped by bind_workspace and by dsbdd_engine_clear_pocket_frame,
+ * and only applies to calls with exactly (n_lig, n_pocket, batch).  edge_bound_frame = upper bound on the
+ * frame's edge count (sum of squared pocket sizes of the frame samples + 32 per sample). */
+int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_pocket, const int64_t* mask_frame,
+                                  const int32_t* twin_local, int64_t n_lig, int64_t n_pocket, int64_t batch,
+                                  int64_t n_frame, int64_t batch_frame, int64_t edge_bound_frame);
+int dsbdd_engine_clear_pocket_frame(dsbdd_engine* e);
 
 /* Optional per-block trace (debug / parity tests): after every EquivariantBlock
  * the node features h [N][H] and coordinates x [N][3] are copied to

@@ -192,3 +192,55 @@ def test_bench_problem_reverse_steps_teacher_forced(arch, B, n_steps):
         worst = max(worst, excess(h_l, o_l), excess(h_p, o_p))
         z_l, z_p = o_l, o_p          # teacher forcing: the oracle's state feeds the next step
     assert worst <= 0, worst         # 1e-4 per timestep (+ rtol 1e-5 on large joint states)
+
+
+def test_pocket_frame_block0_split_and_shared_pockets():
+    """Pocket frame (csrc/engine.hip, dsbdd_engine_set_pocket_frame): block 0 evaluates the pocket-pocket
+    messages on the chain's raw pocket coordinates, separately from the edges with a ligand endpoint, and for
+    a batch of identical pockets only once.  (i) parity with the oracle at 1e-4 while the pocket is translated
+    per sample (what the reverse steps do), (ii) the shared and the per-sample evaluation agree bit for bit,
+    (iii) so do a batch and its halves (frames of their own)."""
+    from diffsbdd_amd.engine import edge_capacity
+    B = 8
+    cfg, dd, xl, xp, t, ml, mp = bench_problem("crossdock_fullatom_cond", B)
+    sd = W.random_state_dict(cfg, 0)
+    d = dev()
+    N = len(ml) + len(mp)
+    n0 = len(mp) // B
+    # raw pocket = sample 0's coordinates for every sample; the chain state is a per-sample translation of it
+    raw = xp[:n0, :3].repeat(B, 1)
+    g = torch.Generator().manual_seed(3)
+    shift = torch.randn(B, 3, generator=g)
+    xp_t = torch.cat([raw + shift[mp], xp[:, 3:]], 1)
+    xl_t = torch.cat([xl[:, :3] + shift[ml], xl[:, 3:]], 1)
+    sizes = torch.full((B,), n0)
+
+    def run(shared, sl=slice(None), sp=slice(None), batch=B):
+        m = make_dynamics(cfg, sd)
+        eng = m.engine()
+        a = [v.to(d) for v in (xl_t[sl], xp_t[sp], t[:batch], ml[sl] - ml[sl][0], mp[sp] - mp[sp][0])]
+        cap = edge_capacity(a[3], a[4], batch)
+        eng.set_pocket_frame(raw[sp].to(d), a[4], sizes[:batch].to(d), a[0].shape[0], batch, cap, shared)
+        outs = [m.forward_async(*a, batch=batch, edge_cap=cap) for _ in range(3)]      # eager, capture, replay
+        torch.cuda.synchronize()
+        assert all(int(o[2].item()) == 0 for o in outs)
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+        er, ec = eng.last_edges(a[0].shape[0] + a[1].shape[0])
+        eng.clear_pocket_frame()
+        return outs[0][0], outs[0][1], torch.stack([er, ec])
+
+    s_l, s_p, edges = run(True)
+    u_l, u_p, _ = run(False)
+    assert torch.equal(s_l, u_l) and torch.equal(s_p, u_p)                      # (ii)
+    with oracle_threads():
+        o_l, o_p, _ = eo.dynamics_forward(sd, cfg, xl_t, xp_t, t, ml, mp, edges=edges)
+    assert excess(s_l, o_l) <= 0 and excess(s_p, o_p) <= 0                      # (i) 1e-4
+    nl = len(ml) // B
+    h_l, h_p, _ = run(True, slice(4 * nl, None), slice(4 * n0, None), 4)        # samples 4..7 as their own batch
+    assert torch.equal(h_l, s_l[4 * nl:]) and torch.equal(h_p, s_p[4 * n0:])    # (iii)
+    one_l, one_p, _ = run(False, slice(7 * nl, None), slice(7 * n0, None), 1)   # a single sample, not shared
+    assert torch.equal(one_l, s_l[7 * nl:]) and torch.equal(one_p, s_p[7 * n0:])
+    # without a frame (plain forward) the association of block 0 differs: same numbers to rounding
+    m = make_dynamics(cfg, sd)
+    p_l, p_p = m(*[v.to(d) for v in (xl_t, xp_t, t, ml, mp)])
+    assert (p_l - s_l).abs().max().item() < 1e-5 and (p_p - s_p).abs().max().item() < 1e-5
