@@ -86,9 +86,6 @@ struct dsbdd_engine {
   int ts_cap = 0, ts_next = 0;
   hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the
                                       // legacy default stream, which cannot be captured)
-  hipStream_t side_stream = nullptr;  // block 0 with a pocket frame: the small pocket-pocket launch runs beside the
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // ligand-endpoint launch (fork / join by events, capturable)
-  int use_side = 1;                   // DSBDD_SIDE_STREAM=0: one stream
   // captured graphs hold the raw weight / workspace pointers of the moment they were captured
   void drop_graphs() {
     for (GraphEntry& g : graphs) {
@@ -101,9 +98,6 @@ struct dsbdd_engine {
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     drop_graphs();
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    if (side_stream) (void)hipStreamDestroy(side_stream);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
   }
 };
 
@@ -192,8 +186,6 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (csp && atoi(csp) == 0) e->coord_split = 0;
   const char* ngp = getenv("DSBDD_NODE_GROUP");
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
-  const char* sst = getenv("DSBDD_SIDE_STREAM");
-  if (sst && atoi(sst) == 0) e->use_side = 0;
   const char* mwg = getenv("DSBDD_EDGE_MAX_WG");
   if (mwg && atoi(mwg) > 0) e->edge_max_wg = atoi(mwg);
   *out = e;
@@ -316,11 +308,6 @@ int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_
   e->frame_nlig = n_lig; e->frame_npoc = n_pocket; e->frame_batch = batch;
   e->frame_n3 = n3; e->frame_cap3 = edge_bound_frame;
   e->frame_shared = (n_frame < n_pocket) ? 1 : 0;
-  if (e->use_side && !e->side_stream) {
-    if (hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess) e->side_stream = nullptr;
-    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) e->ev_fork = nullptr;
-    if (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) e->ev_join = nullptr;
-  }
   e->frame = true;
   return DSBDD_OK;
 }
@@ -636,24 +623,13 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         EdgeArgs a2 = ea;
         a2.erow = e->erow2; a2.ecol = e->ecol2; a2.ed0 = e->ed02; a2.e_count = e->row_ptr2 + N;
         // (B) pocket-pocket edges of the frame (all samples, or the representative of identical pockets),
-        //     raw pocket coordinates -> aggB / agg_headB.  With identical pockets it is a few dozen tiles: it
-        //     runs beside (A) on a second stream (fork / join by events; the pair is captured into the graph).
+        //     raw pocket coordinates -> aggB / agg_headB.  (Running the small launch (B) on a second stream
+        //     beside (A) was measured: 29.13 vs 29.42 ligands/s -- no gain, removed.)
         EdgeArgs a3 = ea;
         a3.erow = e->erow3; a3.ecol = e->ecol3; a3.ed0 = e->ed03; a3.e_count = e->row_ptr3 + e->frame_n3;
         a3.x = e->xcanon; a3.agg = e->aggB; a3.agg_head = e->agg_headB;
-        a3.tile_ctr = e->tile_ctr + 0;   // (the work-queue counters are unused by the static schedule)
-        const bool side = e->use_side && e->frame_shared && e->side_stream && e->ev_fork && e->ev_join;
-        if (side) {
-          HIP_TRY(hipEventRecord(e->ev_fork, s));
-          HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-          HIP_TRY(launch_edge(e, e->side_stream, MODE_GCL, a3, e->frame_cap3));
-          HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
-          HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
-          HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
-        } else {
-          HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
-          HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
-        }
+        HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
+        HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
         hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
                            (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,

@@ -522,6 +522,8 @@ class EnVariationalDiffusion(nn.Module):
             raise ValueError("NaN detected in EGNN output")
 
     share_identical_pockets = True   # evaluate block 0's pocket-pocket messages once for a batch of identical pockets
+    frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
+                                     # extra launches of the split cost more than their few pocket-pocket edges
 
     def _begin_chain(self, lig_mask, pocket_mask, batch, pocket=None):
         """Start of a sampling call: int64 contiguous masks on the device and the edge bound of
@@ -538,7 +540,10 @@ class EnVariationalDiffusion(nn.Module):
         cap = edge_capacity(lm, pm, batch)
         self._chain = (cap,)
         self._framed = False
-        if pocket is not None and not self.dynamics.update_pocket_coords and pm.numel() > 0:
+        if pocket is not None and not self.dynamics.update_pocket_coords and pm.numel() > 0 and \
+                int(pocket['size'].min()) >= self.frame_min_pocket_nodes:
+            # (the size rule looks at every sample's pocket: in practice a property of the model's pocket
+            # representation -- full-atom pockets have hundreds of nodes, C-alpha pockets a few dozen)
             sizes = pocket['size'].to(dev).to(torch.int64)
             x = pocket['x'].to(device=dev, dtype=torch.float32)
             shared = False
