@@ -50,6 +50,11 @@ struct dsbdd_engine {
   int *erow2, *ecol2, *row_ptr2, *deg2, *scan_tmp2, *seg_base2;
   int *erow3, *ecol3, *row_ptr3, *deg3, *scan_tmp3, *seg_base3, *node_batch3, *lig_off3, *poc_off3, *twin;
   float *ed02, *ed03, *xcanon, *aggB, *agg_headB;
+  // level-ordered list (graph.h, "Level-ordered edge list"): pocket-conditioned calls that return the ligand part only
+  int *lvl, *seg_rows, *seg_edges, *node_base, *edge_base, *lvl_cnt, *lvl_end, *lvl_list, *row_ptrL, *erowL, *ecolL;
+  float* ed0L;
+  int64_t cap_edgesL = 0;
+  int prune = 1;                        // DSBDD_PRUNE=0: evaluate every row in every stage
   // pocket frame of the running chain (dsbdd_engine_set_pocket_frame): raw pocket coordinates are rigid in
   // pocket-conditioning mode, so block 0's pocket-pocket messages are evaluated on them, separately
   bool frame = false;
@@ -123,7 +128,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
   const int H = c.hidden_nf, JP = pad4(c.joint_nf + 1);
   const int LE = pad4(2 * (c.atom_nf > c.residue_nf ? c.atom_nf : c.residue_nf));
   const int PQ = (c.reflection_equivariant ? 2 : 4) * H;
-  const int64_t T = E / 32 + 2;        // wave tiles
+  const int64_t EL = E + 32 * kLevels * B;   // level-ordered list: one padded segment per (level, sample)
+  const int64_t T = EL / 32 + 2;             // wave tiles
   size_t sizes[] = {
       (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4, (size_t)(N + 1) * 4,  // 0-4
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4,                                                  // 5-7 erow ecol ed0
@@ -141,7 +147,10 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 36-40 list 3
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4,                                                 // 41 scan_tmp3 42 seg_base3
       (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4,                       // 43 node_batch3 44 lig_off3 45 poc_off3 46 twin
-      (size_t)N * 12, (size_t)N * H * 4, (size_t)T * H * 4};                                        // 47 xcanon 48 aggB 49 agg_headB
+      (size_t)N * 12, (size_t)N * H * 4, (size_t)T * H * 4,                                         // 47 xcanon 48 aggB 49 agg_headB
+      (size_t)N * 4, (size_t)kLevels * B * 4, (size_t)kLevels * B * 4,                              // 50 lvl 51 seg_rows 52 seg_edges
+      (size_t)(kLevels * B + 1) * 4, (size_t)(kLevels * B + 1) * 4, 64, 64,                         // 53 node_base 54 edge_base 55 lvl_cnt 56 lvl_end
+      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4};          // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -154,7 +163,7 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
                             int* act_flag = nullptr, int* scan_tmp = nullptr, int* seg_base = nullptr,
-                            const EdgeList2* list2 = nullptr, int id_offset = 0);
+                            const EdgeList2* list2 = nullptr, int id_offset = 0, int* lvl = nullptr);
 
 extern "C" {
 
@@ -186,6 +195,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (csp && atoi(csp) == 0) e->coord_split = 0;
   const char* ngp = getenv("DSBDD_NODE_GROUP");
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
+  const char* prn = getenv("DSBDD_PRUNE");
+  if (prn && atoi(prn) == 0) e->prune = 0;
   const char* mwg = getenv("DSBDD_EDGE_MAX_WG");
   if (mwg && atoi(mwg) > 0) e->edge_max_wg = atoi(mwg);
   *out = e;
@@ -255,7 +266,13 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->w2tp = (float*)(b + L.off[23]);
   e->agg_head = (float*)(b + L.off[24]); e->xagg_head = (float*)(b + L.off[25]);
   e->scan_tmp = (int*)(b + L.off[26]); e->seg_base = (int*)(b + L.off[27]); e->tile_ctr = (int*)(b + L.off[28]);
-  e->cap_tiles = E / 32 + 2;
+  e->cap_tiles = (E + 32 * kLevels * B) / 32 + 2;
+  e->cap_edgesL = E + 32 * kLevels * B;
+  e->lvl = (int*)(b + L.off[50]); e->seg_rows = (int*)(b + L.off[51]); e->seg_edges = (int*)(b + L.off[52]);
+  e->node_base = (int*)(b + L.off[53]); e->edge_base = (int*)(b + L.off[54]);
+  e->lvl_cnt = (int*)(b + L.off[55]); e->lvl_end = (int*)(b + L.off[56]);
+  e->lvl_list = (int*)(b + L.off[57]); e->row_ptrL = (int*)(b + L.off[58]);
+  e->erowL = (int*)(b + L.off[59]); e->ecolL = (int*)(b + L.off[60]); e->ed0L = (float*)(b + L.off[61]);
   e->erow2 = (int*)(b + L.off[29]); e->ecol2 = (int*)(b + L.off[30]); e->ed02 = (float*)(b + L.off[31]);
   e->row_ptr2 = (int*)(b + L.off[32]); e->deg2 = (int*)(b + L.off[33]);
   e->scan_tmp2 = (int*)(b + L.off[34]); e->seg_base2 = (int*)(b + L.off[35]);
@@ -370,6 +387,14 @@ int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** out) {
     case DSBDD_BUF_X: *out = e->x; break;
     case DSBDD_BUF_NODE_BATCH: *out = e->node_batch; break;
     case DSBDD_BUF_DEG: *out = e->deg; break;
+    case DSBDD_BUF_LEVEL: *out = e->lvl; break;
+    case DSBDD_BUF_LEVEL_LIST: *out = e->lvl_list; break;
+    case DSBDD_BUF_LEVEL_COUNT: *out = e->lvl_cnt; break;
+    case DSBDD_BUF_LEVEL_END: *out = e->lvl_end; break;
+    case DSBDD_BUF_LROW_PTR: *out = e->row_ptrL; break;
+    case DSBDD_BUF_LEDGE_ROW: *out = e->erowL; break;
+    case DSBDD_BUF_LEDGE_COL: *out = e->ecolL; break;
+    case DSBDD_BUF_LEDGE_D0: *out = e->ed0L; break;
     default: return fail(DSBDD_ERR_ARG, "unknown buffer id");
   }
   return DSBDD_OK;
@@ -442,7 +467,8 @@ static Cutoffs cutoffs_of(const dsbdd_config& c) {
 static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int B, const dsbdd_config& c,
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
-                            int* act_flag, int* scan_tmp, int* seg_base, const EdgeList2* list2, int id_offset) {
+                            int* act_flag, int* scan_tmp, int* seg_base, const EdgeList2* list2, int id_offset,
+                            int* lvl) {
   const int waves_per_block = kThreads / 64;
   int blocks = (N + waves_per_block - 1) / waves_per_block;
   if (blocks > 4096) blocks = 4096;
@@ -456,14 +482,14 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   if (list2 && aligned) l2 = *list2;
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr, l2, 0);
+                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr, l2, 0, lvl);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg,
                      (const int*)l2.deg, l2.row_ptr, l2.seg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
-                     (int*)nullptr, sg, row_ptr, l2, id_offset);
+                     (int*)nullptr, sg, row_ptr, l2, id_offset, (int*)nullptr);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -492,6 +518,10 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // ligand endpoint; the pocket-pocket part comes from the static list built by set_pocket_frame.
   const bool split0 = e->frame && subset && !ext && n_lig == e->frame_nlig && n_pocket == e->frame_npoc &&
                       batch == e->frame_batch;
+  // Ligand output only (eps_pocket == nullptr) in pocket-conditioning mode: the stages evaluate the rows the
+  // ligand output depends on, prefixes of the level-ordered list (graph.h, "Level-ordered edge list")
+  const bool prune = e->prune && subset && !ext && !eps_pocket && !e->trace_h && !e->trace_x && nlig > 0;
+  const int G_stages = c.n_layers * c.inv_sublayers;
   // ---- masks -> offsets, split inputs ---------------------------------------
   {
     const int work = N > B + 1 ? N : B + 1;
@@ -542,9 +572,36 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
                               e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
                               subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base,
-                              split0 ? &l2 : nullptr);
+                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr);
     if (rc) return rc;
+    if (prune) {
+      LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
+                   e->ed0, e->seg_rows, e->seg_edges, e->node_base, e->edge_base, e->lvl_cnt, e->lvl_end,
+                   e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL};
+      hipLaunchKernelGGL(levels_kernel, dim3(B), dim3(kThreads), 0, s, la);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(level_scan_kernel, dim3(1), dim3(1024), 0, s, la, N);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(level_place_kernel, dim3(B), dim3(kThreads), 0, s, la);
+      HIP_TRY(hipGetLastError());
+      int64_t cb = (e->cap_edges + 255) / 256;
+      if (cb > 2048) cb = 2048;
+      if (cb < 1) cb = 1;
+      hipLaunchKernelGGL(level_copy_kernel, dim3((int)cb), dim3(256), 0, s, la, N);
+      HIP_TRY(hipGetLastError());
+    }
   }
+  // the list the stages after block 0's split run on
+  const int* L_row = prune ? e->erowL : e->erow;
+  const int* L_col = prune ? e->ecolL : e->ecol;
+  const float* L_d0 = prune ? e->ed0L : e->ed0;
+  const int* L_ptr = prune ? e->row_ptrL : e->row_ptr;
+  const int L_cap = prune ? (int)e->cap_edgesL : (int)e->cap_edges;
+  const int64_t L_bound = prune ? e->cap_edgesL : edge_bound;
+  // rows / edge prefix of the stage that computes the nodes of level <= r (r >= kLevels - 1: everything)
+  auto rows_of = [&](int r, NodeLinearArgs& a) {
+    if (prune && r < kLevels - 1) { a.row_idx = e->lvl_list; a.m_count = e->lvl_cnt + r; }
+  };
   if (subset) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N, SegAlign{},
                        (const int*)nullptr, (int*)nullptr, SegAlign{});
@@ -557,8 +614,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
 
   const int n_upd = c.update_pocket_coords ? N : nlig;   // update_coords_mask, dynamics.py:130-132
-  const int* e_all = e->row_ptr + N;
-  const int* e_upd = e->row_ptr + n_upd;                 // edges are row-sorted: a prefix
+  const int* e_all = L_ptr + N;
+  const int* e_upd = prune ? e->lvl_end : e->row_ptr + n_upd;   // edges are row-sorted: a prefix (level 0 = ligand rows)
 
   // lane-grouped copies of the three W2^T matrices of every block (see EdgeMlpW::W2TP)
   const bool bperm = e->edge_bperm && (H == 256 || H == 128);
@@ -578,8 +635,10 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     e->w2tp_ready = true;
   }
   auto gcl_pq = [&](int blk, int sub) {
-    return NodeLinearArgs{e->h, H, H, nullptr, 0, 0, W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, nullptr,
-                          nullptr, 0, e->pqg, 2 * H, (int)N, 2 * H, 0, nullptr, nullptr};
+    NodeLinearArgs a{e->h, H, H, nullptr, 0, 0, W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, nullptr,
+                     nullptr, 0, e->pqg, 2 * H, (int)N, 2 * H, 0, nullptr, nullptr};
+    rows_of(G_stages - (blk * c.inv_sublayers + sub) + 1, a);   // the stage reads its neighbours one level out
+    return a;
   };
   bool pqg_ready = false;
   for (int blk = 0; blk < c.n_layers; ++blk) {
@@ -602,6 +661,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
           grp0[0].row_idx = e->act_list; grp0[0].m_count = e->act_ptr + N;
           grp0[1] = gcl_pq(blk, sub);
           grp0[1].A1 = e->h + (size_t)nlig * H; grp0[1].C = e->pqg + (size_t)nlig * 2 * H; grp0[1].M = (int)e->frame_n3;
+          grp0[1].row_idx = nullptr; grp0[1].m_count = nullptr;
         }
         if (!(rows0 && launch_node_group(s, grp0, 2) == hipSuccess)) {
           (void)hipGetLastError();
@@ -609,8 +669,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         }
       }
       pqg_ready = false;
+      const int radius = G_stages - (blk * c.inv_sublayers + sub);   // this stage computes the nodes of level <= radius
+      const bool all_rows = !prune || radius >= kLevels - 1;
       EdgeArgs ea{};
-      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_all; ea.e_cap = (int)e->cap_edges; ea.x = e->x;
+      ea.erow = L_row; ea.ecol = L_col; ea.ed0 = L_d0; ea.e_count = all_rows ? e_all : e->lvl_end + radius;
+      ea.e_cap = L_cap; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
@@ -622,12 +685,13 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // (A) edges with a ligand endpoint, current coordinates -> agg / agg_head
         EdgeArgs a2 = ea;
         a2.erow = e->erow2; a2.ecol = e->ecol2; a2.ed0 = e->ed02; a2.e_count = e->row_ptr2 + N;
+        a2.e_cap = (int)e->cap_edges;
         // (B) pocket-pocket edges of the frame (all samples, or the representative of identical pockets),
         //     raw pocket coordinates -> aggB / agg_headB.  (Running the small launch (B) on a second stream
         //     beside (A) was measured: 29.13 vs 29.42 ligands/s -- no gain, removed.)
         EdgeArgs a3 = ea;
         a3.erow = e->erow3; a3.ecol = e->ecol3; a3.ed0 = e->ed03; a3.e_count = e->row_ptr3 + e->frame_n3;
-        a3.x = e->xcanon; a3.agg = e->aggB; a3.agg_head = e->agg_headB;
+        a3.x = e->xcanon; a3.agg = e->aggB; a3.agg_head = e->agg_headB; a3.e_cap = (int)e->cap_edges;
         HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
         HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
         hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
@@ -636,21 +700,27 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                            (const int*)e->deg3, (const int*)e->twin, nlig, nlig, N, H);
         HIP_TRY(hipGetLastError());
       } else {
-        const bool timed = e->time_now && e->ev_used + 2 <= e->ev.size();
+        // (timed: the launches over the whole list only, so that every timed launch is the same work)
+        const bool timed = e->time_now && all_rows && e->ev_used + 2 <= e->ev.size();
         if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
-        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, edge_bound));
+        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, L_bound));
         if (timed) {
           HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
           e->ev_used += 2;
         }
         // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
         hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
-                           (const float*)e->agg_head, (const int*)e->row_ptr, (const int*)e->deg, N, H);
+                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, N, H);
         HIP_TRY(hipGetLastError());
       }
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
-      HIP_TRY(nl(s, e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H, N, H, 1));
-      HIP_TRY(nl(s, e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H, N, H, 0));
+      NodeLinearArgs n1{e->h, H, H, e->agg, H, H, G(DSBDD_GCL_N1_WT), H, G(DSBDD_GCL_N1_B), nullptr, 0, e->t1, H,
+                        (int)N, H, 1, nullptr, nullptr};
+      NodeLinearArgs n2{e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H,
+                        (int)N, H, 0, nullptr, nullptr};
+      rows_of(radius, n1); rows_of(radius, n2);
+      HIP_TRY(launch_node_linear(s, n1));
+      HIP_TRY(launch_node_linear(s, n2));
     }
     {
       auto Q = [&](int which) { return W[eq_slot(c, blk, which)]; };
@@ -677,7 +747,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         for (int i = 0; i < nc; ++i) HIP_TRY(launch_node_linear(s, grp[i]));
       }
       EdgeArgs ea{};
-      ea.erow = e->erow; ea.ecol = e->ecol; ea.ed0 = e->ed0; ea.e_count = e_upd; ea.e_cap = (int)e->cap_edges; ea.x = e->x;
+      ea.erow = L_row; ea.ecol = L_col; ea.ed0 = L_d0; ea.e_count = e_upd; ea.e_cap = L_cap; ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
                            Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers)};
@@ -694,12 +764,12 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.pass_split = e->coord_split;
       if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
      
-      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, edge_bound));
+      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, L_bound));
       if (n_upd > 0) {
         const int n_q = (e->coord_split && n_mlp == 2) ? 2 : 1;
         hipLaunchKernelGGL(coord_update_kernel, dim3((3 * n_upd + 255) / 256), dim3(256), 0, s, e->x,
                            (const float*)e->xagg, (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride,
-                           (const int*)e->row_ptr, (const int*)e->deg, 3 * n_upd);
+                           L_ptr, (const int*)e->deg, 3 * n_upd);
         HIP_TRY(hipGetLastError());
       }
     }
@@ -709,7 +779,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       HIP_TRY(hipMemcpyAsync(e->trace_x + (size_t)blk * N * 3, e->x, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
   }
   // ---- embedding_out, decoders (egnn_new.py:241, dynamics.py:147-153) --------
-  HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, W[DSBDD_G_EMBOUT_WT], JP, W[DSBDD_G_EMBOUT_B], nullptr, 0, e->hout, JP, N, JP, 0));
+  HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, W[DSBDD_G_EMBOUT_WT], JP, W[DSBDD_G_EMBOUT_B], nullptr, 0, e->hout, JP,
+             eps_pocket ? N : n_lig, JP, 0));
   HIP_TRY(nl(s, e->hout, JP, J, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_DEC_B0], nullptr, 0,
              e->enc_tmp, LE, n_lig, 2 * a, 1));
   HIP_TRY(nl(s, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W1T], pad4(a), W[DSBDD_G_ATOM_DEC_B1], nullptr, 0,

@@ -14,6 +14,7 @@ namespace dsbdd {
 
 constexpr int kTileCtrInts = 32;   // 16 queue heads (8 XCDs x 2 MLP populations) + completion count
 constexpr int kEdgeAlign = 32;     // edges of one (sample, node set) start at a multiple of a wave tile
+constexpr int kLevels = 5;         // hop levels of the level-ordered edge list: 0 ligand, 1..3, 4 = farther
 
 struct Cutoffs {
   int has_l, has_p, has_i;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     const int* __restrict__ lig_off, const int* __restrict__ poc_off, int n_lig, int n_nodes,
     Cutoffs cut, int* __restrict__ deg, const int* __restrict__ row_ptr, int* __restrict__ erow,
     int* __restrict__ ecol, float* __restrict__ ed0, int e_cap, int* __restrict__ status,
-    int* __restrict__ act_flag, SegAlign seg, int* __restrict__ row_ptr_out, EdgeList2 l2, int id_offset) {
+    int* __restrict__ act_flag, SegAlign seg, int* __restrict__ row_ptr_out, EdgeList2 l2, int id_offset,
+    int* __restrict__ lvl = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -137,6 +139,8 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       // "active" for the coordinate MLPs in pocket-conditioning mode: ligand nodes and
       // pocket nodes that are a column of some ligand-row edge (graph is symmetric)
       if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
+      // hop level of the node (levels_kernel below): 0 ligand, 1 = pocket node with a ligand neighbour
+      if (lvl) lvl[i] = il ? 0 : (cnt_lig > 0 ? 1 : kLevels - 1);
     }
     if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
     if (FILL && seg.seg_base) {
@@ -261,6 +265,157 @@ __device__ void scan_one(const int* deg, int* row_ptr, int n, SegAlign seg, int*
   if (t == 0) {
     seg.seg_base[S] = carry;
     row_ptr[n] = carry;           // padded total; row_ptr[0 .. n) is written by edges_kernel<true>
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Level-ordered edge list (pocket-conditioning mode, ligand output only).
+//
+// The caller of a pocket-conditioned denoiser step reads the LIGAND rows of the output only
+// (conditional_model.py:268-272 discards the pocket part), and the pocket coordinates are never updated.
+// Walking the network backwards, the last message stage therefore only has to produce h for the nodes the
+// last coordinate stage reads -- the ligand nodes and their neighbours (hop <= 1) --, the stage before it
+// for hop <= 2, and so on: stage g of G message stages computes the rows with hop <= G - g, and reads its
+// neighbours' h at hop <= G - g + 1.  Everything else is dead code for this call and is not evaluated.
+// (Exactly the same numbers come out for the ligand: no live value depends on a skipped one.)
+//
+// hop(i) = graph distance from node i to the nearest ligand node of its sample (0 for ligand nodes), through
+// the edges of this call; level(i) = min(hop, kLevels - 1).  The edge list is re-ordered by
+// (level, node set, sample, row): the rows a stage needs are then a PREFIX of the list (lvl_end[r], a device
+// scalar, like the update_coords_mask prefix), and the same nodes a prefix of lvl_list (lvl_cnt[r]) for the
+// node-level GEMMs.  Every (level, sample) segment starts at a wave-tile boundary and a row's position in
+// its segment depends on its own sample only, so results stay independent of the batch composition.
+//
+//   levels_kernel   one workgroup per sample: hop levels 2, 3 by relaxation over the natural-order list
+//                   (level 1 comes from the count pass), then rows / edges per (level, sample)
+//   level_scan_kernel   one workgroup: exclusive scans over the kLevels * B segments
+//   level_place_kernel  one workgroup per sample, wave L places level L: new row_ptr, lvl_list, pads
+//   level_copy_kernel   one thread per natural-list slot: move the edge to its new position
+struct LevelArgs {
+  const int* node_batch; const int* lig_off; const int* poc_off; int n_lig; int B;
+  int* lvl;                 // [N]
+  const int* deg;           // [N]
+  const int* row_ptr_nat;   // [N + 1] natural-order list
+  const int* erow_nat; const int* ecol_nat; const float* ed0_nat;
+  int* seg_rows;            // [kLevels * B] rows of segment (L, b);   level 0 = the ligand rows of sample b
+  int* seg_edges;           // [kLevels * B] edges (not padded)
+  int* node_base;           // [kLevels * B + 1] exclusive scan of seg_rows
+  int* edge_base;           // [kLevels * B + 1] exclusive scan of the padded seg_edges
+  int* lvl_cnt;             // [kLevels] nodes with level <= r
+  int* lvl_end;             // [kLevels] end of the edges of the rows with level <= r (padded)
+  int* lvl_list;            // [N] nodes ordered by (level, node id)
+  int* row_ptr;             // [N + 1] level-ordered list
+  int* erow; int* ecol; float* ed0; int e_cap;
+};
+
+__global__ __launch_bounds__(kThreads) void levels_kernel(LevelArgs a) {
+  __shared__ int s_rows[kLevels], s_edges[kLevels];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int p0 = a.n_lig + a.poc_off[b], p1 = a.n_lig + a.poc_off[b + 1];
+  const int l0 = a.lig_off[b], l1 = a.lig_off[b + 1];
+  if (t < kLevels) { s_rows[t] = 0; s_edges[t] = 0; }
+  for (int k = 2; k < kLevels - 1; ++k) {
+    __syncthreads();                       // level k-1 is final (global writes of this workgroup are visible to it)
+    for (int i = p0 + t; i < p1; i += kThreads) {
+      if (a.lvl[i] != kLevels - 1) continue;
+      const int s = a.row_ptr_nat[i], d = a.deg[i];
+      bool hit = false;
+      for (int e = s; e < s + d && !hit; ++e) {
+        const int j = a.ecol_nat[e];
+        hit = j >= a.n_lig && a.lvl[j] == k - 1;     // (a ligand neighbour would have made it level 1)
+      }
+      if (hit) a.lvl[i] = k;               // readers of this pass test == k-1: no race
+    }
+  }
+  __syncthreads();
+  for (int i = p0 + t; i < p1; i += kThreads) {
+    const int L = a.lvl[i];
+    atomicAdd(&s_rows[L], 1);              // integer sums: order does not matter
+    atomicAdd(&s_edges[L], a.deg[i]);
+  }
+  int le = 0;
+  for (int i = l0 + t; i < l1; i += kThreads) le += a.deg[i];
+  if (le) atomicAdd(&s_edges[0], le);
+  __syncthreads();
+  if (t < kLevels) {
+    a.seg_rows[t * a.B + b] = t == 0 ? (l1 - l0) : s_rows[t];
+    a.seg_edges[t * a.B + b] = s_edges[t];
+  }
+}
+
+__global__ __launch_bounds__(1024) void level_scan_kernel(LevelArgs a, int n_nodes) {
+  __shared__ int s_wave[16];
+  __shared__ int s_tot;
+  const int t = threadIdx.x, S = kLevels * a.B;
+  int carry_n = 0, carry_e = 0;
+  for (int base = 0; base < S; base += 1024) {
+    const int k = base + t;
+    const int r = k < S ? a.seg_rows[k] : 0;
+    const int e = k < S ? ((a.seg_edges[k] + kEdgeAlign - 1) & ~(kEdgeAlign - 1)) : 0;
+    const int xn = carry_n + block_scan_1024(r, s_wave, &s_tot);
+    carry_n += s_tot;
+    __syncthreads();
+    const int xe = carry_e + block_scan_1024(e, s_wave, &s_tot);
+    carry_e += s_tot;
+    __syncthreads();
+    if (k < S) { a.node_base[k] = xn; a.edge_base[k] = xe; }
+  }
+  if (t == 0) { a.node_base[S] = carry_n; a.edge_base[S] = carry_e; a.row_ptr[n_nodes] = carry_e; }
+  __syncthreads();
+  if (t < kLevels) {                        // cumulative ends of the levels
+    a.lvl_cnt[t] = t == kLevels - 1 ? carry_n : a.node_base[(t + 1) * a.B];
+    a.lvl_end[t] = t == kLevels - 1 ? carry_e : a.edge_base[(t + 1) * a.B];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void level_place_kernel(LevelArgs a) {
+  static_assert(kThreads / 64 >= kLevels - 1, "one wave per pocket level");
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  auto pads = [&](int from) {               // fill the segment up to the next wave-tile boundary
+    const int to = (from + kEdgeAlign - 1) & ~(kEdgeAlign - 1), pos = from + lane;
+    if (pos < to && pos < a.e_cap) { a.erow[pos] = -1; a.ecol[pos] = 0; a.ed0[pos] = 0.f; }
+  };
+  if (w == 0) {                             // ligand rows keep their natural order
+    const int l0 = a.lig_off[b], l1 = a.lig_off[b + 1];
+    const int nb = a.node_base[b], eb = a.edge_base[b], s0 = l0 < l1 ? a.row_ptr_nat[l0] : 0;
+    for (int i = l0 + lane; i < l1; i += 64) {
+      a.lvl_list[nb + (i - l0)] = i;
+      a.row_ptr[i] = eb + (a.row_ptr_nat[i] - s0);
+    }
+    pads(eb + a.seg_edges[b]);
+  }
+  const int L = w + 1;                      // pocket level of this wave
+  if (L >= kLevels) return;
+  const int p0 = a.n_lig + a.poc_off[b], p1 = a.n_lig + a.poc_off[b + 1];
+  int n_run = a.node_base[L * a.B + b], e_run = a.edge_base[L * a.B + b];
+  for (int i0 = p0; i0 < p1; i0 += 64) {
+    const int i = i0 + lane;
+    const bool mine = i < p1 && a.lvl[i] == L;
+    const int d = mine ? a.deg[i] : 0;
+    const unsigned long long m = __ballot(mine);
+    int incl = d;                            // inclusive wave scan of the degrees of this level's rows
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (mine) {
+      a.lvl_list[n_run + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      a.row_ptr[i] = e_run + incl - d;
+    }
+    n_run += __popcll(m);
+    e_run += __shfl(incl, 63);
+  }
+  pads(e_run);
+}
+
+__global__ void level_copy_kernel(LevelArgs a, int n_nodes) {
+  const int total = a.row_ptr_nat[n_nodes];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int i = a.erow_nat[e];
+    if (i < 0) continue;                    // padding of the natural-order list
+    const int pos = a.row_ptr[i] + (e - a.row_ptr_nat[i]);
+    if (pos >= 0 && pos < a.e_cap) { a.erow[pos] = i; a.ecol[pos] = a.ecol_nat[e]; a.ed0[pos] = a.ed0_nat[e]; }
   }
 }
 

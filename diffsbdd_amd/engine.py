@@ -320,6 +320,23 @@ class HipEngine:
         keep = row >= 0                                   # padding entries carry row = -1
         return torch.from_numpy(row[keep].astype("int64")), torch.from_numpy(col[keep].astype("int64"))
 
+    def last_levels(self, n_nodes):
+        """Level structures of the last ligand-output-only call in pocket-conditioning mode (csrc/graph.h,
+        "Level-ordered edge list"), as numpy arrays (debug / tests; syncs): dict with level[N], order[N] (nodes by
+        (level, id)), count[5] (nodes with level <= r), end[5] (edge prefix ends), row_ptr[N + 1] and the
+        re-ordered list row / col / d0 (padding entries have row = -1)."""
+        import numpy as np
+        torch.cuda.synchronize(self.device)
+        rd = lambda which, n, dt: self._read(self.buffer_ptr(which), n, dt)
+        out = {"level": rd(_lib.BUF_LEVEL, n_nodes, np.int32), "order": rd(_lib.BUF_LEVEL_LIST, n_nodes, np.int32),
+               "count": rd(_lib.BUF_LEVEL_COUNT, 5, np.int32), "end": rd(_lib.BUF_LEVEL_END, 5, np.int32),
+               "row_ptr": rd(_lib.BUF_LROW_PTR, n_nodes + 1, np.int32), "deg": rd(_lib.BUF_DEG, n_nodes, np.int32)}
+        E = int(out["row_ptr"][-1])
+        out["row"] = rd(_lib.BUF_LEDGE_ROW, E, np.int32)
+        out["col"] = rd(_lib.BUF_LEDGE_COL, E, np.int32)
+        out["d0"] = rd(_lib.BUF_LEDGE_D0, E, np.float32)
+        return out
+
     def _read(self, ptr, count, dtype):
         import numpy as np
         itemsize = np.dtype(dtype).itemsize

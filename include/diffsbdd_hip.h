@@ -191,7 +191,11 @@ int dsbdd_engine_graph_stats(const dsbdd_engine* e, int64_t* replays, int64_t* c
 /* Introspection of the last forward (device pointers into the workspace). */
 enum {
   DSBDD_BUF_EDGE_ROW = 0, DSBDD_BUF_EDGE_COL, DSBDD_BUF_EDGE_D0, DSBDD_BUF_ROW_PTR,
-  DSBDD_BUF_H, DSBDD_BUF_X, DSBDD_BUF_NODE_BATCH, DSBDD_BUF_DEG
+  DSBDD_BUF_H, DSBDD_BUF_X, DSBDD_BUF_NODE_BATCH, DSBDD_BUF_DEG,
+  /* level-ordered list of the last ligand-output-only call in pocket-conditioning mode (csrc/graph.h):
+   * level[N], nodes by (level, id) [N], cumulative node counts [5], edge prefix ends [5], and the list */
+  DSBDD_BUF_LEVEL, DSBDD_BUF_LEVEL_LIST, DSBDD_BUF_LEVEL_COUNT, DSBDD_BUF_LEVEL_END,
+  DSBDD_BUF_LROW_PTR, DSBDD_BUF_LEDGE_ROW, DSBDD_BUF_LEDGE_COL, DSBDD_BUF_LEDGE_D0
 };
 int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** ptr_out);
 

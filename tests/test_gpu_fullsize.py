@@ -244,3 +244,103 @@ def test_pocket_frame_block0_split_and_shared_pockets():
     m = make_dynamics(cfg, sd)
     p_l, p_p = m(*[v.to(d) for v in (xl_t, xp_t, t, ml, mp)])
     assert (p_l - s_l).abs().max().item() < 1e-5 and (p_p - s_p).abs().max().item() < 1e-5
+
+
+def _hop_levels(row, col, n_lig, n_nodes, n_levels=5):
+    """Reference for csrc/graph.h levels_kernel: graph distance to the nearest ligand node, capped."""
+    lvl = np.full(n_nodes, n_levels - 1, dtype=np.int64)
+    lvl[:n_lig] = 0
+    for k in range(1, n_levels - 1):
+        src = lvl[col] == k - 1
+        hit = np.zeros(n_nodes, dtype=bool)
+        hit[row[src]] = True
+        lvl[hit & (lvl == n_levels - 1)] = k
+    return lvl
+
+
+@pytest.mark.parametrize("arch,B,frame", [
+    ("crossdock_fullatom_cond", 8, False),
+    ("crossdock_fullatom_cond", 8, True),
+    ("crossdock_ca_cond", 8, False),
+    ("small_cond", 6, True),              # two blocks: block 0 is a pruned stage AND split by the pocket frame
+    ("small_variant", 6, False),          # two sublayers per block, ligand cutoff, E(3) variant
+])
+def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
+    """A pocket-conditioned call that returns the ligand part only (what ConditionalDDPM's chains ask for,
+    conditional_model.py:268-272) evaluates, per message stage, the rows the ligand output depends on -- prefixes
+    of the level-ordered edge list (csrc/graph.h).  (i) the level structures against a numpy BFS over the
+    natural-order list, (ii) ligand eps against the all-rows call (different summation tiles: 2e-5) and the
+    oracle (1e-4), (iii) eager / captured / replayed calls and a batch vs its second half: bit-identical."""
+    from diffsbdd_amd.engine import edge_capacity
+    cfg, dd, xl, xp, t, ml, mp = bench_problem(arch, B)
+    sd = W.random_state_dict(cfg, 0)
+    d = dev()
+    nl, n0 = len(ml) // B, len(mp) // B
+    sizes = torch.full((B,), n0)
+
+    def run(want_pocket, lo=0):
+        sl, sp, batch = slice(lo * nl, None), slice(lo * n0, None), B - lo
+        m = make_dynamics(cfg, sd)
+        eng = m.engine()
+        a = [v.to(d) for v in (xl[sl], xp[sp], t[:batch], ml[sl] - lo, mp[sp] - lo)]
+        cap = edge_capacity(a[3], a[4], batch)
+        if frame:
+            eng.set_pocket_frame(xp[sp, :3].to(d), a[4], sizes[:batch].to(d), a[0].shape[0], batch, cap, False)
+        outs = [m.forward_async(*a, batch=batch, edge_cap=cap, want_pocket=want_pocket) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(int(o[2].item()) == 0 for o in outs)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])      # (iii)
+        n = a[0].shape[0] + a[1].shape[0]
+        er, ec = eng.last_edges(n)
+        lv = eng.last_levels(n) if not want_pocket else None
+        if frame:
+            eng.clear_pocket_frame()
+        return outs[0][0], torch.stack([er, ec]), lv
+
+    full, edges, _ = run(True)
+    lig, edges2, lv = run(False)
+    assert torch.equal(edges, edges2)
+    N = len(ml) + len(mp)
+    row, col = edges[0].numpy(), edges[1].numpy()
+    # (i) levels, their order and the re-ordered list
+    want = _hop_levels(row, col, len(ml), N)
+    assert np.array_equal(lv["level"], want)
+    order = np.lexsort((np.arange(N), want))
+    assert np.array_equal(lv["order"], order)
+    assert np.array_equal(lv["count"], np.cumsum(np.bincount(want, minlength=5)))
+    deg = np.bincount(row, minlength=N)
+    assert np.array_equal(lv["deg"], deg)
+    nat_ptr = np.concatenate([[0], np.cumsum(deg)])            # natural list without its padding
+    pos = 0
+    batch_of = np.concatenate([ml.numpy(), mp.numpy()])
+    prev_key = None
+    level_last = {}
+    for i in order:
+        key = (want[i], batch_of[i])
+        if key != prev_key:
+            pos = (pos + 31) // 32 * 32                        # every (level, sample) segment starts a wave tile
+            prev_key = key
+        assert lv["row_ptr"][i] == pos
+        s = slice(pos, pos + deg[i])
+        assert (lv["row"][s] == i).all()
+        assert np.array_equal(lv["col"][s], col[nat_ptr[i]:nat_ptr[i + 1]])
+        pos += deg[i]
+        level_last[want[i]] = pos
+    running = 0
+    for r in range(5):                                         # edge prefix of the rows with level <= r
+        if r in level_last:
+            running = (level_last[r] + 31) // 32 * 32
+        assert lv["end"][r] == running
+    assert lv["row_ptr"][N] == running
+    pad = np.ones(len(lv["row"]), dtype=bool)
+    for i in range(N):
+        pad[lv["row_ptr"][i]:lv["row_ptr"][i] + deg[i]] = False
+    assert (lv["row"][pad] == -1).all()
+    # (ii) same ligand output
+    assert (lig - full).abs().max().item() < 2e-5
+    with oracle_threads():
+        o_l, _, _ = eo.dynamics_forward(sd, cfg, xl, xp, t, ml, mp, edges=edges)
+    assert excess(lig, o_l) <= 0
+    # (iii) the second half of the batch on its own
+    half, _, _ = run(False, lo=B // 2)
+    assert torch.equal(half, lig[B // 2 * nl:])
