@@ -61,6 +61,22 @@ def load_pocket(key, batch, device):
     return prepare_pocket(z[key + "_x"], z[key + "_types"], n_types, repeats=batch, device=device)
 
 
+def anchor_ligand(batch, n_lig, atom_nf, device):
+    """The pose the 'anchored' chains hold on to: the 3rfm ligand's own atom positions inside the pocket
+    (14 heavy atoms), filled up to n_lig atoms with jittered copies (seeded), random atom types."""
+    z = np.load(os.path.join(ROOT, "diffsbdd_amd", "data", "pocket_3rfm.npz"))
+    rng = np.random.RandomState(7)
+    base = z["ligand_x"].astype(np.float32)
+    extra = max(n_lig - len(base), 0)
+    pose = np.concatenate([base, base[rng.randint(0, len(base), extra)] + rng.normal(scale=0.9, size=(extra, 3))])[:n_lig]
+    types = rng.randint(0, atom_nf, n_lig)
+    x = torch.from_numpy(np.tile(pose, (batch, 1)).astype(np.float32)).to(device)
+    one_hot = torch.zeros(batch * n_lig, atom_nf, device=device)
+    one_hot[torch.arange(batch * n_lig), torch.from_numpy(np.tile(types, batch))] = 1.0
+    return {"x": x, "one_hot": one_hot, "size": torch.full((batch,), n_lig, dtype=torch.int64, device=device),
+            "mask": torch.repeat_interleave(torch.arange(batch, device=device), n_lig)}
+
+
 def build_model(arch, device):
     from diffsbdd_amd.conditional_model import ConditionalDDPM
     from diffsbdd_amd.dynamics import EGNNDynamics
@@ -153,6 +169,13 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="concurrent sub-batches per GPU (diffsbdd_amd/streams.py); 0 = the default (1: splitting "
                          "was measured slower, host-bound graph submission)")
+    ap.add_argument("--states", default="anchored", choices=["anchored", "free"],
+                    help="pocket-conditioned workloads: 'anchored' (default, the headline) keeps every step's ligand "
+                         "state on the forward process of a pose inside the pocket -- ConditionalDDPM.inpaint with "
+                         "every ligand atom known --, which is the state distribution a trained model's chain has; "
+                         "'free' is sample_given_pocket free-running on the random weights, whose ligand drifts out "
+                         "of the pocket (fewer ligand-pocket contacts, cheaper calls).  The other one is reported "
+                         "as a secondary figure.")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -185,10 +208,17 @@ def main():
     n_streams = args.streams or (1 if joint else auto_streams(B * args.n_lig + pocket0["x"].shape[0], B))
     replicas = StreamReplicas(model, n_streams) if (n_streams > 1 and not joint) else None
 
-    def chain(seed):
+    anchor = None if joint else anchor_ligand(B, args.n_lig, cfg["atom_nf"], device)
+
+    def chain(seed, states=None):
+        states = states or args.states
         model.seed(seed, sample_offset=lo)
         pocket = {k: v.clone() for k, v in pocket0.items()}
-        if joint:
+        if not joint and states == "anchored" and replicas is None:
+            ligand = {k: v.clone() for k, v in anchor.items()}
+            out_l, out_p, lm, pm = model.inpaint(ligand, pocket, torch.ones(B * args.n_lig, device=device),
+                                                 resamplings=1, timesteps=T)
+        elif joint:
             lmask = torch.repeat_interleave(torch.arange(B, device=device), args.n_lig)
             ligand = {"x": torch.zeros(B * args.n_lig, 3, device=device),
                       "one_hot": torch.zeros(B * args.n_lig, cfg["atom_nf"], device=device),
@@ -225,6 +255,7 @@ def main():
         # the other 7 replay the engine's captured graph, as in production)
         per_call = cfg["n_layers"] * cfg["inv_sublayers"]
         eng.profile(args.time_every, max_launches=(args.steps * n_calls // args.time_every + 2) * per_call)
+    lv0 = eng.level_stats(raw=True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         all_lig, all_mask = chain(200 + k)
@@ -232,6 +263,21 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = (eng.profile_read() if not args.no_kernel_timing else (0.0, 0))
     eng.profile(False, 0)
+    lv_main = eng.level_stats(since=lv0)
+    e_main = eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]) if replicas is None else None
+    # secondary figure: the other state model of the pocket-conditioned chain (one warm-up, one timed chain)
+    other = None
+    if not joint and replicas is None and world == 1:
+        o_states = "free" if args.states == "anchored" else "anchored"
+        chain(300, o_states)
+        sync()
+        lv1 = eng.level_stats(raw=True)
+        t1 = time.perf_counter()
+        chain(301, o_states)
+        sync()
+        dt = time.perf_counter() - t1
+        other = {"states": o_states, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3, "steps": 1,
+                 "live_levels": eng.level_stats(since=lv1)}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -243,7 +289,7 @@ def main():
     if rank == 0:
         N = B * args.n_lig + pocket0["x"].shape[0]
         if replicas is None:
-            E = E_timed = eng.edge_count(N)
+            E = E_timed = e_main          # edges of the main leg's last call
         else:   # the timed engine (replica 0) runs the first sub-batch only
             per = (B + n_streams - 1) // n_streams
             subs = [min(per, B - i * per) for i in range(n_streams) if B - i * per > 0]
@@ -276,6 +322,9 @@ def main():
             # Pocket-conditioned chains: block 0 is split by the pocket frame and the last stages run on prefixes
             # of the level-ordered list (csrc/graph.h), so fewer than n_layers launches per call qualify.
             "timed_launch_kind": "full edge list",
+            # mean over the calls of the chain: nodes / edge-list slots with hop level <= r (r = 0: ligand rows,
+            # r = 4: everything); message stage g of G evaluates level <= G - g
+            "live_levels": lv_main,
             "hbm_algorithmic_gbps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None,
             "hbm_frac_of_8TBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_n else None,
         }
@@ -291,12 +340,16 @@ def main():
             "config": {"workload": f"{args.workload}: {B} pockets/GPU (3rfm {key} pocket, "
                                    f"{pocket0['x'].shape[0] // B} nodes) x {args.n_lig} ligand atoms, "
                                    f"T={T} reverse steps" + (" (RePaint, resamplings=2)" if joint else "") +
-                                   f" + final decode = {n_calls} EGNN calls per chain",
+                                   f" + final decode = {n_calls} EGNN calls per chain" +
+                                   ("" if joint else (", ligand states anchored to the forward process of a pose in "
+                                                      "the pocket (inpaint, all atoms known)" if args.states == "anchored"
+                                                      and replicas is None else ", free-running on random weights")),
+                       "states": None if joint else (args.states if replicas is None else "free"),
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
                        "streams_per_gpu": n_streams,
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "other_states": other,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
             "hipgraph": dict(zip(("replays", "captures", "eager_calls"), eng.graph_stats())),
             "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,

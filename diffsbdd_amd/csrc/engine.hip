@@ -53,6 +53,8 @@ struct dsbdd_engine {
   // level-ordered list (graph.h, "Level-ordered edge list"): pocket-conditioned calls that return the ligand part only
   int *lvl, *seg_rows, *seg_edges, *node_base, *edge_base, *lvl_cnt, *lvl_end, *lvl_list, *row_ptrL, *erowL, *ecolL;
   float* ed0L;
+  unsigned long long* lvl_stats = nullptr;
+  bool lvl_stats_zeroed = false;
   int64_t cap_edgesL = 0;
   int prune = 1;                        // DSBDD_PRUNE=0: evaluate every row in every stage
   // pocket frame of the running chain (dsbdd_engine_set_pocket_frame): raw pocket coordinates are rigid in
@@ -150,7 +152,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * 12, (size_t)N * H * 4, (size_t)T * H * 4,                                         // 47 xcanon 48 aggB 49 agg_headB
       (size_t)N * 4, (size_t)kLevels * B * 4, (size_t)kLevels * B * 4,                              // 50 lvl 51 seg_rows 52 seg_edges
       (size_t)(kLevels * B + 1) * 4, (size_t)(kLevels * B + 1) * 4, 64, 64,                         // 53 node_base 54 edge_base 55 lvl_cnt 56 lvl_end
-      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4};          // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
+      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4,           // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
+      128};                                                                                         // 62 lvl_stats
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -273,6 +276,8 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->lvl_cnt = (int*)(b + L.off[55]); e->lvl_end = (int*)(b + L.off[56]);
   e->lvl_list = (int*)(b + L.off[57]); e->row_ptrL = (int*)(b + L.off[58]);
   e->erowL = (int*)(b + L.off[59]); e->ecolL = (int*)(b + L.off[60]); e->ed0L = (float*)(b + L.off[61]);
+  e->lvl_stats = (unsigned long long*)(b + L.off[62]);
+  e->lvl_stats_zeroed = false;          // cleared by the first (eager) call that uses it
   e->erow2 = (int*)(b + L.off[29]); e->ecol2 = (int*)(b + L.off[30]); e->ed02 = (float*)(b + L.off[31]);
   e->row_ptr2 = (int*)(b + L.off[32]); e->deg2 = (int*)(b + L.off[33]);
   e->scan_tmp2 = (int*)(b + L.off[34]); e->seg_base2 = (int*)(b + L.off[35]);
@@ -395,6 +400,7 @@ int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** out) {
     case DSBDD_BUF_LEDGE_ROW: *out = e->erowL; break;
     case DSBDD_BUF_LEDGE_COL: *out = e->ecolL; break;
     case DSBDD_BUF_LEDGE_D0: *out = e->ed0L; break;
+    case DSBDD_BUF_LEVEL_STATS: *out = e->lvl_stats; break;
     default: return fail(DSBDD_ERR_ARG, "unknown buffer id");
   }
   return DSBDD_OK;
@@ -577,7 +583,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     if (prune) {
       LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
                    e->ed0, e->seg_rows, e->seg_edges, e->node_base, e->edge_base, e->lvl_cnt, e->lvl_end,
-                   e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL};
+                   e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL, e->lvl_stats};
+      if (!e->lvl_stats_zeroed) {
+        HIP_TRY(zero_async(e->lvl_stats, 128, s));
+        e->lvl_stats_zeroed = true;
+      }
       hipLaunchKernelGGL(levels_kernel, dim3(B), dim3(kThreads), 0, s, la);
       HIP_TRY(hipGetLastError());
       hipLaunchKernelGGL(level_scan_kernel, dim3(1), dim3(1024), 0, s, la, N);

@@ -306,6 +306,7 @@ struct LevelArgs {
   int* lvl_list;            // [N] nodes ordered by (level, node id)
   int* row_ptr;             // [N + 1] level-ordered list
   int* erow; int* ecol; float* ed0; int e_cap;
+  unsigned long long* stats;   // [2 * kLevels + 1] running sums over calls: lvl_cnt[r], lvl_end[r], calls (bench / tests)
 };
 
 __global__ __launch_bounds__(kThreads) void levels_kernel(LevelArgs a) {
@@ -365,6 +366,11 @@ __global__ __launch_bounds__(1024) void level_scan_kernel(LevelArgs a, int n_nod
   if (t < kLevels) {                        // cumulative ends of the levels
     a.lvl_cnt[t] = t == kLevels - 1 ? carry_n : a.node_base[(t + 1) * a.B];
     a.lvl_end[t] = t == kLevels - 1 ? carry_e : a.edge_base[(t + 1) * a.B];
+    if (a.stats) {
+      a.stats[t] += (unsigned long long)a.lvl_cnt[t];
+      a.stats[kLevels + t] += (unsigned long long)a.lvl_end[t];
+      if (t == 0) a.stats[2 * kLevels] += 1ull;
+    }
   }
 }
 

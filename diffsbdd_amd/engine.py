@@ -337,6 +337,23 @@ class HipEngine:
         out["d0"] = rd(_lib.BUF_LEDGE_D0, E, np.float32)
         return out
 
+    def level_stats(self, raw=False, since=None):
+        """Running sums over the ligand-output-only calls since the workspace was bound (syncs): mean number of
+        nodes with level <= r, mean edge prefix end for r = 0..4, number of calls.  `raw`: the 11 sums themselves
+        (to pass back later as `since`: statistics of the calls in between).  None when there were no calls."""
+        import numpy as np
+        if self.workspace is None:
+            return np.zeros(11) if raw else None
+        torch.cuda.synchronize(self.device)
+        st = self._read(self.buffer_ptr(_lib.BUF_LEVEL_STATS), 11, np.uint64).astype(np.float64)
+        if raw:
+            return st
+        if since is not None:
+            st = st - since
+        if st[10] <= 0:
+            return None
+        return {"nodes": (st[:5] / st[10]).tolist(), "edge_slots": (st[5:10] / st[10]).tolist(), "calls": int(st[10])}
+
     def _read(self, ptr, count, dtype):
         import numpy as np
         itemsize = np.dtype(dtype).itemsize

@@ -195,7 +195,10 @@ enum {
   /* level-ordered list of the last ligand-output-only call in pocket-conditioning mode (csrc/graph.h):
    * level[N], nodes by (level, id) [N], cumulative node counts [5], edge prefix ends [5], and the list */
   DSBDD_BUF_LEVEL, DSBDD_BUF_LEVEL_LIST, DSBDD_BUF_LEVEL_COUNT, DSBDD_BUF_LEVEL_END,
-  DSBDD_BUF_LROW_PTR, DSBDD_BUF_LEDGE_ROW, DSBDD_BUF_LEDGE_COL, DSBDD_BUF_LEDGE_D0
+  DSBDD_BUF_LROW_PTR, DSBDD_BUF_LEDGE_ROW, DSBDD_BUF_LEDGE_COL, DSBDD_BUF_LEDGE_D0,
+  /* uint64[11]: sums over the calls since the workspace was bound of the 5 node counts, the 5 edge prefix
+   * ends, and the number of such calls */
+  DSBDD_BUF_LEVEL_STATS
 };
 int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** ptr_out);
 
