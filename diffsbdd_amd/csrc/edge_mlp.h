@@ -79,6 +79,7 @@ struct EdgeArgs {
   size_t xagg_stride;     // floats between the two copies of xagg / xagg_head
   size_t xhead_stride;
   float norm_factor;
+  int wt_base;            // global index of this launch's first wave tile (the list pointers may start inside the list)
   int* tile_ctr;          // work-queue counters, all zero between launches (graph.h: kTileCtrInts)
   // -DDSBDD_TIMESTAMPS builds only: [64 workgroups][16 marks] of wall_clock64() (100 MHz) for this launch
   unsigned long long* ts;
@@ -125,14 +126,15 @@ __global__ __launch_bounds__(kThreads) void agg_complete_kernel(float* agg, cons
 __global__ __launch_bounds__(kThreads) void agg_complete2_kernel(
     float* agg, const float* head_a, const int* row_ptr_a, const int* deg_a, const float* agg_b,
     const float* head_b, const int* row_ptr_b, const int* deg_b, const int* twin_local, int twin_base,
-    int n_lig, int n_rows, int H) {
+    int n_lig, int n_rows, int H, int n_ghost) {
   const int row = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (row >= n_rows) return;
-  const int da = deg_a[row], sa = row_ptr_a[row];
+  if (row >= n_rows + n_ghost) return;
+  const bool ghost = row >= n_rows;        // rows of the canonical pocket: the B part of pocket atom row - n_rows only
+  const int da = ghost ? 0 : deg_a[row], sa = ghost ? 0 : row_ptr_a[row];
   const int a0 = sa >> 5, a1 = (sa + da - 1) >> 5;
   int db = 0, sb = 0, tw = 0;
   if (row >= n_lig) {
-    const int tl = twin_local[row - n_lig];
+    const int tl = ghost ? row - n_rows : twin_local[row - n_lig];
     db = deg_b[tl]; sb = row_ptr_b[tl]; tw = twin_base + tl;
   }
   const int b0 = sb >> 5, b1 = (sb + db - 1) >> 5;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   float nx_d0 = 0.f, nxr[3] = {0.f, 0.f, 0.f}, nxc[3] = {0.f, 0.f, 0.f};
   auto fetch_idx = [&](int tile) {
     const int e0 = tile * BMB + w * BMW, e = e0 + j;
-    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = tile * 4 + w;
+    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = p.wt_base + tile * 4 + w;
     if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
     if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1];
   };

@@ -57,6 +57,13 @@ struct dsbdd_engine {
   bool lvl_stats_zeroed = false;
   int64_t cap_edgesL = 0;
   int prune = 1;                        // DSBDD_PRUNE=0: evaluate every row in every stage
+  // forward cone (identical pockets): the first message stages evaluate only the rows the ligand can have influenced;
+  // the rest take the values of the canonical pocket, computed once on ghost rows N .. N + n_ghost
+  int cone = 1;                         // DSBDD_CONE=0: off
+  int64_t ghost_slots = 0;              // slots of the ghost segment at the front of the level-ordered list
+  // plan of the last forward (host side): radius and ghost use of every message stage, level of the timed launches
+  std::vector<int> plan_radius, plan_ghost;
+  int plan_timed_level = kLevels - 1;
   // pocket frame of the running chain (dsbdd_engine_set_pocket_frame): raw pocket coordinates are rigid in
   // pocket-conditioning mode, so block 0's pocket-pocket messages are evaluated on them, separately
   bool frame = false;
@@ -130,17 +137,18 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
   const int H = c.hidden_nf, JP = pad4(c.joint_nf + 1);
   const int LE = pad4(2 * (c.atom_nf > c.residue_nf ? c.atom_nf : c.residue_nf));
   const int PQ = (c.reflection_equivariant ? 2 : 4) * H;
-  const int64_t EL = E + 32 * kLevels * B;   // level-ordered list: one padded segment per (level, sample)
+  const int64_t EL = 2 * E + 32 * kLevels * B;   // level-ordered list: ghost segment + one padded segment per (level, sample)
+  const int64_t NG = N + np;                 // + the ghost rows of a canonical pocket (forward cone)
   const int64_t T = EL / 32 + 2;             // wave tiles
   size_t sizes[] = {
-      (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4, (size_t)(N + 1) * 4,  // 0-4
+      (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)NG * 4, (size_t)(N + 1) * 4, // 0-4 (3 deg: + ghosts)
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4,                                                  // 5-7 erow ecol ed0
-      (size_t)N * 12, (size_t)N * 12, (size_t)N * 24, (size_t)B * 12,                               // 8-11 x x_in xagg[2] mean
+      (size_t)NG * 12, (size_t)N * 12, (size_t)N * 24, (size_t)B * 12,                              // 8-11 x x_in xagg[2] mean
       (size_t)N * JP * 4, (size_t)N * LE * 4,                                                       // 12 h0, 13 enc_tmp
-      (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * H * 4, (size_t)N * PQ * 4,                  // 14 h 15 t1 16 agg 17 pq
+      (size_t)NG * H * 4, (size_t)NG * H * 4, (size_t)NG * H * 4, (size_t)N * PQ * 4,               // 14 h 15 t1 16 agg 17 pq
       (size_t)N * JP * 4,                                                                           // 18 hout
       (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
-      (size_t)N * 2 * H * 4,                                                                        // 22 pqg (GCL P|Q)
+      (size_t)NG * 2 * H * 4,                                                                       // 22 pqg (GCL P|Q)
       (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 4,                                      // 23 lane-grouped W2^T copies
       (size_t)T * H * 4, (size_t)T * 2 * 16,                                                        // 24 agg_head, 25 xagg_head[2][T][4]
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4,                       // 26 scan_tmp 27 seg_base 28 tile_ctr
@@ -152,7 +160,7 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * 12, (size_t)N * H * 4, (size_t)T * H * 4,                                         // 47 xcanon 48 aggB 49 agg_headB
       (size_t)N * 4, (size_t)kLevels * B * 4, (size_t)kLevels * B * 4,                              // 50 lvl 51 seg_rows 52 seg_edges
       (size_t)(kLevels * B + 1) * 4, (size_t)(kLevels * B + 1) * 4, 64, 64,                         // 53 node_base 54 edge_base 55 lvl_cnt 56 lvl_end
-      (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4,           // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
+      (size_t)NG * 4, (size_t)(NG + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4,         // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
       128};                                                                                         // 62 lvl_stats
   WsLayout L;
   size_t o = 0;
@@ -200,6 +208,8 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
+  const char* cn = getenv("DSBDD_CONE");
+  if (cn && atoi(cn) == 0) e->cone = 0;
   const char* mwg = getenv("DSBDD_EDGE_MAX_WG");
   if (mwg && atoi(mwg) > 0) e->edge_max_wg = atoi(mwg);
   *out = e;
@@ -269,8 +279,8 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->w2tp = (float*)(b + L.off[23]);
   e->agg_head = (float*)(b + L.off[24]); e->xagg_head = (float*)(b + L.off[25]);
   e->scan_tmp = (int*)(b + L.off[26]); e->seg_base = (int*)(b + L.off[27]); e->tile_ctr = (int*)(b + L.off[28]);
-  e->cap_tiles = (E + 32 * kLevels * B) / 32 + 2;
-  e->cap_edgesL = E + 32 * kLevels * B;
+  e->cap_edgesL = 2 * E + 32 * kLevels * B;
+  e->cap_tiles = e->cap_edgesL / 32 + 2;
   e->lvl = (int*)(b + L.off[50]); e->seg_rows = (int*)(b + L.off[51]); e->seg_edges = (int*)(b + L.off[52]);
   e->node_base = (int*)(b + L.off[53]); e->edge_base = (int*)(b + L.off[54]);
   e->lvl_cnt = (int*)(b + L.off[55]); e->lvl_end = (int*)(b + L.off[56]);
@@ -329,7 +339,25 @@ int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_
   if (rc) return rc;
   e->frame_nlig = n_lig; e->frame_npoc = n_pocket; e->frame_batch = batch;
   e->frame_n3 = n3; e->frame_cap3 = edge_bound_frame;
-  e->frame_shared = (n_frame < n_pocket) ? 1 : 0;
+  e->frame_shared = b3 == 1 ? 1 : 0;      // one representative pocket for the whole batch
+  e->ghost_slots = 0;
+  if (e->frame_shared) {
+    // ghost rows N .. N + n3 of the canonical pocket: coordinates, and the front segment of the level-ordered list
+    const int N = (int)(n_lig + n_pocket);
+    HIP_TRY(hipMemcpyAsync(e->x + 3 * (size_t)N, x_pocket, (size_t)n3 * 12, hipMemcpyDeviceToDevice, s));
+    int64_t gb = (edge_bound_frame + 255) / 256;
+    if (gb > 1024) gb = 1024;
+    hipLaunchKernelGGL(ghost_setup_kernel, dim3((int)gb), dim3(256), 0, s, (const int*)e->erow3, (const int*)e->ecol3,
+                       (const float*)e->ed03, (const int*)e->row_ptr3, (const int*)e->deg3, n3, (int)n_lig, N, e->erowL,
+                       e->ecolL, e->ed0L, (int)e->cap_edgesL, e->deg, e->row_ptrL, e->lvl_list);
+    HIP_TRY(hipGetLastError());
+    int slots = 0;                         // one host sync per chain (the chain start has one already)
+    HIP_TRY(hipMemcpyAsync(&slots, e->row_ptr3 + n3, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (slots < 0 || slots > e->cap_edges || (slots & (kEdgeAlign - 1)))
+      return fail(DSBDD_ERR_CAPACITY, "pocket frame: pocket-pocket list exceeds the edge capacity");
+    e->ghost_slots = slots;
+  }
   e->frame = true;
   return DSBDD_OK;
 }
@@ -338,6 +366,27 @@ int dsbdd_engine_clear_pocket_frame(dsbdd_engine* e) {
   if (!e) return fail(DSBDD_ERR_ARG, "null argument");
   if (e->frame) e->drop_graphs();
   e->frame = false;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghost, int32_t capacity,
+                           int32_t* n_stages, int32_t* timed_level) {
+  if (!e || !radius || !ghost || !n_stages || !timed_level) return fail(DSBDD_ERR_ARG, "null argument");
+  const int n = (int)e->plan_radius.size();
+  if (capacity < n) return fail(DSBDD_ERR_CAPACITY, "plan arrays too short");
+  for (int i = 0; i < n; ++i) { radius[i] = e->plan_radius[i]; ghost[i] = e->plan_ghost[i]; }
+  *n_stages = n; *timed_level = e->plan_timed_level;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value) {
+  if (!e) return fail(DSBDD_ERR_ARG, "null argument");
+  switch (which) {
+    case DSBDD_OPT_PRUNE: e->prune = value ? 1 : 0; break;
+    case DSBDD_OPT_CONE: e->cone = value ? 1 : 0; break;
+    default: return fail(DSBDD_ERR_ARG, "unknown option");
+  }
+  e->drop_graphs();
   return DSBDD_OK;
 }
 
@@ -528,6 +577,36 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // ligand output depends on, prefixes of the level-ordered list (graph.h, "Level-ordered edge list")
   const bool prune = e->prune && subset && !ext && !eps_pocket && !e->trace_h && !e->trace_x && nlig > 0;
   const int G_stages = c.n_layers * c.inv_sublayers;
+  // Forward cone (identical pockets, one t for the batch): after message stage g only the nodes within g + 1 hops of
+  // a ligand node can differ from the ligand-free ("canonical") pocket network, which is evaluated once, on the ghost
+  // rows N .. N + n_ghost (its stage-0 messages are the frame's pocket-pocket launch).  Stage g then computes the
+  // rows of level <= min(g + 1, G - g); the rows the next stage reads beyond those get the canonical values.
+  const bool cone = prune && split0 && e->frame_shared && e->cone && t_count == 1 && G_stages >= 2;
+  const int n_ghost = cone ? (int)e->frame_n3 : 0;
+  const int64_t ghost_slots = cone ? e->ghost_slots : 0;
+  constexpr int LV = kLevels - 1;                       // "everything"
+  auto radius_of = [&](int g) {
+    const int bw = G_stages - g, fw = g + 1;
+    const int r = cone ? (bw < fw ? bw : fw) : bw;
+    return r < LV ? r : LV;
+  };
+  // ghost rows are evaluated while a later stage still reads canonical values: the ascending part of the radii
+  int g_ghost_last = -1;
+  if (cone)
+    for (int g = 0; g + 1 < G_stages; ++g) {
+      const int rd = radius_of(g + 1) + 1 < LV ? radius_of(g + 1) + 1 : LV;
+      if (rd > radius_of(g)) g_ghost_last = g;
+    }
+  e->plan_radius.assign(G_stages, LV); e->plan_ghost.assign(G_stages, 0);
+  e->plan_timed_level = LV;
+  if (prune) {
+    int rt = 0;
+    for (int g = 0; g < G_stages; ++g) {
+      e->plan_radius[g] = radius_of(g); e->plan_ghost[g] = g <= g_ghost_last;
+      if (!(split0 && g == 0) && radius_of(g) > rt) rt = radius_of(g);
+    }
+    e->plan_timed_level = rt;
+  }
   // ---- masks -> offsets, split inputs ---------------------------------------
   {
     const int work = N > B + 1 ? N : B + 1;
@@ -583,7 +662,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     if (prune) {
       LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
                    e->ed0, e->seg_rows, e->seg_edges, e->node_base, e->edge_base, e->lvl_cnt, e->lvl_end,
-                   e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL, e->lvl_stats};
+                   e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL, e->lvl_stats,
+                   n_ghost, (int)ghost_slots};
       if (!e->lvl_stats_zeroed) {
         HIP_TRY(zero_async(e->lvl_stats, 128, s));
         e->lvl_stats_zeroed = true;
@@ -608,9 +688,13 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   const int* L_ptr = prune ? e->row_ptrL : e->row_ptr;
   const int L_cap = prune ? (int)e->cap_edgesL : (int)e->cap_edges;
   const int64_t L_bound = prune ? e->cap_edgesL : edge_bound;
-  // rows / edge prefix of the stage that computes the nodes of level <= r (r >= kLevels - 1: everything)
-  auto rows_of = [&](int r, NodeLinearArgs& a) {
-    if (prune && r < kLevels - 1) { a.row_idx = e->lvl_list; a.m_count = e->lvl_cnt + r; }
+  // rows of the nodes of level <= r (r >= kLevels - 1: everything), with or without the ghost rows in front
+  auto rows_of = [&](int r, bool ghost, NodeLinearArgs& a) {
+    if (!prune || (r >= LV && !ghost)) return;
+    if (r > LV) r = LV;
+    a.row_idx = ghost ? e->lvl_list : e->lvl_list + n_ghost;
+    a.m_count = ghost ? e->lvl_cnt + r : e->lvl_cnt + kLevels + r;
+    a.M = N + n_ghost;
   };
   if (subset) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N, SegAlign{},
@@ -622,10 +706,17 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   }
   // ---- embedding (egnn_new.py:233) ---------------------------------------------
   HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
+  if (cone) {   // the canonical pocket starts from the representative's embedded features (sample 0's pocket rows)
+    const size_t n16 = (size_t)n_ghost * H / 4;
+    hipLaunchKernelGGL(copy16_kernel, dim3((int)((n16 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<uint4*>(e->h + (size_t)N * H),
+                       reinterpret_cast<const uint4*>(e->h + (size_t)nlig * H), n16);
+    HIP_TRY(hipGetLastError());
+  }
 
   const int n_upd = c.update_pocket_coords ? N : nlig;   // update_coords_mask, dynamics.py:130-132
-  const int* e_all = L_ptr + N;
-  const int* e_upd = prune ? e->lvl_end : e->row_ptr + n_upd;   // edges are row-sorted: a prefix (level 0 = ligand rows)
+  const int* e_all = prune ? e->lvl_end + kLevels + LV : e->row_ptr + N;   // (counted from the end of the ghost segment)
+  const int* e_upd = prune ? e->lvl_end + kLevels : e->row_ptr + n_upd;    // edges are row-sorted: a prefix (level 0 = ligand rows)
 
   // lane-grouped copies of the three W2^T matrices of every block (see EdgeMlpW::W2TP)
   const bool bperm = e->edge_bperm && (H == 256 || H == 128);
@@ -647,7 +738,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   auto gcl_pq = [&](int blk, int sub) {
     NodeLinearArgs a{e->h, H, H, nullptr, 0, 0, W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, nullptr,
                      nullptr, 0, e->pqg, 2 * H, (int)N, 2 * H, 0, nullptr, nullptr};
-    rows_of(G_stages - (blk * c.inv_sublayers + sub) + 1, a);   // the stage reads its neighbours one level out
+    const int g = blk * c.inv_sublayers + sub;
+    rows_of(radius_of(g) + 1, g <= g_ghost_last && g > 0, a);    // the stage reads its neighbours one level out
     return a;
   };
   bool pqg_ready = false;
@@ -679,11 +771,16 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         }
       }
       pqg_ready = false;
-      const int radius = G_stages - (blk * c.inv_sublayers + sub);   // this stage computes the nodes of level <= radius
-      const bool all_rows = !prune || radius >= kLevels - 1;
+      const int g = blk * c.inv_sublayers + sub;
+      const int radius = radius_of(g);               // this stage computes the nodes of level <= radius
+      const bool ghost = g <= g_ghost_last;          // ... and the ghost rows of the canonical pocket
+      const bool all_rows = !prune || radius >= LV;
+      // list range of the stage: from the ghost segment or from its end, up to the end of level `radius`
+      const int64_t begin = ghost ? 0 : ghost_slots;
       EdgeArgs ea{};
-      ea.erow = L_row; ea.ecol = L_col; ea.ed0 = L_d0; ea.e_count = all_rows ? e_all : e->lvl_end + radius;
-      ea.e_cap = L_cap; ea.x = e->x;
+      ea.erow = L_row + begin; ea.ecol = L_col + begin; ea.ed0 = L_d0 + begin;
+      ea.e_count = !prune ? e_all : (ghost ? e->lvl_end + radius : e->lvl_end + kLevels + radius);
+      ea.e_cap = L_cap - (int)begin; ea.wt_base = (int)(begin / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
@@ -704,14 +801,14 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         a3.x = e->xcanon; a3.agg = e->aggB; a3.agg_head = e->agg_headB; a3.e_cap = (int)e->cap_edges;
         HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
         HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
-        hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
+        hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + n_ghost + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
                            (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,
-                           (const int*)e->deg3, (const int*)e->twin, nlig, nlig, N, H);
+                           (const int*)e->deg3, (const int*)e->twin, nlig, nlig, N, H, n_ghost);
         HIP_TRY(hipGetLastError());
       } else {
         // (timed: the launches over the whole list only, so that every timed launch is the same work)
-        const bool timed = e->time_now && all_rows && e->ev_used + 2 <= e->ev.size();
+        const bool timed = e->time_now && (all_rows || radius == e->plan_timed_level) && e->ev_used + 2 <= e->ev.size();
         if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
         HIP_TRY(launch_edge(e, s, MODE_GCL, ea, L_bound));
         if (timed) {
@@ -719,8 +816,9 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
           e->ev_used += 2;
         }
         // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
-        hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, e->agg,
-                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, N, H);
+        const int n_rows = N + (ghost ? n_ghost : 0);
+        hipLaunchKernelGGL(agg_complete_kernel, dim3((n_rows + 3) / 4), dim3(kThreads), 0, s, e->agg,
+                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, n_rows, H);
         HIP_TRY(hipGetLastError());
       }
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
@@ -728,9 +826,18 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                         (int)N, H, 1, nullptr, nullptr};
       NodeLinearArgs n2{e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H,
                         (int)N, H, 0, nullptr, nullptr};
-      rows_of(radius, n1); rows_of(radius, n2);
+      rows_of(radius, ghost, n1); rows_of(radius, ghost, n2);
       HIP_TRY(launch_node_linear(s, n1));
       HIP_TRY(launch_node_linear(s, n2));
+      if (ghost) {
+        // the rows the next stage reads but this one did not compute: canonical values
+        const int hi = radius_of(g + 1) + 1 < LV ? radius_of(g + 1) + 1 : LV;
+        if (hi > radius) {
+          hipLaunchKernelGGL(canon_fill_kernel, dim3((N - nlig + 3) / 4), dim3(kThreads), 0, s, e->h,
+                             (const int*)e->lvl, (const int*)e->twin, nlig, N, N, radius, hi, H);
+          HIP_TRY(hipGetLastError());
+        }
+      }
     }
     {
       auto Q = [&](int which) { return W[eq_slot(c, blk, which)]; };
@@ -757,7 +864,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         for (int i = 0; i < nc; ++i) HIP_TRY(launch_node_linear(s, grp[i]));
       }
       EdgeArgs ea{};
-      ea.erow = L_row; ea.ecol = L_col; ea.ed0 = L_d0; ea.e_count = e_upd; ea.e_cap = L_cap; ea.x = e->x;
+      ea.erow = L_row + ghost_slots; ea.ecol = L_col + ghost_slots; ea.ed0 = L_d0 + ghost_slots; ea.e_count = e_upd;
+      ea.e_cap = L_cap - (int)ghost_slots; ea.wt_base = (int)(ghost_slots / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
                            Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers)};

@@ -301,12 +301,16 @@ struct LevelArgs {
   int* seg_edges;           // [kLevels * B] edges (not padded)
   int* node_base;           // [kLevels * B + 1] exclusive scan of seg_rows
   int* edge_base;           // [kLevels * B + 1] exclusive scan of the padded seg_edges
-  int* lvl_cnt;             // [kLevels] nodes with level <= r
-  int* lvl_end;             // [kLevels] end of the edges of the rows with level <= r (padded)
-  int* lvl_list;            // [N] nodes ordered by (level, node id)
-  int* row_ptr;             // [N + 1] level-ordered list
+  int* lvl_cnt;             // [2][kLevels] nodes with level <= r: entries of lvl_list / without the leading ghost rows
+  int* lvl_end;             // [2][kLevels] end of the edges of the rows with level <= r (padded): list position / minus edge_off
+  int* lvl_list;            // [node_off + N] ghost rows, then the nodes ordered by (level, node id)
+  int* row_ptr;             // [N] level-ordered list (the total is lvl_end[kLevels - 1])
   int* erow; int* ecol; float* ed0; int e_cap;
-  unsigned long long* stats;   // [2 * kLevels + 1] running sums over calls: lvl_cnt[r], lvl_end[r], calls (bench / tests)
+  // running sums over calls (bench / tests): [0..5) nodes with level <= r, [5..10) list slots, [10..15) edges, [15] calls
+  unsigned long long* stats;
+  // "ghost" rows of the canonical pocket (engine.hip, forward cone): node_off entries at the front of lvl_list and
+  // edge_off slots (a multiple of kEdgeAlign) at the front of the edge list are theirs, written once per chain
+  int node_off; int edge_off;
 };
 
 __global__ __launch_bounds__(kThreads) void levels_kernel(LevelArgs a) {
@@ -359,17 +363,22 @@ __global__ __launch_bounds__(1024) void level_scan_kernel(LevelArgs a, int n_nod
     const int xe = carry_e + block_scan_1024(e, s_wave, &s_tot);
     carry_e += s_tot;
     __syncthreads();
-    if (k < S) { a.node_base[k] = xn; a.edge_base[k] = xe; }
+    if (k < S) { a.node_base[k] = a.node_off + xn; a.edge_base[k] = a.edge_off + xe; }
   }
-  if (t == 0) { a.node_base[S] = carry_n; a.edge_base[S] = carry_e; a.row_ptr[n_nodes] = carry_e; }
+  if (t == 0) { a.node_base[S] = a.node_off + carry_n; a.edge_base[S] = a.edge_off + carry_e; }
   __syncthreads();
   if (t < kLevels) {                        // cumulative ends of the levels
-    a.lvl_cnt[t] = t == kLevels - 1 ? carry_n : a.node_base[(t + 1) * a.B];
-    a.lvl_end[t] = t == kLevels - 1 ? carry_e : a.edge_base[(t + 1) * a.B];
+    const int cn = t == kLevels - 1 ? a.node_off + carry_n : a.node_base[(t + 1) * a.B];
+    const int ce = t == kLevels - 1 ? a.edge_off + carry_e : a.edge_base[(t + 1) * a.B];
+    a.lvl_cnt[t] = cn; a.lvl_cnt[kLevels + t] = cn - a.node_off;
+    a.lvl_end[t] = ce; a.lvl_end[kLevels + t] = ce - a.edge_off;
     if (a.stats) {
-      a.stats[t] += (unsigned long long)a.lvl_cnt[t];
-      a.stats[kLevels + t] += (unsigned long long)a.lvl_end[t];
-      if (t == 0) a.stats[2 * kLevels] += 1ull;
+      unsigned long long ed = 0;            // edges (without padding) of the rows with level <= t
+      for (int k = 0; k < (t + 1) * a.B; ++k) ed += (unsigned long long)a.seg_edges[k];
+      a.stats[t] += (unsigned long long)(cn - a.node_off);
+      a.stats[kLevels + t] += (unsigned long long)(ce - a.edge_off);
+      a.stats[2 * kLevels + t] += ed;
+      if (t == 0) a.stats[3 * kLevels] += 1ull;
     }
   }
 }
@@ -415,6 +424,40 @@ __global__ __launch_bounds__(kThreads) void level_place_kernel(LevelArgs a) {
   pads(e_run);
 }
 
+// Ghost rows of the canonical pocket: the static pocket-pocket list of the frame's representative (node ids
+// id_src + i) becomes the front segment of the level-ordered list with node ids id_dst + i; their degrees,
+// list positions and places at the front of lvl_list are static for the chain.
+__global__ void ghost_setup_kernel(const int* erow3, const int* ecol3, const float* ed03, const int* row_ptr3,
+                                   const int* deg3, int n3, int id_src, int id_dst, int* erow, int* ecol,
+                                   float* ed0, int e_cap, int* deg, int* row_ptr, int* lvl_list) {
+  const int total = min(row_ptr3[n3], e_cap);
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int r = erow3[p];
+    erow[p] = r < 0 ? -1 : r - id_src + id_dst;
+    ecol[p] = r < 0 ? 0 : ecol3[p] - id_src + id_dst;
+    ed0[p] = ed03[p];
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
+    deg[id_dst + i] = deg3[i];
+    row_ptr[id_dst + i] = row_ptr3[i];
+    lvl_list[i] = id_dst + i;
+  }
+}
+
+// h[i] <- h[ghost twin of i] for the pocket rows with lo < level <= hi: rows the next message stage reads but the
+// ligand could not have influenced yet -- their value is the canonical pocket's (engine.hip, forward cone).
+__global__ __launch_bounds__(kThreads) void canon_fill_kernel(float* h, const int* lvl, const int* twin_local,
+                                                              int n_lig, int n_nodes, int ghost_base, int lo,
+                                                              int hi, int H) {
+  const int i = n_lig + ((blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (i >= n_nodes) return;
+  const int L = lvl[i];
+  if (L <= lo || L > hi) return;
+  const float* src = h + (size_t)(ghost_base + twin_local[i - n_lig]) * H;
+  float* dst = h + (size_t)i * H;
+  for (int k = 4 * lane; k < H; k += 256) *reinterpret_cast<float4*>(dst + k) = ld4(src + k);
+}
+
 __global__ void level_copy_kernel(LevelArgs a, int n_nodes) {
   const int total = a.row_ptr_nat[n_nodes];
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -433,6 +476,11 @@ __global__ void zero_kernel(uint4* p, size_t n16, unsigned char* tail, int n_tai
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
     p[i] = z;
   if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0;
+}
+
+__global__ void copy16_kernel(uint4* dst, const uint4* src, size_t n16) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 
 // ptr must be 16-byte aligned (every workspace buffer is 256-byte aligned)

@@ -547,7 +547,7 @@ class EnVariationalDiffusion(nn.Module):
             sizes = pocket['size'].to(dev).to(torch.int64)
             x = pocket['x'].to(device=dev, dtype=torch.float32)
             shared = False
-            if self.share_identical_pockets and batch > 1 and bool((sizes == sizes[0]).all()) \
+            if self.share_identical_pockets and bool((sizes == sizes[0]).all()) \
                     and int(sizes[0]) * batch == x.shape[0]:
                 n0 = int(sizes[0])
                 h = pocket['one_hot'].to(dev)
@@ -571,7 +571,8 @@ class EnVariationalDiffusion(nn.Module):
         if buf is None:
             if not hasattr(self, "_dyn_bufs") or len(self._dyn_bufs) > 16:
                 self._dyn_bufs = {}
-            buf = (torch.empty((batch,), dtype=torch.float32, device=z_lig.device),
+            # one t for the whole batch (dynamics.py:105-107 accepts it; the engine's forward cone requires it)
+            buf = (torch.empty((1,), dtype=torch.float32, device=z_lig.device),
                    torch.empty_like(z_lig), torch.empty_like(z_pocket) if want_pocket else None)
             self._dyn_bufs[key] = buf
         t, eps_l, eps_p = buf

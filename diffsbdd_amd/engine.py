@@ -323,36 +323,52 @@ class HipEngine:
     def last_levels(self, n_nodes):
         """Level structures of the last ligand-output-only call in pocket-conditioning mode (csrc/graph.h,
         "Level-ordered edge list"), as numpy arrays (debug / tests; syncs): dict with level[N], order[N] (nodes by
-        (level, id)), count[5] (nodes with level <= r), end[5] (edge prefix ends), row_ptr[N + 1] and the
-        re-ordered list row / col / d0 (padding entries have row = -1)."""
+        (level, id)), count[5] (nodes with level <= r), end[5] (list position where the rows of level <= r end),
+        row_ptr[N], deg[N], the re-ordered list row / col / d0 (padding entries have row = -1), and the number of
+        ghost nodes / list slots of a canonical pocket in front of them (forward cone)."""
         import numpy as np
         torch.cuda.synchronize(self.device)
         rd = lambda which, n, dt: self._read(self.buffer_ptr(which), n, dt)
-        out = {"level": rd(_lib.BUF_LEVEL, n_nodes, np.int32), "order": rd(_lib.BUF_LEVEL_LIST, n_nodes, np.int32),
-               "count": rd(_lib.BUF_LEVEL_COUNT, 5, np.int32), "end": rd(_lib.BUF_LEVEL_END, 5, np.int32),
-               "row_ptr": rd(_lib.BUF_LROW_PTR, n_nodes + 1, np.int32), "deg": rd(_lib.BUF_DEG, n_nodes, np.int32)}
-        E = int(out["row_ptr"][-1])
+        cnt, end = rd(_lib.BUF_LEVEL_COUNT, 10, np.int32), rd(_lib.BUF_LEVEL_END, 10, np.int32)
+        ng, gs = int(cnt[4] - cnt[9]), int(end[4] - end[9])
+        out = {"level": rd(_lib.BUF_LEVEL, n_nodes, np.int32), "order": rd(_lib.BUF_LEVEL_LIST, ng + n_nodes, np.int32)[ng:],
+               "count": cnt[5:], "end": end[:5], "ghost_nodes": ng, "ghost_slots": gs,
+               "row_ptr": rd(_lib.BUF_LROW_PTR, n_nodes, np.int32), "deg": rd(_lib.BUF_DEG, n_nodes, np.int32)}
+        E = int(end[4])
         out["row"] = rd(_lib.BUF_LEDGE_ROW, E, np.int32)
         out["col"] = rd(_lib.BUF_LEDGE_COL, E, np.int32)
         out["d0"] = rd(_lib.BUF_LEDGE_D0, E, np.float32)
         return out
 
     def level_stats(self, raw=False, since=None):
-        """Running sums over the ligand-output-only calls since the workspace was bound (syncs): mean number of
-        nodes with level <= r, mean edge prefix end for r = 0..4, number of calls.  `raw`: the 11 sums themselves
-        (to pass back later as `since`: statistics of the calls in between).  None when there were no calls."""
+        """Running sums over the ligand-output-only calls since the workspace was bound (syncs): per call, the mean
+        number of nodes with level <= r, list slots and edges of those rows (r = 0..4), and the number of calls.
+        `raw`: the 16 sums themselves (to pass back later as `since`: statistics of the calls in between).
+        None when there were no such calls."""
         import numpy as np
         if self.workspace is None:
-            return np.zeros(11) if raw else None
+            return np.zeros(16) if raw else None
         torch.cuda.synchronize(self.device)
-        st = self._read(self.buffer_ptr(_lib.BUF_LEVEL_STATS), 11, np.uint64).astype(np.float64)
+        st = self._read(self.buffer_ptr(_lib.BUF_LEVEL_STATS), 16, np.uint64).astype(np.float64)
         if raw:
             return st
         if since is not None:
             st = st - since
-        if st[10] <= 0:
+        if st[15] <= 0:
             return None
-        return {"nodes": (st[:5] / st[10]).tolist(), "edge_slots": (st[5:10] / st[10]).tolist(), "calls": int(st[10])}
+        return {"nodes": (st[:5] / st[15]).tolist(), "list_slots": (st[5:10] / st[15]).tolist(),
+                "edges": (st[10:15] / st[15]).tolist(), "calls": int(st[15])}
+
+    def last_plan(self):
+        """(radius per message stage, ghost flag per stage, level of the timed launches) of the last forward."""
+        r = (C.c_int32 * 64)()
+        g = (C.c_int32 * 64)()
+        n, tl = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.dsbdd_engine_last_plan(self.handle, r, g, 64, C.byref(n), C.byref(tl)))
+        return list(r[:n.value]), list(g[:n.value]), tl.value
+
+    def set_option(self, which, value):
+        _lib.check(self.lib.dsbdd_engine_set_option(self.handle, which, int(value)))
 
     def _read(self, ptr, count, dtype):
         import numpy as np

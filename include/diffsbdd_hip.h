@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DSBDD_ABI_VERSION 3
+#define DSBDD_ABI_VERSION 4
 
 enum {
   DSBDD_OK = 0,
@@ -188,6 +188,18 @@ int dsbdd_engine_profile_read(dsbdd_engine* e, double* total_ms, int64_t* launch
  * DSBDD_GRAPH=0.  Counters: graph replays, captures, eager calls. */
 int dsbdd_engine_graph_stats(const dsbdd_engine* e, int64_t* replays, int64_t* captures, int64_t* eager);
 
+/* Which rows the message stages of the last forward evaluated (host-side bookkeeping, no sync): radius[g] = hop
+ * level up to which stage g computed its rows (4 = every row), ghost[g] = 1 when the stage also evaluated the
+ * canonical pocket (identical pockets, csrc/engine.hip "forward cone"), timed_level = radius of the launches that
+ * dsbdd_engine_profile brackets.  All 4 / 0 unless the call was a ligand-output-only call in pocket-conditioning
+ * mode (eps_pocket == NULL), see csrc/graph.h "Level-ordered edge list". */
+int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghost, int32_t capacity,
+                           int32_t* n_stages, int32_t* timed_level);
+
+/* Switches of the dead-row elimination (default on; environment: DSBDD_PRUNE=0 / DSBDD_CONE=0). */
+enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1 };
+int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value);
+
 /* Introspection of the last forward (device pointers into the workspace). */
 enum {
   DSBDD_BUF_EDGE_ROW = 0, DSBDD_BUF_EDGE_COL, DSBDD_BUF_EDGE_D0, DSBDD_BUF_ROW_PTR,
@@ -196,8 +208,8 @@ enum {
    * level[N], nodes by (level, id) [N], cumulative node counts [5], edge prefix ends [5], and the list */
   DSBDD_BUF_LEVEL, DSBDD_BUF_LEVEL_LIST, DSBDD_BUF_LEVEL_COUNT, DSBDD_BUF_LEVEL_END,
   DSBDD_BUF_LROW_PTR, DSBDD_BUF_LEDGE_ROW, DSBDD_BUF_LEDGE_COL, DSBDD_BUF_LEDGE_D0,
-  /* uint64[11]: sums over the calls since the workspace was bound of the 5 node counts, the 5 edge prefix
-   * ends, and the number of such calls */
+  /* uint64[16]: sums over the calls since the workspace was bound of the 5 node counts, the 5 list prefix
+   * lengths, the 5 edge counts (level <= r), and the number of such calls */
   DSBDD_BUF_LEVEL_STATS
 };
 int dsbdd_engine_buffer(const dsbdd_engine* e, int which, void** ptr_out);

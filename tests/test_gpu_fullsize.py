@@ -262,7 +262,9 @@ def _hop_levels(row, col, n_lig, n_nodes, n_levels=5):
     ("crossdock_fullatom_cond", 8, False),
     ("crossdock_fullatom_cond", 8, True),
     ("crossdock_ca_cond", 8, False),
+    ("crossdock_fullatom_cond", 8, "shared"),   # identical pockets: forward cone on top (ghost rows of the canonical pocket)
     ("small_cond", 6, True),              # two blocks: block 0 is a pruned stage AND split by the pocket frame
+    ("small_cond", 6, "shared"),
     ("small_variant", 6, False),          # two sublayers per block, ligand cutoff, E(3) variant
 ])
 def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
@@ -278,14 +280,24 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
     nl, n0 = len(ml) // B, len(mp) // B
     sizes = torch.full((B,), n0)
 
-    def run(want_pocket, lo=0):
+    shared = frame == "shared"
+    from diffsbdd_amd import _lib
+    if shared:      # identical pockets: every sample's pocket is EXACTLY sample 0's plus a translation (what a chain has)
+        raw = xp[:n0, :3].repeat(B, 1)
+        delta = (xp[:, :3] - raw).view(B, n0, 3)[:, 0]
+        xp = torch.cat([raw + delta[mp], xp[:, 3:]], 1)
+    else:
+        raw = xp[:, :3]
+
+    def run(want_pocket, lo=0, cone=True):
         sl, sp, batch = slice(lo * nl, None), slice(lo * n0, None), B - lo
         m = make_dynamics(cfg, sd)
         eng = m.engine()
-        a = [v.to(d) for v in (xl[sl], xp[sp], t[:batch], ml[sl] - lo, mp[sp] - lo)]
+        a = [v.to(d) for v in (xl[sl], xp[sp], t[:1] if shared else t[:batch], ml[sl] - lo, mp[sp] - lo)]
         cap = edge_capacity(a[3], a[4], batch)
         if frame:
-            eng.set_pocket_frame(xp[sp, :3].to(d), a[4], sizes[:batch].to(d), a[0].shape[0], batch, cap, False)
+            eng.set_pocket_frame(raw[sp].to(d), a[4], sizes[:batch].to(d), a[0].shape[0], batch, cap, shared)
+        eng.set_option(_lib.OPT_CONE, cone)
         outs = [m.forward_async(*a, batch=batch, edge_cap=cap, want_pocket=want_pocket) for _ in range(3)]
         torch.cuda.synchronize()
         assert all(int(o[2].item()) == 0 for o in outs)
@@ -293,12 +305,23 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
         n = a[0].shape[0] + a[1].shape[0]
         er, ec = eng.last_edges(n)
         lv = eng.last_levels(n) if not want_pocket else None
+        plan = eng.last_plan()
         if frame:
             eng.clear_pocket_frame()
-        return outs[0][0], torch.stack([er, ec]), lv
+        return outs[0][0], torch.stack([er, ec]), lv, plan
 
-    full, edges, _ = run(True)
-    lig, edges2, lv = run(False)
+    full, edges, _, plan = run(True)
+    assert set(plan[0]) == {4} and not any(plan[1])                 # every row in every stage
+    lig, edges2, lv, plan = run(False)
+    G = cfg["n_layers"] * cfg["inv_sublayers"]
+    if shared:      # forward cone: stage g computes level <= min(g + 1, G - g), ghosts while the radii ascend
+        assert plan[0] == [min(g + 1, G - g, 4) for g in range(G)]
+        assert plan[1] == [int(g + 1 < G and min(min(g + 2, G - g - 1) + 1, 4) > min(g + 1, G - g, 4)) for g in range(G)]
+        nocone, _, _, plan2 = run(False, cone=False)
+        assert plan2[0] == [min(G - g, 4) for g in range(G)] and not any(plan2[1])
+        assert (nocone - lig).abs().max().item() < 2e-5
+    else:
+        assert plan[0] == [min(G - g, 4) for g in range(G)] and not any(plan[1])
     assert torch.equal(edges, edges2)
     N = len(ml) + len(mp)
     row, col = edges[0].numpy(), edges[1].numpy()
@@ -311,7 +334,11 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
     deg = np.bincount(row, minlength=N)
     assert np.array_equal(lv["deg"], deg)
     nat_ptr = np.concatenate([[0], np.cumsum(deg)])            # natural list without its padding
-    pos = 0
+    ghost_slots = 0
+    if shared:      # the canonical pocket's pocket-pocket list sits in front of the level-ordered list
+        ghost_slots = (int(((row >= len(ml)) & (col >= len(ml)) & (row < len(ml) + n0)).sum()) + 31) // 32 * 32
+    assert lv["ghost_slots"] == ghost_slots and lv["ghost_nodes"] == (n0 if shared else 0)
+    pos = ghost_slots
     batch_of = np.concatenate([ml.numpy(), mp.numpy()])
     prev_key = None
     level_last = {}
@@ -326,13 +353,14 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
         assert np.array_equal(lv["col"][s], col[nat_ptr[i]:nat_ptr[i + 1]])
         pos += deg[i]
         level_last[want[i]] = pos
-    running = 0
+    running = ghost_slots
     for r in range(5):                                         # edge prefix of the rows with level <= r
         if r in level_last:
             running = (level_last[r] + 31) // 32 * 32
         assert lv["end"][r] == running
-    assert lv["row_ptr"][N] == running
+    assert lv["end"][4] == running
     pad = np.ones(len(lv["row"]), dtype=bool)
+    pad[:ghost_slots] = False
     for i in range(N):
         pad[lv["row_ptr"][i]:lv["row_ptr"][i] + deg[i]] = False
     assert (lv["row"][pad] == -1).all()
@@ -342,5 +370,5 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
         o_l, _, _ = eo.dynamics_forward(sd, cfg, xl, xp, t, ml, mp, edges=edges)
     assert excess(lig, o_l) <= 0
     # (iii) the second half of the batch on its own
-    half, _, _ = run(False, lo=B // 2)
+    half, _, _, _ = run(False, lo=B // 2)
     assert torch.equal(half, lig[B // 2 * nl:])
