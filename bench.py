@@ -176,6 +176,7 @@ def main():
                          "'free' is sample_given_pocket free-running on the random weights, whose ligand drifts out "
                          "of the pocket (fewer ligand-pocket contacts, cheaper calls).  The other one is reported "
                          "as a secondary figure.")
+    ap.add_argument("--no-other-leg", action="store_true", help="skip the secondary figure (the other state model)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -267,7 +268,7 @@ def main():
     e_main = eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]) if replicas is None else None
     # secondary figure: the other state model of the pocket-conditioned chain (one warm-up, one timed chain)
     other = None
-    if not joint and replicas is None and world == 1:
+    if not joint and replicas is None and world == 1 and not args.no_other_leg:
         o_states = "free" if args.states == "anchored" else "anchored"
         chain(300, o_states)
         sync()

@@ -373,8 +373,13 @@ __global__ __launch_bounds__(1024) void level_scan_kernel(LevelArgs a, int n_nod
     a.lvl_cnt[t] = cn; a.lvl_cnt[kLevels + t] = cn - a.node_off;
     a.lvl_end[t] = ce; a.lvl_end[kLevels + t] = ce - a.edge_off;
     if (a.stats) {
-      unsigned long long ed = 0;            // edges (without padding) of the rows with level <= t
-      for (int k = 0; k < (t + 1) * a.B; ++k) ed += (unsigned long long)a.seg_edges[k];
+      int own = 0;                          // edges (without padding) of level t, then of the rows with level <= t
+      for (int k = t * a.B; k < (t + 1) * a.B; ++k) own += a.seg_edges[k];
+      s_wave[t] = own;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long ed = 0;
+      for (int k = 0; k <= t; ++k) ed += (unsigned long long)s_wave[k];   // (same wave: LDS writes are in order)
       a.stats[t] += (unsigned long long)(cn - a.node_off);
       a.stats[kLevels + t] += (unsigned long long)(ce - a.edge_off);
       a.stats[2 * kLevels + t] += ed;
