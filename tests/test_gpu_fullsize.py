@@ -372,3 +372,50 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
     # (iii) the second half of the batch on its own
     half, _, _, _ = run(False, lo=B // 2)
     assert torch.equal(half, lig[B // 2 * nl:])
+
+
+def test_full_atom_chains_with_identical_pockets_vs_oracle():
+    """Free-running chains on a full-atom pocket repeated over the batch -- the configuration in which the
+    chain hands the engine a pocket frame and the engine runs the forward cone on a canonical pocket
+    (csrc/engine.hip): ConditionalDDPM.sample_given_pocket and .inpaint (every ligand atom known: bench.py's
+    anchored states) against the oracle with the same noise tape, 4 steps, 1e-3 on coordinates (the tolerance
+    of the other free-running tests), identical atom types."""
+    from diffsbdd_amd.pocket import prepare_pocket
+    arch, B, T = "crossdock_fullatom_cond", 3, 4
+    cfg, dd = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, 0)
+    z = np.load(os.path.join(GOLDEN_DIR, "pocket_3rfm.npz"))
+    pocket = prepare_pocket(z["fa_x"], z["fa_types"], cfg["residue_nf"], repeats=B)
+    n_lig = torch.full((B,), 14)
+    om = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
+                        dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
+    model = _make_ddpm(arch, sd)
+    # sample_given_pocket
+    tape = do.NoiseTape(5)
+    with oracle_threads():
+        o_l, o_p, _, _ = do.cond_sample_given_pocket(om, {k: v.clone() for k, v in pocket.items()}, n_lig, tape, timesteps=T)
+    model.set_noise_source(do.NoiseReplay(tape.draws))
+    h_l, h_p, _, _ = model.sample_given_pocket({k: v.clone() for k, v in pocket.items()}, n_lig, timesteps=T)
+    radius, ghost, _ = model.dynamics.engine().last_plan()
+    assert radius == [1, 2, 3, 3, 2, 1] and ghost == [1, 1, 1, 0, 0, 0]          # the cone was on
+    assert (h_l.cpu()[:, :3] - o_l[:, :3]).abs().max().item() < 1e-3
+    assert torch.equal(h_l.cpu()[:, 3:].long(), o_l[:, 3:].long())
+    assert (h_p.cpu() - o_p).abs().max().item() < 1e-3
+    # inpaint with the 3rfm ligand as the known part (all atoms)
+    g = torch.Generator().manual_seed(2)
+    ligand = {"x": torch.from_numpy(z["ligand_x"]).float().repeat(B, 1),
+              "one_hot": torch.nn.functional.one_hot(torch.randint(0, cfg["atom_nf"], (B * 14,), generator=g),
+                                                     cfg["atom_nf"]).float(),
+              "size": n_lig, "mask": torch.repeat_interleave(torch.arange(B), 14)}
+    fixed = torch.ones(B * 14)
+    tape = do.NoiseTape(6)
+    with oracle_threads():
+        o_l, o_p, _, _ = do.cond_inpaint(om, {k: v.clone() for k, v in ligand.items()},
+                                         {k: v.clone() for k, v in pocket.items()}, fixed, tape, resamplings=1, timesteps=T)
+    model.set_noise_source(do.NoiseReplay(tape.draws))
+    h_l, h_p, _, _ = model.inpaint({k: v.clone() for k, v in ligand.items()}, {k: v.clone() for k, v in pocket.items()},
+                                   fixed, resamplings=1, timesteps=T)
+    assert model.dynamics.engine().last_plan()[0] == [1, 2, 3, 3, 2, 1]
+    assert (h_l.cpu()[:, :3] - o_l[:, :3]).abs().max().item() < 1e-3
+    assert torch.equal(h_l.cpu()[:, 3:].long(), o_l[:, 3:].long())
+    assert (h_p.cpu() - o_p).abs().max().item() < 1e-3
