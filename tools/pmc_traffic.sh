@@ -9,11 +9,11 @@ TAG=${1:-r2}
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  (cd /tmp && timeout 200 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p -- python $R/bench.py --steps 1 --warmup 0 --timesteps 5 --no-cpu-baseline --no-kernel-timing > /tmp/pmc_$C.log 2>&1)
+  (cd /tmp && timeout 200 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p -- python $R/bench.py --steps 1 --warmup 0 --timesteps 5 --no-cpu-baseline --no-kernel-timing --no-other-leg > /tmp/pmc_$C.log 2>&1)
   DB=$(find /tmp/pmc_$C -name "*.db" | head -1)
   if [ -z "$DB" ]; then echo "no db for $C"; tail -3 /tmp/pmc_$C.log; continue; fi
   L=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
-  python $R/tools/rocpd_pmc.py $DB edge_wave > $R/gpurun_out/${TAG}_pmc_$L.md
+  python $R/tools/rocpd_pmc.py $DB edge_wave --longest 0.9 > $R/gpurun_out/${TAG}_pmc_$L.md
   rm -rf /tmp/pmc_$C
 done
 python - <<PY
@@ -29,6 +29,7 @@ out = {"kernel": "edge_wave_kernel<256, MODE_GCL, BPERM>", "launches_averaged": 
        "FETCH_SIZE_kb": f, "WRITE_SIZE_kb": w, "fetch_bytes_corrected": 2 * f * 1024, "write_bytes": w * 1024,
        "traffic_bytes_per_launch": 2 * f * 1024 + w * 1024,
        "traffic_bytes_per_launch_uncorrected": (f + w) * 1024,
+       "dispatch_filter": "duration >= 0.9 x the 90th-percentile duration of the kernel = the launches bench.py times (largest radius)",
        "_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 0 "
                    "--timesteps 5; bytes = counter * 1024; FETCH doubled per the gfx950 note of MI355X_MICROARCH.md (upper bound)"}
 json.dump(out, open("$R/gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)

@@ -3,7 +3,9 @@
 (`rocprofv3 --pmc ... --kernel-trace -d DIR -o NAME`).  Prints one markdown
 table: kernel | dispatches | avg duration us | avg of every counter (summed over
 the counter's instances/dimensions per dispatch).
-Usage: rocpd_pmc.py results.db [name-filter]"""
+Usage: rocpd_pmc.py results.db [name-filter] [--longest F]
+--longest F: per kernel name, only the dispatches whose duration is >= F x the 90th-percentile duration of that
+name (the launches of a kernel differ in size when the stages run on prefixes of the edge list)."""
 import re
 import sqlite3
 import sys
@@ -12,7 +14,8 @@ from collections import defaultdict
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    flt = sys.argv[2] if len(sys.argv) > 2 else ""
+    flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else ""
+    longest = float(sys.argv[sys.argv.index("--longest") + 1]) if "--longest" in sys.argv else 0.0
     cur = db.cursor()
     names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
     if "--schema" in sys.argv:
@@ -38,12 +41,20 @@ def main():
         key = "dispatch_id"
     kern = {r[0]: (r[1], r[2]) for r in cur.execute(f"select {key}, name, end-start from kernels")}
     agg = defaultdict(lambda: [0, 0.0, defaultdict(float)])
+    clean = lambda nm: re.sub(r"\(.*", "", nm).replace("void ", "")
+    durs = defaultdict(list)
+    for d in per_disp:
+        if d in kern:
+            durs[clean(kern[d][0])].append(kern[d][1])
+    dmax = {k: sorted(v)[min(len(v) - 1, int(0.9 * len(v)))] for k, v in durs.items()}
     for d, ctr in per_disp.items():
         if d not in kern:
             continue
         nm, dur = kern[d]
-        nm = re.sub(r"\(.*", "", nm).replace("void ", "")
+        nm = clean(nm)
         if flt and flt not in nm:
+            continue
+        if dur < longest * dmax[nm]:
             continue
         a = agg[nm]
         a[0] += 1
