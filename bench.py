@@ -266,6 +266,7 @@ def main():
     eng.profile(False, 0)
     lv_main = eng.level_stats(since=lv0)
     e_main = eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]) if replicas is None else None
+    timed_level = eng.last_plan()[2]
     # secondary figure: the other state model of the pocket-conditioned chain (one warm-up, one timed chain)
     other = None
     if not joint and replicas is None and world == 1 and not args.no_other_leg:
@@ -291,6 +292,10 @@ def main():
         N = B * args.n_lig + pocket0["x"].shape[0]
         if replicas is None:
             E = E_timed = e_main          # edges of the main leg's last call
+            # the timed launches are those of the largest radius of the call's plan (csrc/engine.hip): the rows of
+            # level <= timed_level, a prefix of the edge list whose mean length the engine accumulated
+            if lv_main is not None and timed_level < 4:
+                E_timed = lv_main["edges"][timed_level]
         else:   # the timed engine (replica 0) runs the first sub-batch only
             per = (B + n_streams - 1) // n_streams
             subs = [min(per, B - i * per) for i in range(n_streams) if B - i * per > 0]
@@ -306,12 +311,12 @@ def main():
         N_timed = N if replicas is None else n_sub[0]
         bytes_per_launch = 4.0 * (N_timed * 2 * H + H * H + 3 * E_timed + 3 * N_timed + N_timed * H)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-        if args.workload == "crossdock_fullatom_cond" and B == 64 and os.path.isfile(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r2f_pmc_traffic.json")
+        if args.workload == "crossdock_fullatom_cond" and B == 64 and args.states == "anchored" and os.path.isfile(tpath):
             # PMC counters cannot be read from inside this process; the figure is the one measured
             # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r2_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r2f_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
         roofline = {
             "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
             "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -322,7 +327,8 @@ def main():
             # timed = the message-stage launches that run over the WHOLE edge list (same work every launch).
             # Pocket-conditioned chains: block 0 is split by the pocket frame and the last stages run on prefixes
             # of the level-ordered list (csrc/graph.h), so fewer than n_layers launches per call qualify.
-            "timed_launch_kind": "full edge list",
+            "timed_launch_kind": ("full edge list" if replicas is not None or lv_main is None or timed_level >= 4
+                                  else f"rows of hop level <= {timed_level} (the call's largest message-stage launches)"),
             # mean over the calls of the chain: nodes / edge-list slots with hop level <= r (r = 0: ligand rows,
             # r = 4: everything); message stage g of G evaluates level <= G - g
             "live_levels": lv_main,

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Per-kernel summary (count / total / avg / min / max / share) from a rocprofv3
 rocpd sqlite database (`rocprofv3 --kernel-trace --stats -d DIR -o NAME` writes
-DIR/NAME_results.db on ROCm 7.2).  Usage: rocpd_stats.py results.db [top_n]"""
+DIR/NAME_results.db on ROCm 7.2).  Usage: rocpd_stats.py results.db [top_n]
+The launches of the message-stage kernel differ in size (every stage runs on a prefix of the level-ordered edge
+list): a second table splits `edge_wave_kernel<H, 0, ...>` into its largest launches (duration >= 0.9 x the
+90th percentile: the ones bench.py brackets with HIP events) and the rest."""
 import re
 import sqlite3
 import sys
@@ -24,6 +27,21 @@ def main():
         nm = re.sub(r"\(.*", "", r[0]).replace("void ", "")[:64]
         print(f"| `{nm}` | {r[1]} | {r[2] / 1e6:.2f} | {r[3] / 1e3:.1f} | {r[4] / 1e3:.1f} | {r[5] / 1e3:.1f} | "
               f"{100 * r[2] / tot:.1f} | {r[6]}+{r[7]} | {r[8]} | {r[9]}x{r[10]} |")
+
+
+    # size classes of the message-stage kernel
+    ed = cur.execute("select name, end-start from kernels where name like '%edge_wave_kernel<%, 0, %'").fetchall()
+    if ed:
+        d = sorted(x[1] for x in ed)
+        ref = d[min(len(d) - 1, int(0.9 * len(d)))]
+        big = [x for x in d if x >= 0.9 * ref]
+        rest = [x for x in d if x < 0.9 * ref]
+        print()
+        print("| message-stage launches (`edge_wave_kernel<H, 0, ...>`) | calls | avg us | min us | max us |")
+        print("|---|---|---|---|---|")
+        for label, v in (("largest (the timed ones: rows of the largest radius)", big), ("all others (smaller prefixes, block 0 split)", rest)):
+            if v:
+                print(f"| {label} | {len(v)} | {sum(v) / len(v) / 1e3:.1f} | {v[0] / 1e3:.1f} | {v[-1] / 1e3:.1f} |")
 
 
 if __name__ == "__main__":
