@@ -143,6 +143,10 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* workspace, size_t bytes, 
  * block 0 are the same in every sample (same atom features, same time step, same distances) and are then
  * evaluated once -- 82 % of that stage's edges at the benchmark batch.  Both variants give bit-identical
  * results: the association A + B and the raw-coordinate distances are the same.
+ * One representative for the whole batch (batch_frame == 1) additionally enables the FORWARD CONE of the
+ * ligand-output-only calls (eps_pocket == NULL, t_count == 1; see dsbdd_dynamics_forward): the ligand-free pocket
+ * network is evaluated once on ghost rows and stage g computes the rows within min(g + 1, G - g) hops of a ligand
+ * atom only.  This function synchronises the stream once (it reads the frame's edge count back).
  * The frame lives in the workspace; it is dropped by bind_workspace and by dsbdd_engine_clear_pocket_frame,
  * and only applies to calls with exactly (n_lig, n_pocket, batch).  edge_bound_frame = upper bound on the
  * frame's edge count (sum of squared pocket sizes of the frame samples + 32 per sample). */
@@ -163,7 +167,11 @@ int dsbdd_engine_set_trace(dsbdd_engine* e, float* trace_h, float* trace_x);
  *     (row,col), node numbering [ligand | pocket]); NULL -> radius graph is
  *     built on device as dynamics.py:169-187 does.
  *   eps_lig   [n_lig][3+atom_nf]       eps_pocket [n_pocket][3+residue_nf] (may be NULL)
- *   status    int32 device word, OR-ed with DSBDD_STATUS_* (caller zeroes it) */
+ *   status    int32 device word, OR-ed with DSBDD_STATUS_* (caller zeroes it)
+ * eps_pocket == NULL in pocket-conditioning mode (what ConditionalDDPM's chains need, conditional_model.py:268-272)
+ * lets the engine skip every row the ligand output does not depend on: message stage g of G evaluates the nodes
+ * within G - g hops of a ligand atom (csrc/graph.h "Level-ordered edge list"; dsbdd_engine_last_plan reports the
+ * radii).  eps_lig is the same up to fp32 summation order (different wave-tile boundaries). */
 int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig,
                            const float* xh_pocket, const float* t, int64_t t_count,
                            const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
@@ -172,8 +180,8 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig,
                            float* eps_pocket, int32_t* status);
 
 /* Timing of the dominant kernel (the fused GCL edge stage): with enable = k > 0,
- * every launch of that kernel inside every k-th dsbdd_dynamics_forward call is
- * bracketed by hipEventRecord on the caller's stream (up to max_launches timed
+ * the largest launches of that kernel (all of them when every stage runs on the whole edge list) inside every
+ * k-th dsbdd_dynamics_forward call are bracketed by hipEventRecord on the caller's stream (up to max_launches timed
  * launches between reads); those calls run eagerly, the others may replay their
  * captured graph.  enable = 1 times every call, 0 switches timing off.  dsbdd_engine_profile_read waits for the recorded events, returns
  * the summed kernel time and the number of timed launches, and resets. */
