@@ -419,3 +419,80 @@ def test_full_atom_chains_with_identical_pockets_vs_oracle():
     assert (h_l.cpu()[:, :3] - o_l[:, :3]).abs().max().item() < 1e-3
     assert torch.equal(h_l.cpu()[:, 3:].long(), o_l[:, 3:].long())
     assert (h_p.cpu() - o_p).abs().max().item() < 1e-3
+
+
+def test_ligand_only_call_with_ragged_and_empty_samples():
+    """Edge cases of the row elimination with a pocket frame: a batch of DIFFERENT full-atom pockets (286 / 201 / 150
+    atoms: per-sample frame, no sharing), ligands of different sizes including a sample WITHOUT ligand atoms (all of
+    its pocket rows are unreachable: level 4), and a single-sample batch (its own representative: forward cone).
+    Ligand eps against the oracle (1e-4) and the all-rows call (2e-5); levels against the BFS."""
+    from diffsbdd_amd.engine import edge_capacity
+    from diffsbdd_amd.pocket import prepare_pocket
+    cfg, dd = W.arch_cfg("crossdock_fullatom_cond")
+    sd = W.random_state_dict(cfg, 0)
+    z = np.load(os.path.join(GOLDEN_DIR, "pocket_3rfm.npz"))
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    P = torch.from_numpy(z["fa_x"]).float()
+    types = torch.from_numpy(z["fa_types"]).long()
+    center = P.mean(0)
+    order = (P - center).norm(dim=1).argsort()            # pockets 2 and 3: the atoms closest to the centre
+    sizes_p = [286, 201, 150, 286]
+    sizes_l = [23, 9, 0, 14]
+    xs, hs, mp, ml, xl = [], [], [], [], []
+    for b, (n_p, n_l) in enumerate(zip(sizes_p, sizes_l)):
+        idx = order[:n_p].sort().values
+        shift = torch.randn(3, generator=g) * 3
+        xs.append(P[idx] - center + shift)
+        hs.append(torch.nn.functional.one_hot(types[idx], cfg["residue_nf"]).float() / dd["norm_values"][1])
+        mp.append(torch.full((n_p,), b))
+        ml.append(torch.full((n_l,), b))
+        xl.append(shift + torch.randn(n_l, 3, generator=g) * 1.5)
+    xp_all = torch.cat([torch.cat(xs), torch.cat(hs)], 1)
+    mp_all, ml_all = torch.cat(mp), torch.cat(ml)
+    xl_all = torch.cat([torch.cat(xl), torch.randn(len(ml_all), cfg["atom_nf"], generator=g) * 0.5], 1)
+    B = len(sizes_p)
+    t = torch.full((1,), 0.4)
+
+    def run(sel, want_pocket, shared=False):
+        keep_l = torch.isin(ml_all, torch.tensor(sel))
+        keep_p = torch.isin(mp_all, torch.tensor(sel))
+        remap = torch.full((B,), -1, dtype=torch.long)
+        remap[torch.tensor(sel)] = torch.arange(len(sel))
+        a_cpu = (xl_all[keep_l], xp_all[keep_p], t, remap[ml_all[keep_l]], remap[mp_all[keep_p]])
+        a = [v.to(d) for v in a_cpu]
+        m = make_dynamics(cfg, sd)
+        eng = m.engine()
+        cap = edge_capacity(a[3], a[4], len(sel))
+        szs = torch.tensor([sizes_p[s] for s in sel])
+        eng.set_pocket_frame(a[1][:, :3].contiguous(), a[4], szs.to(d), a[0].shape[0], len(sel), cap, shared)
+        outs = [m.forward_async(*a, batch=len(sel), edge_cap=cap, want_pocket=want_pocket) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(int(o[2].item()) == 0 for o in outs) and torch.equal(outs[0][0], outs[2][0])
+        n = a[0].shape[0] + a[1].shape[0]
+        er, ec = eng.last_edges(n)
+        lv = None if want_pocket else eng.last_levels(n)
+        plan = eng.last_plan()
+        eng.clear_pocket_frame()
+        return outs[0][0], torch.stack([er, ec]), lv, plan, a_cpu
+
+    full, edges, _, _, a_cpu = run([0, 1, 2, 3], True)
+    lig, _, lv, plan, _ = run([0, 1, 2, 3], False)
+    assert plan[0] == [4, 4, 4, 3, 2, 1] and not any(plan[1])          # different pockets: backward cone only
+    n_l = len(ml_all)
+    want = _hop_levels(edges[0].numpy(), edges[1].numpy(), n_l, n_l + len(mp_all))
+    assert np.array_equal(lv["level"], want)
+    rows_2 = n_l + sum(sizes_p[:2])
+    assert (want[rows_2:rows_2 + sizes_p[2]] == 4).all()               # the sample without a ligand
+    assert (lig - full).abs().max().item() < 2e-5
+    with oracle_threads():
+        o_l, _, _ = eo.dynamics_forward(sd, cfg, *a_cpu[:2], t, *a_cpu[3:], edges=edges)
+    assert excess(lig, o_l) <= 0
+    # samples 0 and 3 on their own (single-sample batches are their own representative: forward cone)
+    for s, lo, hi in ((0, 0, 23), (3, 32, 46)):
+        one, e1, _, plan1, a1 = run([s], False)
+        assert plan1[0] == [1, 2, 3, 3, 2, 1] and plan1[1] == [1, 1, 1, 0, 0, 0]
+        assert (one - lig[lo:hi]).abs().max().item() < 2e-5
+        with oracle_threads():
+            o1, _, _ = eo.dynamics_forward(sd, cfg, *a1[:2], t, *a1[3:], edges=e1)
+        assert excess(one, o1) <= 0
