@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSBDD_LIB: load another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("DSBDD_LIB") or os.path.join(_HERE, "libdiffsbdd_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # error / status codes (include/diffsbdd_hip.h)
 OK, ERR_ARG, ERR_STATE, ERR_CAPACITY, ERR_LAUNCH = 0, -1, -2, -3, -4
@@ -61,7 +61,7 @@ SIGNATURES = {
     "dsbdd_engine_workspace_bytes": (C.c_size_t, [_P, _I64, _I64, _I64, _I64]),
     "dsbdd_engine_bind_workspace": (C.c_int, [_P, _P, C.c_size_t, _I64, _I64, _I64, _I64]),
     "dsbdd_engine_set_trace": (C.c_int, [_P, _P, _P]),
-    "dsbdd_engine_set_pocket_frame": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64]),
+    "dsbdd_engine_set_pocket_frame": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64]),
     "dsbdd_engine_clear_pocket_frame": (C.c_int, [_P]),
     "dsbdd_dynamics_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64,
                                          _P, _P, _I64, _P, _P, _P]),

@@ -49,7 +49,8 @@ struct dsbdd_engine {
   // second per-call list (edges with a ligand endpoint) and the static pocket-pocket list of the pocket frame
   int *erow2, *ecol2, *row_ptr2, *deg2, *scan_tmp2, *seg_base2;
   int *erow3, *ecol3, *row_ptr3, *deg3, *scan_tmp3, *seg_base3, *node_batch3, *lig_off3, *poc_off3, *twin;
-  float *ed02, *ed03, *xcanon, *aggB, *agg_headB;
+  float *ed02, *ed03, *xframe, *aggB, *agg_headB;
+  int* frame_rows;                      // pocket row (0-based in the pocket array) of every frame row
   // level-ordered list (graph.h, "Level-ordered edge list"): pocket-conditioned calls that return the ligand part only
   int *lvl, *seg_rows, *seg_edges, *node_base, *edge_base, *lvl_cnt, *lvl_end, *lvl_list, *row_ptrL, *erowL, *ecolL;
   float* ed0L;
@@ -68,7 +69,7 @@ struct dsbdd_engine {
   // pocket-conditioning mode, so block 0's pocket-pocket messages are evaluated on them, separately
   bool frame = false;
   int64_t frame_nlig = 0, frame_npoc = 0, frame_batch = 0, frame_n3 = 0, frame_cap3 = 0;
-  int frame_shared = 0;
+  bool ghost_dirty = true;              // the ghost rows / ghost list segment must be (re)written before the next framed call
   int64_t cap_tiles = 0;                // wave tiles (32 edges) of the edge capacity
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
@@ -157,11 +158,11 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 36-40 list 3
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4,                                                 // 41 scan_tmp3 42 seg_base3
       (size_t)N * 4, (size_t)(B + 1) * 4, (size_t)(B + 1) * 4, (size_t)N * 4,                       // 43 node_batch3 44 lig_off3 45 poc_off3 46 twin
-      (size_t)N * 12, (size_t)N * H * 4, (size_t)T * H * 4,                                         // 47 xcanon 48 aggB 49 agg_headB
+      (size_t)N * 12, (size_t)NG * H * 4, (size_t)T * H * 4,                                        // 47 xframe 48 aggB (ghost ids) 49 agg_headB
       (size_t)N * 4, (size_t)kLevels * B * 4, (size_t)kLevels * B * 4,                              // 50 lvl 51 seg_rows 52 seg_edges
       (size_t)(kLevels * B + 1) * 4, (size_t)(kLevels * B + 1) * 4, 64, 64,                         // 53 node_base 54 edge_base 55 lvl_cnt 56 lvl_end
       (size_t)NG * 4, (size_t)(NG + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4,         // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
-      128};                                                                                         // 62 lvl_stats
+      128, (size_t)N * 4};                                                                          // 62 lvl_stats 63 frame_rows
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -296,8 +297,10 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->scan_tmp3 = (int*)(b + L.off[41]); e->seg_base3 = (int*)(b + L.off[42]);
   e->node_batch3 = (int*)(b + L.off[43]); e->lig_off3 = (int*)(b + L.off[44]); e->poc_off3 = (int*)(b + L.off[45]);
   e->twin = (int*)(b + L.off[46]);
-  e->xcanon = (float*)(b + L.off[47]); e->aggB = (float*)(b + L.off[48]); e->agg_headB = (float*)(b + L.off[49]);
+  e->xframe = (float*)(b + L.off[47]); e->aggB = (float*)(b + L.off[48]); e->agg_headB = (float*)(b + L.off[49]);
+  e->frame_rows = (int*)(b + L.off[63]);
   e->frame = false;               // a pocket frame lives in the workspace
+  e->ghost_dirty = true;
   e->w2tp_ready = false;
   return DSBDD_OK;
 }
@@ -311,10 +314,27 @@ int dsbdd_debug_set_timestamps(dsbdd_engine* e, unsigned long long* buf, int cap
 }
 #endif
 
-int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_pocket, const int64_t* mask_frame,
-                                  const int32_t* twin_local, int64_t n_lig, int64_t n_pocket, int64_t batch,
-                                  int64_t n_frame, int64_t batch_frame, int64_t edge_bound_frame) {
-  if (!e || !x_pocket || !mask_frame || !twin_local) return fail(DSBDD_ERR_ARG, "null argument");
+// Ghost rows N .. N + n3 (the frame's pockets as nodes of their own: coordinates, degrees, positions) and the front
+// segment of the level-ordered list, from the pristine frame data (list 3, xframe).  Re-run whenever a call without
+// the frame may have written over them.
+static int ghost_setup(dsbdd_engine* e, hipStream_t s) {
+  const int n3 = (int)e->frame_n3, N = (int)(e->frame_nlig + e->frame_npoc);
+  int64_t gb = (e->frame_cap3 + 255) / 256;
+  if (gb > 1024) gb = 1024;
+  hipLaunchKernelGGL(ghost_setup_kernel, dim3((int)gb), dim3(256), 0, s, (const int*)e->erow3, (const int*)e->ecol3,
+                     (const float*)e->ed03, (const int*)e->row_ptr3, (const int*)e->deg3, n3, N, N, e->erowL,
+                     e->ecolL, e->ed0L, (int)e->cap_edgesL, e->deg, e->row_ptrL, e->lvl_list,
+                     (const float*)e->xframe, e->x);
+  HIP_TRY(hipGetLastError());
+  e->ghost_dirty = false;
+  return DSBDD_OK;
+}
+
+int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_frame, const int64_t* mask_frame,
+                                  const int32_t* frame_rows, const int32_t* twin_local, int64_t n_lig,
+                                  int64_t n_pocket, int64_t batch, int64_t n_frame, int64_t batch_frame,
+                                  int64_t edge_bound_frame) {
+  if (!e || !x_frame || !mask_frame || !frame_rows || !twin_local) return fail(DSBDD_ERR_ARG, "null argument");
   if (!e->ws) return fail(DSBDD_ERR_STATE, "workspace not bound");
   if (e->cfg.update_pocket_coords) return fail(DSBDD_ERR_STATE, "a pocket frame needs rigid pocket coordinates");
   if (n_lig < 0 || n_lig > e->cap_lig || n_pocket < 1 || n_pocket > e->cap_poc || batch < 1 || batch > e->cap_batch ||
@@ -324,40 +344,30 @@ int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->drop_graphs();
   e->frame = false;
-  const int n3 = (int)n_frame, b3 = (int)batch_frame;
-  // raw pocket coordinates at the pocket rows of an [N][3] array (node ids of the edge kernels are global)
-  HIP_TRY(hipMemcpyAsync(e->xcanon + 3 * n_lig, x_pocket, (size_t)n_pocket * 12, hipMemcpyDeviceToDevice, s));
+  const int n3 = (int)n_frame, b3 = (int)batch_frame, N = (int)(n_lig + n_pocket);
+  HIP_TRY(hipMemcpyAsync(e->xframe, x_frame, (size_t)n3 * 12, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->frame_rows, frame_rows, (size_t)n3 * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(e->twin, twin_local, (size_t)n_pocket * 4, hipMemcpyDeviceToDevice, s));
-  // the pocket-pocket radius graph of the frame: a pocket-only problem (no ligand nodes), node ids + n_lig
+  // the pocket-pocket radius graph of the frame: a pocket-only problem (no ligand nodes) whose nodes are the
+  // ghost rows N .. N + n3 of the engine's node arrays
   const int work = n3 > b3 + 1 ? n3 : b3 + 1;
   hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, (const int64_t*)nullptr, 0, mask_frame,
                      n3, b3, e->node_batch3, e->lig_off3, e->poc_off3, (int*)nullptr);
   HIP_TRY(hipGetLastError());
-  int rc = build_edges_impl(s, x_pocket, 0, n3, b3, e->cfg, e->node_batch3, e->lig_off3, e->poc_off3, e->deg3,
+  int rc = build_edges_impl(s, x_frame, 0, n3, b3, e->cfg, e->node_batch3, e->lig_off3, e->poc_off3, e->deg3,
                             e->row_ptr3, e->erow3, e->ecol3, e->ed03, e->cap_edges, e->tile_ctr + 24, nullptr,
-                            e->scan_tmp3, e->seg_base3, nullptr, (int)n_lig);
+                            e->scan_tmp3, e->seg_base3, nullptr, N);
   if (rc) return rc;
   e->frame_nlig = n_lig; e->frame_npoc = n_pocket; e->frame_batch = batch;
   e->frame_n3 = n3; e->frame_cap3 = edge_bound_frame;
-  e->frame_shared = b3 == 1 ? 1 : 0;      // one representative pocket for the whole batch
-  e->ghost_slots = 0;
-  if (e->frame_shared) {
-    // ghost rows N .. N + n3 of the canonical pocket: coordinates, and the front segment of the level-ordered list
-    const int N = (int)(n_lig + n_pocket);
-    HIP_TRY(hipMemcpyAsync(e->x + 3 * (size_t)N, x_pocket, (size_t)n3 * 12, hipMemcpyDeviceToDevice, s));
-    int64_t gb = (edge_bound_frame + 255) / 256;
-    if (gb > 1024) gb = 1024;
-    hipLaunchKernelGGL(ghost_setup_kernel, dim3((int)gb), dim3(256), 0, s, (const int*)e->erow3, (const int*)e->ecol3,
-                       (const float*)e->ed03, (const int*)e->row_ptr3, (const int*)e->deg3, n3, (int)n_lig, N, e->erowL,
-                       e->ecolL, e->ed0L, (int)e->cap_edgesL, e->deg, e->row_ptrL, e->lvl_list);
-    HIP_TRY(hipGetLastError());
-    int slots = 0;                         // one host sync per chain (the chain start has one already)
-    HIP_TRY(hipMemcpyAsync(&slots, e->row_ptr3 + n3, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (slots < 0 || slots > e->cap_edges || (slots & (kEdgeAlign - 1)))
-      return fail(DSBDD_ERR_CAPACITY, "pocket frame: pocket-pocket list exceeds the edge capacity");
-    e->ghost_slots = slots;
-  }
+  rc = ghost_setup(e, s);
+  if (rc) return rc;
+  int slots = 0;                         // one host sync per chain (the chain start has one already)
+  HIP_TRY(hipMemcpyAsync(&slots, e->row_ptr3 + n3, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (slots < 0 || slots > e->cap_edges || (slots & (kEdgeAlign - 1)))
+    return fail(DSBDD_ERR_CAPACITY, "pocket frame: pocket-pocket list exceeds the edge capacity");
+  e->ghost_slots = slots;
   e->frame = true;
   return DSBDD_OK;
 }
@@ -581,9 +591,17 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // a ligand node can differ from the ligand-free ("canonical") pocket network, which is evaluated once, on the ghost
   // rows N .. N + n_ghost (its stage-0 messages are the frame's pocket-pocket launch).  Stage g then computes the
   // rows of level <= min(g + 1, G - g); the rows the next stage reads beyond those get the canonical values.
-  const bool cone = prune && split0 && e->frame_shared && e->cone && t_count == 1 && G_stages >= 2;
-  const int n_ghost = cone ? (int)e->frame_n3 : 0;
-  const int64_t ghost_slots = cone ? e->ghost_slots : 0;
+  const bool cone = prune && split0 && e->cone && t_count == 1 && G_stages >= 2;
+  // with a frame, the frame's pockets are the ghost rows N .. N + n_frame_rows; in the level-ordered list they own the
+  // first n_ghost entries of lvl_list and the first ghost_slots edge slots
+  const int n_frame_rows = split0 ? (int)e->frame_n3 : 0;
+  const int n_ghost = (split0 && prune) ? n_frame_rows : 0;
+  const int64_t ghost_slots = (split0 && prune) ? e->ghost_slots : 0;
+  if (split0 && e->ghost_dirty) {
+    int rc = ghost_setup(e, s);
+    if (rc) return rc;
+  }
+  if (!split0) e->ghost_dirty = true;     // this call may write over the ghost rows
   constexpr int LV = kLevels - 1;                       // "everything"
   auto radius_of = [&](int g) {
     const int bw = G_stages - g, fw = g + 1;
@@ -706,11 +724,9 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   }
   // ---- embedding (egnn_new.py:233) ---------------------------------------------
   HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
-  if (cone) {   // the canonical pocket starts from the representative's embedded features (sample 0's pocket rows)
-    const size_t n16 = (size_t)n_ghost * H / 4;
-    hipLaunchKernelGGL(copy16_kernel, dim3((int)((n16 + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<uint4*>(e->h + (size_t)N * H),
-                       reinterpret_cast<const uint4*>(e->h + (size_t)nlig * H), n16);
+  if (split0) {   // the ghost rows start from the embedded features of the pockets they stand for
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_frame_rows + 3) / 4), dim3(kThreads), 0, s, e->h + (size_t)N * H,
+                       (const float*)(e->h + (size_t)nlig * H), (const int*)e->frame_rows, n_frame_rows, H);
     HIP_TRY(hipGetLastError());
   }
 
@@ -754,20 +770,21 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       // P | Q projections of the edge MLP's first layer (those of a block's first sublayer
       // were launched together with the previous block's coordinate projections)
       if (!pqg_ready) {
-        const bool rows0 = split0 && blk == 0 && sub == 0 && e->frame_shared;
+        const bool rows0 = split0 && blk == 0 && sub == 0;
         NodeLinearArgs grp0[2];
         if (rows0) {
-          // identical pockets: block 0 reads P|Q only at the active nodes (ligand nodes + pocket nodes with a
-          // ligand neighbour: the endpoints of the ligand-endpoint list) and at the representative's pocket
+          // pocket frame: block 0 reads P|Q only at the active nodes (ligand nodes + pocket nodes with a ligand
+          // neighbour: the endpoints of the ligand-endpoint list) and at the ghost rows (the frame's pockets)
           grp0[0] = gcl_pq(blk, sub);
-          grp0[0].row_idx = e->act_list; grp0[0].m_count = e->act_ptr + N;
+          grp0[0].row_idx = e->act_list; grp0[0].m_count = e->act_ptr + N; grp0[0].M = N;
           grp0[1] = gcl_pq(blk, sub);
-          grp0[1].A1 = e->h + (size_t)nlig * H; grp0[1].C = e->pqg + (size_t)nlig * 2 * H; grp0[1].M = (int)e->frame_n3;
+          grp0[1].A1 = e->h + (size_t)N * H; grp0[1].C = e->pqg + (size_t)N * 2 * H; grp0[1].M = n_frame_rows;
           grp0[1].row_idx = nullptr; grp0[1].m_count = nullptr;
         }
         if (!(rows0 && launch_node_group(s, grp0, 2) == hipSuccess)) {
           (void)hipGetLastError();
           HIP_TRY(launch_node_linear(s, gcl_pq(blk, sub)));
+          if (rows0) HIP_TRY(launch_node_linear(s, grp0[1]));       // the ghost rows separately
         }
       }
       pqg_ready = false;
@@ -792,19 +809,19 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // (A) edges with a ligand endpoint, current coordinates -> agg / agg_head
         EdgeArgs a2 = ea;
         a2.erow = e->erow2; a2.ecol = e->ecol2; a2.ed0 = e->ed02; a2.e_count = e->row_ptr2 + N;
-        a2.e_cap = (int)e->cap_edges;
+        a2.e_cap = (int)e->cap_edges; a2.wt_base = 0;          // (lists 2 and 3 count their wave tiles from 0)
         // (B) pocket-pocket edges of the frame (all samples, or the representative of identical pockets),
         //     raw pocket coordinates -> aggB / agg_headB.  (Running the small launch (B) on a second stream
         //     beside (A) was measured: 29.13 vs 29.42 ligands/s -- no gain, removed.)
         EdgeArgs a3 = ea;
         a3.erow = e->erow3; a3.ecol = e->ecol3; a3.ed0 = e->ed03; a3.e_count = e->row_ptr3 + e->frame_n3;
-        a3.x = e->xcanon; a3.agg = e->aggB; a3.agg_head = e->agg_headB; a3.e_cap = (int)e->cap_edges;
+        a3.agg = e->aggB; a3.agg_head = e->agg_headB; a3.e_cap = (int)e->cap_edges; a3.wt_base = 0;   // (x: the ghost rows of e->x)
         HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
         HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
         hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + n_ghost + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
                            (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,
-                           (const int*)e->deg3, (const int*)e->twin, nlig, nlig, N, H, n_ghost);
+                           (const int*)e->deg3, (const int*)e->twin, N, nlig, N, H, cone ? n_ghost : 0);
         HIP_TRY(hipGetLastError());
       } else {
         // (timed: the launches over the whole list only, so that every timed launch is the same work)

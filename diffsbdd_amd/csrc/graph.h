@@ -434,7 +434,8 @@ __global__ __launch_bounds__(kThreads) void level_place_kernel(LevelArgs a) {
 // list positions and places at the front of lvl_list are static for the chain.
 __global__ void ghost_setup_kernel(const int* erow3, const int* ecol3, const float* ed03, const int* row_ptr3,
                                    const int* deg3, int n3, int id_src, int id_dst, int* erow, int* ecol,
-                                   float* ed0, int e_cap, int* deg, int* row_ptr, int* lvl_list) {
+                                   float* ed0, int e_cap, int* deg, int* row_ptr, int* lvl_list,
+                                   const float* xframe, float* x) {
   const int total = min(row_ptr3[n3], e_cap);
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
     const int r = erow3[p];
@@ -446,7 +447,19 @@ __global__ void ghost_setup_kernel(const int* erow3, const int* ecol3, const flo
     deg[id_dst + i] = deg3[i];
     row_ptr[id_dst + i] = row_ptr3[i];
     lvl_list[i] = id_dst + i;
+    x[3 * (id_dst + i)] = xframe[3 * i]; x[3 * (id_dst + i) + 1] = xframe[3 * i + 1];
+    x[3 * (id_dst + i) + 2] = xframe[3 * i + 2];
   }
+}
+
+// dst[i][:] = src[rows[i]][:]  (one wave per row, 16-byte lanes): embedded features of the frame's pockets -> ghost rows
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(float* dst, const float* src, const int* rows, int n,
+                                                               int H) {
+  const int i = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float* a = src + (size_t)rows[i] * H;
+  float* b = dst + (size_t)i * H;
+  for (int k = 4 * lane; k < H; k += 256) *reinterpret_cast<float4*>(b + k) = ld4(a + k);
 }
 
 // h[i] <- h[ghost twin of i] for the pocket rows with lo < level <= hi: rows the next message stage reads but the

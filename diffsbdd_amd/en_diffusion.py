@@ -546,16 +546,31 @@ class EnVariationalDiffusion(nn.Module):
             # representation -- full-atom pockets have hundreds of nodes, C-alpha pockets a few dozen)
             sizes = pocket['size'].to(dev).to(torch.int64)
             x = pocket['x'].to(device=dev, dtype=torch.float32)
-            shared = False
-            if self.share_identical_pockets and bool((sizes == sizes[0]).all()) \
-                    and int(sizes[0]) * batch == x.shape[0]:
-                n0 = int(sizes[0])
-                h = pocket['one_hot'].to(dev)
-                shared = bool((x.view(batch, n0, -1) == x[:n0]).all()) and \
-                    bool((h.view(batch, n0, -1) == h[:n0]).all())
-            self.dynamics.engine().set_pocket_frame(x, pm, sizes, lm.numel(), batch, cap, shared)
+            rep = None
+            if self.share_identical_pockets:
+                rep = self._pocket_groups(x, pocket['one_hot'].to(dev), sizes, batch)
+            self.dynamics.engine().set_pocket_frame(x, pm, sizes, lm.numel(), batch, cap, representative=rep)
             self._framed = True
         return lm, pm
+
+    @staticmethod
+    def _pocket_groups(x, one_hot, sizes, batch):
+        """representative[b] = first sample of the batch whose pocket (atom count, coordinates, features) is identical
+        to sample b's.  The common case -- one pocket repeated (prepare_pocket(repeats=n)) -- is decided on the device;
+        otherwise the pockets are hashed on the host (one copy of the pocket array per chain)."""
+        if bool((sizes == sizes[0]).all()) and int(sizes[0]) * batch == x.shape[0]:
+            n0 = int(sizes[0])
+            if bool((x.view(batch, n0, -1) == x[:n0]).all()) and bool((one_hot.view(batch, n0, -1) == one_hot[:n0]).all()):
+                return torch.zeros(batch, dtype=torch.int64)
+        import hashlib
+        xs, hs = x.cpu().numpy(), one_hot.float().cpu().numpy()
+        ends = torch.cumsum(sizes, 0).cpu().tolist()
+        first, rep, lo = {}, [], 0
+        for b, hi in enumerate(ends):
+            key = hashlib.blake2b(xs[lo:hi].tobytes() + hs[lo:hi].tobytes(), digest_size=16).digest()
+            rep.append(first.setdefault(key, b))
+            lo = hi
+        return torch.tensor(rep, dtype=torch.int64)
 
     def _end_chain(self):
         if getattr(self, "_framed", False):

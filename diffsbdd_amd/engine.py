@@ -197,28 +197,39 @@ class HipEngine:
                    "dsbdd_engine_bind_workspace")
         self.caps = caps
 
-    def set_pocket_frame(self, x_pocket, mask_pocket, sizes_pocket, n_lig, batch, edge_cap, shared):
+    def set_pocket_frame(self, x_pocket, mask_pocket, sizes_pocket, n_lig, batch, edge_cap, shared=False,
+                         representative=None):
         """dsbdd_engine_set_pocket_frame: raw pocket coordinates x_pocket [n_pocket, 3] (fp32, device) of a
-        pocket-conditioned chain.  shared=True: every sample has the same pocket -> the frame problem is
-        sample 0's pocket alone and all samples read its block-0 pocket-pocket messages."""
+        pocket-conditioned chain.  `representative` [batch]: for every sample the index of the sample whose pocket
+        stands for it (itself, or an earlier sample with an IDENTICAL pocket); shared=True is the common special case
+        "every sample has sample 0's pocket", the default is "every sample its own".  The frame problem is the
+        representatives' pockets; all samples of a group read its block-0 pocket-pocket messages and, in the forward
+        cone, its canonical pocket network."""
         dev = self.device
         n_pocket = x_pocket.shape[0]
         self.ensure_workspace(n_lig, n_pocket, batch, edge_cap)
         x_pocket = x_pocket.to(device=dev, dtype=torch.float32).contiguous()
-        if shared:
-            n0 = n_pocket // batch
-            twin = torch.arange(n0, dtype=torch.int32, device=dev).repeat(batch)
-            mask3, n3, b3 = mask_pocket[:n0].contiguous(), n0, 1
-            bound = (n0 * n0 + 31) // 32 * 32 + 32
-        else:
-            twin = torch.arange(n_pocket, dtype=torch.int32, device=dev)
-            mask3, n3, b3 = mask_pocket, n_pocket, batch
-            sz = sizes_pocket.to(torch.int64)
-            bound = int((((sz * sz) + 31) // 32 * 32).sum().item()) + 32
-        self._frame_keep = (x_pocket, twin, mask3)
+        sz = sizes_pocket.to(device=dev, dtype=torch.int64)
+        if representative is None:
+            representative = torch.zeros(batch, dtype=torch.int64) if shared else torch.arange(batch)
+        rep = torch.as_tensor(representative, dtype=torch.int64).to(dev)
+        off = torch.cumsum(sz, 0) - sz                                  # first pocket row of every sample
+        reps = torch.unique(rep)                                        # sorted representative samples
+        frame_id = torch.zeros(batch, dtype=torch.int64, device=dev)
+        frame_id[reps] = torch.arange(reps.numel(), device=dev)
+        sz_f = sz[reps]
+        off_f = torch.cumsum(sz_f, 0) - sz_f                            # first frame row of every representative
+        n3, b3 = int(sz_f.sum().item()), int(reps.numel())
+        mask3 = torch.repeat_interleave(torch.arange(b3, device=dev), sz_f)
+        frame_rows = (torch.arange(n3, device=dev) - off_f[mask3] + off[reps][mask3]).to(torch.int32).contiguous()
+        within = torch.arange(n_pocket, device=dev) - off[mask_pocket]   # atom index inside its sample
+        twin = (off_f[frame_id[rep]][mask_pocket] + within).to(torch.int32).contiguous()
+        x_frame = x_pocket[frame_rows.long()].contiguous()
+        bound = int((((sz_f * sz_f) + 31) // 32 * 32).sum().item()) + 32
+        self._frame_keep = (x_frame, twin, mask3, frame_rows)
         _lib.check(self.lib.dsbdd_engine_set_pocket_frame(
-            self.handle, torch.cuda.current_stream(dev).cuda_stream, x_pocket.data_ptr(), mask3.data_ptr(),
-            twin.data_ptr(), n_lig, n_pocket, batch, n3, b3, min(bound, self.caps[3])),
+            self.handle, torch.cuda.current_stream(dev).cuda_stream, x_frame.data_ptr(), mask3.data_ptr(),
+            frame_rows.data_ptr(), twin.data_ptr(), n_lig, n_pocket, batch, n3, b3, min(bound, self.caps[3])),
             "dsbdd_engine_set_pocket_frame")
 
     def clear_pocket_frame(self):

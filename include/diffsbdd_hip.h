@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DSBDD_ABI_VERSION 4
+#define DSBDD_ABI_VERSION 5
 
 enum {
   DSBDD_OK = 0,
@@ -135,24 +135,28 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* workspace, size_t bytes, 
  * centre of mass, conditional_model.py:688-696), so its pocket-pocket radius graph and distances are
  * constants of the chain.  With a frame set, block 0 of dsbdd_dynamics_forward evaluates
  *     agg[node] = [sum over the node's edges with a ligand endpoint] + [sum over its pocket-pocket edges]
- * with the second part taken from the frame: a static edge list built here ONCE from the raw pocket
- * coordinates x_pocket [n_pocket][3].  twin_local [n_pocket] maps every pocket node to its index in the
- * frame problem -- the first n_frame rows of x_pocket / mask_frame (batch_frame samples): either the whole
- * pocket array (twin = identity) or one representative sample of a batch of IDENTICAL pockets
- * (prepare_pocket(repeats = n_samples), lightning_modules.py:738-750), whose pocket-pocket messages of
- * block 0 are the same in every sample (same atom features, same time step, same distances) and are then
- * evaluated once -- 82 % of that stage's edges at the benchmark batch.  Both variants give bit-identical
- * results: the association A + B and the raw-coordinate distances are the same.
- * One representative for the whole batch (batch_frame == 1) additionally enables the FORWARD CONE of the
- * ligand-output-only calls (eps_pocket == NULL, t_count == 1; see dsbdd_dynamics_forward): the ligand-free pocket
- * network is evaluated once on ghost rows and stage g computes the rows within min(g + 1, G - g) hops of a ligand
- * atom only.  This function synchronises the stream once (it reads the frame's edge count back).
+ * with the second part taken from the frame: a static edge list built here ONCE from the raw coordinates of the
+ * frame's pockets.  The frame holds one REPRESENTATIVE pocket per group of identical pockets of the batch
+ * (identical atom features and coordinates, e.g. prepare_pocket(repeats = n_samples), lightning_modules.py:738-750:
+ * one group; a batch packed from several pockets: one per pocket; nothing shared: every sample its own):
+ *   x_frame    [n_frame][3]  raw coordinates of the representatives' atoms, sample after sample
+ *   mask_frame [n_frame]     sample id 0 .. batch_frame-1 of every frame row (sorted)
+ *   frame_rows [n_frame]     row of that atom in the call's pocket array (0-based)
+ *   twin_local [n_pocket]    frame row that stands for pocket row i (its own group's representative)
+ * The pocket-pocket messages of block 0 are the same in every sample of a group (same features, same time step,
+ * same distances) and are evaluated once per representative -- 82 % of that stage's edges at the benchmark batch.
+ * Every grouping gives bit-identical results: the association A + B and the raw-coordinate distances are the same.
+ * The representatives are also the rows of the canonical (ligand-free) pocket network of the FORWARD CONE of the
+ * ligand-output-only calls (eps_pocket == NULL, t_count == 1; see dsbdd_dynamics_forward): stage g then computes the
+ * rows within min(g + 1, G - g) hops of a ligand atom only, the rest comes from the representative.
  * The frame lives in the workspace; it is dropped by bind_workspace and by dsbdd_engine_clear_pocket_frame,
  * and only applies to calls with exactly (n_lig, n_pocket, batch).  edge_bound_frame = upper bound on the
- * frame's edge count (sum of squared pocket sizes of the frame samples + 32 per sample). */
-int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_pocket, const int64_t* mask_frame,
-                                  const int32_t* twin_local, int64_t n_lig, int64_t n_pocket, int64_t batch,
-                                  int64_t n_frame, int64_t batch_frame, int64_t edge_bound_frame);
+ * frame's edge count (sum of squared pocket sizes of the frame samples + 32 per sample).  This function
+ * synchronises the stream once (it reads the frame's edge count back). */
+int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_frame, const int64_t* mask_frame,
+                                  const int32_t* frame_rows, const int32_t* twin_local, int64_t n_lig,
+                                  int64_t n_pocket, int64_t batch, int64_t n_frame, int64_t batch_frame,
+                                  int64_t edge_bound_frame);
 int dsbdd_engine_clear_pocket_frame(dsbdd_engine* e);
 
 /* Optional per-block trace (debug / parity tests): after every EquivariantBlock

@@ -335,9 +335,11 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
     assert np.array_equal(lv["deg"], deg)
     nat_ptr = np.concatenate([[0], np.cumsum(deg)])            # natural list without its padding
     ghost_slots = 0
-    if shared:      # the canonical pocket's pocket-pocket list sits in front of the level-ordered list
-        ghost_slots = (int(((row >= len(ml)) & (col >= len(ml)) & (row < len(ml) + n0)).sum()) + 31) // 32 * 32
-    assert lv["ghost_slots"] == ghost_slots and lv["ghost_nodes"] == (n0 if shared else 0)
+    if frame:       # the pocket-pocket lists of the frame's pockets (one, or every sample's) sit in front of the list
+        for b in range(1 if shared else B):
+            lo_b = len(ml) + b * n0
+            ghost_slots += (int(((row >= lo_b) & (col >= len(ml)) & (row < lo_b + n0)).sum()) + 31) // 32 * 32
+    assert lv["ghost_slots"] == ghost_slots and lv["ghost_nodes"] == (0 if not frame else (n0 if shared else B * n0))
     pos = ghost_slots
     batch_of = np.concatenate([ml.numpy(), mp.numpy()])
     prev_key = None
@@ -423,8 +425,8 @@ def test_full_atom_chains_with_identical_pockets_vs_oracle():
 
 def test_ligand_only_call_with_ragged_and_empty_samples():
     """Edge cases of the row elimination with a pocket frame: a batch of DIFFERENT full-atom pockets (286 / 201 / 150
-    atoms: per-sample frame, no sharing), ligands of different sizes including a sample WITHOUT ligand atoms (all of
-    its pocket rows are unreachable: level 4), and a single-sample batch (its own representative: forward cone).
+    atoms; samples 0 and 3 share one: two samples, one representative), ligands of different sizes including a sample
+    WITHOUT ligand atoms (all of its pocket rows are unreachable: level 4), and single-sample batches.
     Ligand eps against the oracle (1e-4) and the all-rows call (2e-5); levels against the BFS."""
     from diffsbdd_amd.engine import edge_capacity
     from diffsbdd_amd.pocket import prepare_pocket
@@ -439,11 +441,12 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
     order = (P - center).norm(dim=1).argsort()            # pockets 2 and 3: the atoms closest to the centre
     sizes_p = [286, 201, 150, 286]
     sizes_l = [23, 9, 0, 14]
-    xs, hs, mp, ml, xl = [], [], [], [], []
+    xs, raws, hs, mp, ml, xl = [], [], [], [], [], []
     for b, (n_p, n_l) in enumerate(zip(sizes_p, sizes_l)):
         idx = order[:n_p].sort().values
         shift = torch.randn(3, generator=g) * 3
         xs.append(P[idx] - center + shift)
+        raws.append(P[idx] - center)
         hs.append(torch.nn.functional.one_hot(types[idx], cfg["residue_nf"]).float() / dd["norm_values"][1])
         mp.append(torch.full((n_p,), b))
         ml.append(torch.full((n_l,), b))
@@ -454,7 +457,9 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
     B = len(sizes_p)
     t = torch.full((1,), 0.4)
 
-    def run(sel, want_pocket, shared=False):
+    raw_all = torch.cat(raws)
+
+    def run(sel, want_pocket, shared=False, rep=None):
         keep_l = torch.isin(ml_all, torch.tensor(sel))
         keep_p = torch.isin(mp_all, torch.tensor(sel))
         remap = torch.full((B,), -1, dtype=torch.long)
@@ -465,7 +470,11 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
         eng = m.engine()
         cap = edge_capacity(a[3], a[4], len(sel))
         szs = torch.tensor([sizes_p[s] for s in sel])
-        eng.set_pocket_frame(a[1][:, :3].contiguous(), a[4], szs.to(d), a[0].shape[0], len(sel), cap, shared)
+        if rep is None:      # every sample its own representative, frame = the current coordinates
+            eng.set_pocket_frame(a[1][:, :3].contiguous(), a[4], szs.to(d), a[0].shape[0], len(sel), cap, shared)
+        else:                # groups of identical pockets: the frame is the raw (untranslated) pocket
+            eng.set_pocket_frame(raw_all[keep_p].to(d), a[4], szs.to(d), a[0].shape[0], len(sel), cap,
+                                 representative=rep)
         outs = [m.forward_async(*a, batch=len(sel), edge_cap=cap, want_pocket=want_pocket) for _ in range(3)]
         torch.cuda.synchronize()
         assert all(int(o[2].item()) == 0 for o in outs) and torch.equal(outs[0][0], outs[2][0])
@@ -478,7 +487,7 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
 
     full, edges, _, _, a_cpu = run([0, 1, 2, 3], True)
     lig, _, lv, plan, _ = run([0, 1, 2, 3], False)
-    assert plan[0] == [4, 4, 4, 3, 2, 1] and not any(plan[1])          # different pockets: backward cone only
+    assert plan[0] == [1, 2, 3, 3, 2, 1] and plan[1] == [1, 1, 1, 0, 0, 0]   # every pocket its own representative
     n_l = len(ml_all)
     want = _hop_levels(edges[0].numpy(), edges[1].numpy(), n_l, n_l + len(mp_all))
     assert np.array_equal(lv["level"], want)
@@ -488,11 +497,16 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
     with oracle_threads():
         o_l, _, _ = eo.dynamics_forward(sd, cfg, *a_cpu[:2], t, *a_cpu[3:], edges=edges)
     assert excess(lig, o_l) <= 0
-    # samples 0 and 3 on their own (single-sample batches are their own representative: forward cone)
+    # samples 0 and 3 carry the same pocket: one representative for both (raw frame coordinates)
+    grp, _, lvg, plang, _ = run([0, 1, 2, 3], False, rep=[0, 1, 2, 0])
+    assert plang[0] == [1, 2, 3, 3, 2, 1] and lvg["ghost_nodes"] == 286 + 201 + 150 and lv["ghost_nodes"] == sum(sizes_p)
+    assert (grp - lig).abs().max().item() < 2e-5
+    # samples 0 and 3 on their own: the same bits as inside the mixed batch (a sample's result depends on its own
+    # rows and on its representative's canonical pocket only)
     for s, lo, hi in ((0, 0, 23), (3, 32, 46)):
         one, e1, _, plan1, a1 = run([s], False)
         assert plan1[0] == [1, 2, 3, 3, 2, 1] and plan1[1] == [1, 1, 1, 0, 0, 0]
-        assert (one - lig[lo:hi]).abs().max().item() < 2e-5
+        assert torch.equal(one, lig[lo:hi])
         with oracle_threads():
             o1, _, _ = eo.dynamics_forward(sd, cfg, *a1[:2], t, *a1[3:], edges=e1)
         assert excess(one, o1) <= 0
