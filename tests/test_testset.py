@@ -110,3 +110,49 @@ def test_packed_sampling_is_independent_of_the_packing():
         for x, y, z_ in zip(a[name], b[name], c[name]):
             assert x.symbols == y.symbols == z_.symbols
             assert np.array_equal(x.positions, y.positions) and np.array_equal(x.positions, z_.positions)
+
+
+@pytest.mark.gpu
+def test_packed_sampling_full_atom_pockets_is_independent_of_the_packing():
+    """The same with FULL-ATOM pockets (3rfm 286 atoms, 5ndu 287 atoms): here the chain hands the engine a pocket frame
+    with one representative per distinct pocket of the batch and the ligand-output-only calls run the forward /
+    backward cones (csrc/engine.hip).  A pocket's molecules are bit-identical whether it shares its batches with the
+    other pocket (12 or 7 slots) or not (4 slots: mostly one pocket per batch)."""
+    from oracle import weights as W
+    from diffsbdd_amd import pocket as pk
+    from diffsbdd_amd.generate import LigandGenerator
+    from tests._golden import GOLDEN_DIR
+    cfg, dd = W.arch_cfg("crossdock_fullatom_cond")
+    egnn = dict(joint_nf=cfg["joint_nf"], hidden_nf=cfg["hidden_nf"], n_layers=cfg["n_layers"], attention=True,
+                tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False, normalization_factor=100,
+                aggregation_method="sum", edge_cutoff_ligand=None, edge_cutoff_pocket=5.0,
+                edge_cutoff_interaction=5.0, reflection_equivariant=False, edge_embedding_dim=None)
+    diff = dict(diffusion_steps=500, diffusion_noise_schedule="polynomial_2", diffusion_noise_precision=5e-4,
+                diffusion_loss_type="l2", normalize_factors=[1, 4])
+    gen = LigandGenerator("crossdock", egnn, diff, "pocket_conditioning", np.ones((40, 400)), "full-atom",
+                          device="cuda:0")
+    gen.ddpm.dynamics.load_state_dict(W.random_state_dict(cfg, 0))
+    elem = {v: k for k, v in pk.ATOM_ENCODER.items()}
+    residues = {}
+    for name in ("3rfm", "5ndu"):
+        z = np.load(os.path.join(GOLDEN_DIR, f"pocket_{name}.npz"))
+        # one pseudo-residue per atom: the featuriser only looks at (element, xyz) in full-atom mode
+        residues[name] = [dict(chain="A", resseq=i, icode=" ", resname="GLY",
+                               atoms=[("X", elem[int(t)], tuple(map(float, xyz)))], hetero=False)
+                          for i, (xyz, t) in enumerate(zip(z["fa_x"], z["fa_types"]))]
+
+    def run(batch_size):
+        jobs = ts.number_jobs([ts.PocketJob(n, residues[n], len(residues[n]), 6) for n in ("3rfm", "5ndu")])
+        drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=4, seed=5, largest_frag=False, n_nodes_min=2), batch_size)
+        out = {j.name: j.valid for j in drv.run(jobs)}
+        return out, len(drv.batches), gen.ddpm.dynamics.engine().last_plan()
+
+    a, na, plan = run(12)
+    assert plan[0] == [1, 2, 3, 3, 2, 1] and plan[1] == [1, 1, 1, 0, 0, 0]      # frame + cones were on
+    b, nb, _ = run(7)
+    c, nc, _ = run(4)
+    assert (na, nb, nc) == (1, 2, 3)
+    for name in a:
+        for x, y, z_ in zip(a[name], b[name], c[name]):
+            assert x.symbols == y.symbols == z_.symbols
+            assert np.array_equal(x.positions, y.positions) and np.array_equal(x.positions, z_.positions)
