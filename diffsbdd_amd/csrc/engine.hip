@@ -681,7 +681,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
                    e->ed0, e->seg_rows, e->seg_edges, e->node_base, e->edge_base, e->lvl_cnt, e->lvl_end,
                    e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL, e->lvl_stats,
-                   n_ghost, (int)ghost_slots};
+                   n_ghost, (int)ghost_slots, (int)e->cap_edges};
       if (!e->lvl_stats_zeroed) {
         HIP_TRY(zero_async(e->lvl_stats, 128, s));
         e->lvl_stats_zeroed = true;

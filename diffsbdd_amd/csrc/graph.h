@@ -311,6 +311,8 @@ struct LevelArgs {
   // "ghost" rows of the canonical pocket (engine.hip, forward cone): node_off entries at the front of lvl_list and
   // edge_off slots (a multiple of kEdgeAlign) at the front of the edge list are theirs, written once per chain
   int node_off; int edge_off;
+  int e_cap_nat;            // capacity of the natural-order list: never indexed past it, even when the radius graph
+                            // overflowed (status bit 1 is then set by edges_kernel and the call's result is discarded)
 };
 
 __global__ __launch_bounds__(kThreads) void levels_kernel(LevelArgs a) {
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void levels_kernel(LevelArgs a) {
       if (a.lvl[i] != kLevels - 1) continue;
       const int s = a.row_ptr_nat[i], d = a.deg[i];
       bool hit = false;
-      for (int e = s; e < s + d && !hit; ++e) {
+      for (int e = max(s, 0); e < min(s + d, a.e_cap_nat) && !hit; ++e) {
         const int j = a.ecol_nat[e];
         hit = j >= a.n_lig && a.lvl[j] == k - 1;     // (a ligand neighbour would have made it level 1)
       }
@@ -477,10 +479,10 @@ __global__ __launch_bounds__(kThreads) void canon_fill_kernel(float* h, const in
 }
 
 __global__ void level_copy_kernel(LevelArgs a, int n_nodes) {
-  const int total = a.row_ptr_nat[n_nodes];
+  const int total = min(a.row_ptr_nat[n_nodes], a.e_cap_nat);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int i = a.erow_nat[e];
-    if (i < 0) continue;                    // padding of the natural-order list
+    if (i < 0 || i >= n_nodes) continue;    // padding of the natural-order list
     const int pos = a.row_ptr[i] + (e - a.row_ptr_nat[i]);
     if (pos >= 0 && pos < a.e_cap) { a.erow[pos] = i; a.ecol[pos] = a.ecol_nat[e]; a.ed0[pos] = a.ed0_nat[e]; }
   }

@@ -775,3 +775,28 @@ def test_joint_api_variants_vs_reference_golden():
     assert torch.equal(jl.cpu()[:, 3:].long(), c.t("jump_lig")[:, 3:].long())
     assert excess(jp[:, :3], c.t("jump_pocket")[:, :3], atol=1e-3, rtol=1e-4) <= 0
     assert torch.equal(jp.cpu()[:, 3:].long(), c.t("jump_pocket")[:, 3:].long())
+
+
+@pytest.mark.parametrize("want_pocket", [True, False])
+def test_edge_capacity_overflow_is_flagged_not_fatal(want_pocket):
+    """A caller-supplied edge bound that is too small (the engine sizes its lists from it) must end in the
+    overflow status bit -- no index past the lists' capacity in any kernel, including the level-ordering kernels of
+    the ligand-output-only path -- and the next call with a proper bound must be unaffected."""
+    from diffsbdd_amd import _lib
+    from diffsbdd_amd.engine import edge_capacity
+    c = Case("dyn_fullatom_cond")
+    m = make_dynamics(c.cfg, c.state_dict())
+    d = dev()
+    args = [c.t(k).to(d) for k in ("xh_lig", "xh_pocket", "t", "mask_lig", "mask_pocket")]
+    B = int(args[3].max().item()) + 1
+    good = edge_capacity(args[3], args[4], B)
+    ok = m.forward_async(*args, batch=B, edge_cap=good, want_pocket=want_pocket)
+    torch.cuda.synchronize()
+    assert int(ok[2].item()) == 0
+    m2 = make_dynamics(c.cfg, c.state_dict())
+    bad = m2.forward_async(*args, batch=B, edge_cap=256, want_pocket=want_pocket)
+    torch.cuda.synchronize()
+    assert int(bad[2].item()) & _lib.STATUS_EDGE_OVERFLOW
+    again = m2.forward_async(*args, batch=B, edge_cap=good, want_pocket=want_pocket)
+    torch.cuda.synchronize()
+    assert int(again[2].item()) == 0 and torch.equal(again[0], ok[0])
