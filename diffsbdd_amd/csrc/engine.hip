@@ -628,24 +628,31 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // ---- masks -> offsets, split inputs ---------------------------------------
   {
     const int work = N > B + 1 ? N : B + 1;
-    hipLaunchKernelGGL(prep_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
-                       (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off, e->tile_ctr);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(assemble_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xh_lig, dl, xh_pocket, dp,
-                       nlig, N, (const int*)e->node_batch, t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
+    hipLaunchKernelGGL(prep_assemble_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
+                       (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off, e->tile_ctr, xh_lig, dl, xh_pocket, dp,
+                       t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
     HIP_TRY(hipGetLastError());
   }
   // ---- encoders (dynamics.py:96-97) -> h0[:, 0:J] ----------------------------
-  HIP_TRY(nl(s, xh_lig + 3, dl, a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0],
-             nullptr, 0, e->enc_tmp, LE, n_lig, 2 * a, 1));
-  HIP_TRY(nl(s, e->enc_tmp, LE, pad4(2 * a) <= LE ? 2 * a : 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W1T], pad4(J),
-             W[DSBDD_G_ATOM_ENC_B1], nullptr, 0, e->h0, JP, n_lig, J, 0));
   {
-    float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
-    HIP_TRY(nl(s, xh_pocket + 3, dp, r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0],
-               nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
-    HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1],
-               nullptr, 0, e->h0 + (size_t)n_lig * JP, JP, n_pocket, J, 0));
+    Mlp2Problem enc[2] = {
+        {xh_lig + 3, dl, a, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0], 2 * a,
+         W[DSBDD_G_ATOM_ENC_W1T], pad4(J), W[DSBDD_G_ATOM_ENC_B1], J, e->h0, JP, (int)n_lig},
+        {xh_pocket + 3, dp, r, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0], 2 * r,
+         W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1], J, e->h0 + (size_t)n_lig * JP, JP, (int)n_pocket}};
+    if (mlp2_fits(enc[0]) && mlp2_fits(enc[1])) {
+      HIP_TRY(launch_mlp2(s, enc, 2));          // both node sets, both layers: one launch
+    } else {
+      HIP_TRY(nl(s, xh_lig + 3, dl, a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0],
+                 nullptr, 0, e->enc_tmp, LE, n_lig, 2 * a, 1));
+      HIP_TRY(nl(s, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W1T], pad4(J),
+                 W[DSBDD_G_ATOM_ENC_B1], nullptr, 0, e->h0, JP, n_lig, J, 0));
+      float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
+      HIP_TRY(nl(s, xh_pocket + 3, dp, r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0],
+                 nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
+      HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1],
+                 nullptr, 0, e->h0 + (size_t)n_lig * JP, JP, n_pocket, J, 0));
+    }
   }
   // ---- edges (dynamics.py:114, 169-187) ---------------------------------------
   int64_t edge_bound = e->cap_edges;
@@ -714,7 +721,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     a.m_count = ghost ? e->lvl_cnt + r : e->lvl_cnt + kLevels + r;
     a.M = N + n_ghost;
   };
-  if (subset) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
+  // active nodes of the coordinate projections (ligand nodes + pocket nodes with a ligand neighbour) = the nodes of
+  // level <= 1: with the level list they are its prefix (after the ghost entries), otherwise a scan + compaction
+  const int* act_rows = prune ? e->lvl_list + n_ghost : e->act_list;
+  const int* act_count = prune ? e->lvl_cnt + kLevels + 1 : e->act_ptr + N;
+  if (subset && !prune) {   // sorted list of active nodes; its length stays on the device (act_ptr[N])
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)e->act_flag, e->act_ptr, N, SegAlign{},
                        (const int*)nullptr, (int*)nullptr, SegAlign{});
     HIP_TRY(hipGetLastError());
@@ -760,7 +771,9 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   };
   bool pqg_ready = false;
   for (int blk = 0; blk < c.n_layers; ++blk) {
-    if (n_mlp == 2) {   // coord2cross needs the per-sample mean of the block's input x
+    if (n_mlp == 2 && (blk == 0 || !subset)) {   // coord2cross needs the per-sample mean of the block's input x
+                                                 // (pocket-conditioning mode, later blocks: computed by the
+                                                 // previous block's coordinate update)
       hipLaunchKernelGGL(sample_mean_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)e->x,
                          (const int*)e->lig_off, (const int*)e->poc_off, nlig, e->mean);
       HIP_TRY(hipGetLastError());
@@ -776,7 +789,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
           // pocket frame: block 0 reads P|Q only at the active nodes (ligand nodes + pocket nodes with a ligand
           // neighbour: the endpoints of the ligand-endpoint list) and at the ghost rows (the frame's pockets)
           grp0[0] = gcl_pq(blk, sub);
-          grp0[0].row_idx = e->act_list; grp0[0].m_count = e->act_ptr + N; grp0[0].M = N;
+          grp0[0].row_idx = act_rows; grp0[0].m_count = act_count; grp0[0].M = N;
           grp0[1] = gcl_pq(blk, sub);
           grp0[1].A1 = e->h + (size_t)N * H; grp0[1].C = e->pqg + (size_t)N * 2 * H; grp0[1].M = n_frame_rows;
           grp0[1].row_idx = nullptr; grp0[1].m_count = nullptr;
@@ -865,7 +878,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       int ng = 0;
       if (subset) {
         grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
-                                   (int)N, QW, 0, e->act_list, e->act_ptr + N};
+                                   (int)N, QW, 0, act_rows, act_count};
         grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT) + QW, PQ, nullptr, nullptr, 0,
                                    e->pq + QW, PQ, (int)n_lig, QW, 0, nullptr, nullptr};
       } else {
@@ -900,12 +913,25 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
      
       HIP_TRY(launch_edge(e, s, MODE_COORD, ea, L_bound));
-      if (n_upd > 0) {
+      {
         const int n_q = (e->coord_split && n_mlp == 2) ? 2 : 1;
-        hipLaunchKernelGGL(coord_update_kernel, dim3((3 * n_upd + 255) / 256), dim3(256), 0, s, e->x,
-                           (const float*)e->xagg, (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride,
-                           L_ptr, (const int*)e->deg, 3 * n_upd);
-        HIP_TRY(hipGetLastError());
+        // few updated rows (the ligand's): one workgroup per sample updates them and reduces the next block's mean;
+        // all rows updated (joint model): the wide per-component kernel, the mean stays a launch of its own
+        const bool next_mean = subset && n_mlp == 2 && blk + 1 < c.n_layers;
+        if (!subset) {
+          if (n_upd > 0) {
+            hipLaunchKernelGGL(coord_update_kernel, dim3((3 * n_upd + 255) / 256), dim3(256), 0, s, e->x,
+                               (const float*)e->xagg, (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride,
+                               L_ptr, (const int*)e->deg, 3 * n_upd);
+            HIP_TRY(hipGetLastError());
+          }
+        } else if (n_upd > 0 || next_mean) {
+          hipLaunchKernelGGL(coord_update_mean_kernel, dim3(B), dim3(kThreads), 0, s, e->x, (const float*)e->xagg,
+                             (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride, L_ptr,
+                             (const int*)e->deg, n_upd, (const int*)e->lig_off, (const int*)e->poc_off, nlig,
+                             next_mean ? e->mean : (float*)nullptr);
+          HIP_TRY(hipGetLastError());
+        }
       }
     }
     if (e->trace_h)
@@ -916,16 +942,28 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // ---- embedding_out, decoders (egnn_new.py:241, dynamics.py:147-153) --------
   HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, W[DSBDD_G_EMBOUT_WT], JP, W[DSBDD_G_EMBOUT_B], nullptr, 0, e->hout, JP,
              eps_pocket ? N : n_lig, JP, 0));
-  HIP_TRY(nl(s, e->hout, JP, J, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_DEC_B0], nullptr, 0,
-             e->enc_tmp, LE, n_lig, 2 * a, 1));
-  HIP_TRY(nl(s, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W1T], pad4(a), W[DSBDD_G_ATOM_DEC_B1], nullptr, 0,
-             eps_lig + 3, dl, n_lig, a, 0));
-  if (eps_pocket) {
-    float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
-    HIP_TRY(nl(s, e->hout + (size_t)n_lig * JP, JP, J, nullptr, 0, 0, W[DSBDD_G_RES_DEC_W0T], pad4(2 * r),
-               W[DSBDD_G_RES_DEC_B0], nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
-    HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_DEC_W1T], pad4(r), W[DSBDD_G_RES_DEC_B1], nullptr, 0,
-               eps_pocket + 3, dp, n_pocket, r, 0));
+  {
+    Mlp2Problem dec[2] = {
+        {e->hout, JP, J, W[DSBDD_G_ATOM_DEC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_DEC_B0], 2 * a,
+         W[DSBDD_G_ATOM_DEC_W1T], pad4(a), W[DSBDD_G_ATOM_DEC_B1], a, eps_lig + 3, dl, (int)n_lig},
+        {e->hout + (size_t)n_lig * JP, JP, J, W[DSBDD_G_RES_DEC_W0T], pad4(2 * r), W[DSBDD_G_RES_DEC_B0], 2 * r,
+         W[DSBDD_G_RES_DEC_W1T], pad4(r), W[DSBDD_G_RES_DEC_B1], r, eps_pocket ? eps_pocket + 3 : nullptr, dp,
+         (int)n_pocket}};
+    if (mlp2_fits(dec[0]) && mlp2_fits(dec[1])) {
+      HIP_TRY(launch_mlp2(s, dec, eps_pocket ? 2 : 1));
+    } else {
+      HIP_TRY(nl(s, e->hout, JP, J, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_DEC_B0], nullptr, 0,
+                 e->enc_tmp, LE, n_lig, 2 * a, 1));
+      HIP_TRY(nl(s, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_DEC_W1T], pad4(a), W[DSBDD_G_ATOM_DEC_B1], nullptr, 0,
+                 eps_lig + 3, dl, n_lig, a, 0));
+      if (eps_pocket) {
+        float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
+        HIP_TRY(nl(s, e->hout + (size_t)n_lig * JP, JP, J, nullptr, 0, 0, W[DSBDD_G_RES_DEC_W0T], pad4(2 * r),
+                   W[DSBDD_G_RES_DEC_B0], nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
+        HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_DEC_W1T], pad4(r), W[DSBDD_G_RES_DEC_B1], nullptr, 0,
+                   eps_pocket + 3, dp, n_pocket, r, 0));
+      }
+    }
   }
   // ---- velocity, NaN guard, joint-mode COM removal (dynamics.py:136,155-164) --
   hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)e->x, (const float*)e->x_in,

@@ -568,6 +568,29 @@ __global__ void assemble_kernel(const float* xh_lig, int dl, const float* xh_poc
   for (int k = J + 1; k < JP; ++k) h0[(size_t)i * JP + k] = 0.f;
 }
 
+// prep_kernel + assemble_kernel in one launch (thread i: node i and sample i); the time feature is looked up through
+// the masks themselves, so no thread depends on another one's node_batch entry.
+__global__ void prep_assemble_kernel(const int64_t* mask_lig, int n_lig, const int64_t* mask_poc, int n_poc, int B,
+                                     int* node_batch, int* lig_off, int* poc_off, int* tile_ctr, const float* xh_lig,
+                                     int dl, const float* xh_poc, int dp, const float* t, int t_count, float* x,
+                                     float* x_in, float* h0, int J, int JP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile_ctr && i < kTileCtrInts) tile_ctr[i] = 0;
+  if (i <= B) {
+    lig_off[i] = lower_bound_i64(mask_lig, n_lig, i);
+    poc_off[i] = lower_bound_i64(mask_poc, n_poc, i);
+  }
+  if (i >= n_lig + n_poc) return;
+  const int b = (int)(i < n_lig ? mask_lig[i] : mask_poc[i - n_lig]);
+  node_batch[i] = b;
+  const float* src = i < n_lig ? xh_lig + (size_t)i * dl : xh_poc + (size_t)(i - n_lig) * dp;
+  const float a0 = src[0], a1 = src[1], a2 = src[2];
+  x[3 * i] = a0; x[3 * i + 1] = a1; x[3 * i + 2] = a2;
+  x_in[3 * i] = a0; x_in[3 * i + 1] = a1; x_in[3 * i + 2] = a2;
+  h0[(size_t)i * JP + J] = t[t_count == 1 ? 0 : b];
+  for (int k = J + 1; k < JP; ++k) h0[(size_t)i * JP + k] = 0.f;
+}
+
 // mean[b] = mean of x over ALL nodes of sample b (egnn_new.py:307-310); one
 // workgroup per sample.
 __global__ __launch_bounds__(kThreads) void sample_mean_kernel(const float* x, const int* lig_off,
@@ -613,6 +636,49 @@ __global__ void coord_update_kernel(float* x, const float* xagg, const float* xh
     tot += a;
   }
   x[idx] += tot;
+}
+
+// The same update with one workgroup per sample, followed by the per-sample mean of the NEW coordinates (the next
+// block's coord2cross reference point, sample_mean_kernel): one launch instead of two between two blocks.
+// The mean is reduced exactly like sample_mean_kernel does (same bits).
+__global__ __launch_bounds__(kThreads) void coord_update_mean_kernel(
+    float* x, const float* xagg, const float* xhead, int n_q, size_t xagg_stride, size_t xhead_stride,
+    const int* row_ptr, const int* deg, int n_upd, const int* lig_off, const int* poc_off, int n_lig, float* mean) {
+  __shared__ float red[3][kThreads];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
+  for (int seg = 0; seg < 2; ++seg) {
+    const int a = seg ? p0 : l0, e = min(seg ? p1 : l1, n_upd);
+    for (int k = 3 * a + t; k < 3 * e; k += kThreads) {
+      const int i = k / 3, c = k - 3 * i;
+      const int d = deg[i];
+      if (d == 0) continue;
+      const int s = row_ptr[i], t0 = s >> 5, t1 = (s + d - 1) >> 5;
+      float tot = 0.f;
+      for (int q = 0; q < n_q; ++q) {
+        float v = xagg[q * xagg_stride + k];
+        for (int T = t0 + 1; T <= t1; ++T) v += xhead[q * xhead_stride + 4 * (size_t)T + c];
+        tot += v;
+      }
+      x[k] += tot;
+    }
+  }
+  if (!mean) return;
+  __syncthreads();
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = l0 + t; i < l1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+  for (int i = p0 + t; i < p1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+  red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
+    __syncthreads();
+  }
+  if (t < 3) {
+    int cnt = (l1 - l0) + (p1 - p0);
+    if (cnt == 0) cnt = 1;
+    mean[3 * b + t] = red[t][0] / (float)cnt;
+  }
 }
 
 // vel = x_final - x_in (dynamics.py:136), NaN guard (dynamics.py:155-159: flag

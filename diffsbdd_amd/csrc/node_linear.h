@@ -292,6 +292,64 @@ __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The tiny two-layer MLPs at both ends of the denoiser (atom / residue encoders and decoders, dynamics.py:27-49:
+// 10..128 -> 20..40 -> 10..128 features): out = W1 . SiLU(W0 . in + b0) + b1 per node, both layers in one launch on the
+// vector ALUs, up to two independent problems (ligand nodes, pocket nodes) per launch.  They are a few MFLOP; as four
+// separate GEMM launches they cost four launch latencies.
+struct Mlp2Problem {
+  const float* in; int ld_in; int K0;      // [rows][K0]
+  const float* W0T; int ldw0; const float* b0; int M1;   // [K0][ldw0], hidden width M1
+  const float* W1T; int ldw1; const float* b1; int n_out;   // [M1][ldw1]
+  float* out; int ld_out; int rows;
+};
+struct Mlp2Args { Mlp2Problem p[2]; };
+constexpr int kMlp2Rows = 32, kMlp2MaxK = 128, kMlp2MaxMid = 40, kMlp2MaxOut = 128;
+
+__global__ __launch_bounds__(kThreads) void mlp2_kernel(Mlp2Args a) {
+  __shared__ float sW0[kMlp2MaxK * kMlp2MaxMid];
+  __shared__ float sW1[kMlp2MaxMid * kMlp2MaxOut];
+  __shared__ float sIn[kMlp2Rows * (kMlp2MaxK + 1)];
+  __shared__ float sMid[kMlp2Rows * (kMlp2MaxMid + 1)];
+  const Mlp2Problem& p = a.p[blockIdx.y];
+  const int t = threadIdx.x, r0 = blockIdx.x * kMlp2Rows;
+  if (r0 >= p.rows) return;
+  const int nr = min(kMlp2Rows, p.rows - r0);
+  for (int i = t; i < p.K0 * p.M1; i += kThreads) sW0[i] = p.W0T[(size_t)(i / p.M1) * p.ldw0 + i % p.M1];
+  for (int i = t; i < p.M1 * p.n_out; i += kThreads) sW1[i] = p.W1T[(size_t)(i / p.n_out) * p.ldw1 + i % p.n_out];
+  for (int i = t; i < nr * p.K0; i += kThreads)
+    sIn[(i / p.K0) * (kMlp2MaxK + 1) + i % p.K0] = p.in[(size_t)(r0 + i / p.K0) * p.ld_in + i % p.K0];
+  __syncthreads();
+  for (int i = t; i < nr * p.M1; i += kThreads) {
+    const int r = i / p.M1, j = i % p.M1;
+    float v = p.b0[j];
+    const float* x = sIn + r * (kMlp2MaxK + 1);
+    for (int k = 0; k < p.K0; ++k) v = fmaf(x[k], sW0[k * p.M1 + j], v);
+    sMid[r * (kMlp2MaxMid + 1) + j] = silu(v);
+  }
+  __syncthreads();
+  for (int i = t; i < nr * p.n_out; i += kThreads) {
+    const int r = i / p.n_out, c = i % p.n_out;
+    float v = p.b1[c];
+    const float* m = sMid + r * (kMlp2MaxMid + 1);
+    for (int j = 0; j < p.M1; ++j) v = fmaf(m[j], sW1[j * p.n_out + c], v);
+    p.out[(size_t)(r0 + r) * p.ld_out + c] = v;
+  }
+}
+
+inline bool mlp2_fits(const Mlp2Problem& p) {
+  return p.K0 <= kMlp2MaxK && p.M1 <= kMlp2MaxMid && p.n_out <= kMlp2MaxOut;
+}
+
+inline hipError_t launch_mlp2(hipStream_t s, const Mlp2Problem* p, int n) {
+  Mlp2Args a{};
+  int rows = 0;
+  for (int i = 0; i < n; ++i) { a.p[i] = p[i]; rows = max(rows, p[i].rows); }
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mlp2_kernel, dim3((rows + kMlp2Rows - 1) / kMlp2Rows, n), dim3(kThreads), 0, s, a);
+  return hipGetLastError();
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline bool vec_ok(const NodeLinearArgs& a) {
