@@ -147,6 +147,37 @@ def edge_capacity(mask_lig, mask_pocket, batch, check_sorted=True):
     return int((seg(nl * n) + seg(np_ * n)).sum().item())
 
 
+def frame_layout(sizes, representative, mask_pocket):
+    """Index arrays of a pocket frame (include/diffsbdd_hip.h, dsbdd_engine_set_pocket_frame) from the pocket sizes
+    [batch], the representative sample of every sample [batch] (a sample with an identical pocket, possibly itself)
+    and the pocket mask [n_pocket]: (mask_frame [n_frame] = frame sample of every frame row, frame_rows [n_frame] =
+    its row in the pocket array, twin [n_pocket] = the frame row standing for each pocket row, sizes of the frame
+    samples).  The frame samples are the distinct representatives in ascending order.  Pure index arithmetic on
+    whatever device the inputs live on."""
+    dev = sizes.device
+    sz = sizes.to(torch.int64)
+    rep = representative.to(device=dev, dtype=torch.int64)
+    batch = sz.numel()
+    if rep.numel() != batch or bool((rep < 0).any()) or bool((rep >= batch).any()):
+        raise ValueError("representative must name a sample of the batch for every sample")
+    if bool((sz[rep] != sz).any()) or bool((rep[rep] != rep).any()):
+        raise ValueError("a representative must have the same pocket size as the samples it stands for, "
+                         "and must represent itself")
+    off = torch.cumsum(sz, 0) - sz                                      # first pocket row of every sample
+    reps = torch.unique(rep)                                            # sorted representative samples
+    frame_id = torch.zeros(batch, dtype=torch.int64, device=dev)
+    frame_id[reps] = torch.arange(reps.numel(), device=dev)
+    sz_f = sz[reps]
+    off_f = torch.cumsum(sz_f, 0) - sz_f                                # first frame row of every representative
+    n3 = int(sz_f.sum().item())
+    mask3 = torch.repeat_interleave(torch.arange(reps.numel(), device=dev), sz_f)
+    frame_rows = (torch.arange(n3, device=dev) - off_f[mask3] + off[reps][mask3]).to(torch.int32).contiguous()
+    mp = mask_pocket.to(device=dev, dtype=torch.int64)
+    within = torch.arange(mp.numel(), device=dev) - off[mp]             # atom index inside its sample
+    twin = (off_f[frame_id[rep]][mp] + within).to(torch.int32).contiguous()
+    return mask3, frame_rows, twin, sz_f
+
+
 class HipEngine:
     """One dsbdd_engine + its weights and workspace on one GPU."""
 
@@ -213,17 +244,8 @@ class HipEngine:
         if representative is None:
             representative = torch.zeros(batch, dtype=torch.int64) if shared else torch.arange(batch)
         rep = torch.as_tensor(representative, dtype=torch.int64).to(dev)
-        off = torch.cumsum(sz, 0) - sz                                  # first pocket row of every sample
-        reps = torch.unique(rep)                                        # sorted representative samples
-        frame_id = torch.zeros(batch, dtype=torch.int64, device=dev)
-        frame_id[reps] = torch.arange(reps.numel(), device=dev)
-        sz_f = sz[reps]
-        off_f = torch.cumsum(sz_f, 0) - sz_f                            # first frame row of every representative
-        n3, b3 = int(sz_f.sum().item()), int(reps.numel())
-        mask3 = torch.repeat_interleave(torch.arange(b3, device=dev), sz_f)
-        frame_rows = (torch.arange(n3, device=dev) - off_f[mask3] + off[reps][mask3]).to(torch.int32).contiguous()
-        within = torch.arange(n_pocket, device=dev) - off[mask_pocket]   # atom index inside its sample
-        twin = (off_f[frame_id[rep]][mask_pocket] + within).to(torch.int32).contiguous()
+        mask3, frame_rows, twin, sz_f = frame_layout(sz, rep, mask_pocket)
+        n3, b3 = int(frame_rows.numel()), int(sz_f.numel())
         x_frame = x_pocket[frame_rows.long()].contiguous()
         bound = int((((sz_f * sz_f) + 31) // 32 * 32).sum().item()) + 32
         self._frame_keep = (x_frame, twin, mask3, frame_rows)

@@ -344,3 +344,42 @@ def test_aligned_edge_layout_and_atomic_free_aggregation_protocol():
         idx_s, _, _, _, out_s = run(sub)
         pos = {int(i): r for r, i in enumerate(idx)}
         assert np.array_equal(out_s, np.stack([out[pos[int(i)]] for i in idx_s])), sub
+
+
+def test_pocket_groups_and_frame_layout():
+    """Host side of the pocket frame (en_diffusion._pocket_groups, engine.frame_layout): identical pockets are found by
+    content, the frame holds the distinct representatives in order, twin / frame_rows index them consistently, and
+    inconsistent groupings are rejected before anything reaches the GPU."""
+    import torch
+    from diffsbdd_amd.en_diffusion import EnVariationalDiffusion as EVD
+    from diffsbdd_amd.engine import frame_layout
+    g = torch.Generator().manual_seed(0)
+    A, B_ = torch.randn(5, 3, generator=g), torch.randn(7, 3, generator=g)
+    hA, hB = torch.eye(4)[torch.tensor([0, 1, 2, 3, 0])], torch.eye(4)[torch.tensor([1, 1, 2, 0, 3, 2, 1])]
+    # one pocket repeated: decided without hashing -> all zeros
+    x = A.repeat(3, 1)
+    assert EVD._pocket_groups(x, hA.repeat(3, 1), torch.tensor([5, 5, 5]), 3).tolist() == [0, 0, 0]
+    # A B A B' A: B' differs from B in one coordinate; same sizes do not make pockets identical
+    Bp = B_.clone()
+    Bp[3, 1] += 1e-3
+    xs, hs, sizes = torch.cat([A, B_, A, Bp, A]), torch.cat([hA, hB, hA, hB, hA]), torch.tensor([5, 7, 5, 7, 5])
+    rep = EVD._pocket_groups(xs, hs, sizes, 5)
+    assert rep.tolist() == [0, 1, 0, 3, 0]
+    # same coordinates, different atom types -> different pockets
+    hA2 = hA.clone()
+    hA2[0] = torch.eye(4)[2]
+    assert EVD._pocket_groups(torch.cat([A, A]), torch.cat([hA, hA2]), torch.tensor([5, 5]), 2).tolist() == [0, 1]
+    mask = torch.repeat_interleave(torch.arange(5), sizes)
+    mask3, rows, twin, sz_f = frame_layout(sizes, rep, mask)
+    assert sz_f.tolist() == [5, 7, 7] and mask3.tolist() == [0] * 5 + [1] * 7 + [2] * 7
+    assert rows.tolist() == list(range(0, 5)) + list(range(5, 12)) + list(range(17, 24))       # samples 0, 1, 3
+    assert torch.equal(xs[rows.long()][twin.long()], torch.cat([A, B_, A, Bp, A]))               # twin reproduces every pocket
+    assert twin[:5].tolist() == twin[12:17].tolist() == twin[24:].tolist() == [0, 1, 2, 3, 4]
+    # every sample its own representative = identity
+    m3, r3, t3, _ = frame_layout(sizes, torch.arange(5), mask)
+    assert r3.tolist() == t3.tolist() == list(range(29)) and torch.equal(m3, mask)
+    for bad in ([0, 1, 1, 3, 0],        # sample 2 (5 atoms) represented by a 7-atom pocket
+                [0, 1, 0, 3, 2],        # sample 2 represents sample 4 but not itself
+                [0, 1, 0, 3, 9]):       # not a sample of the batch
+        with pytest.raises(ValueError):
+            frame_layout(sizes, torch.tensor(bad), mask)
