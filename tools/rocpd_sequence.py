@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Dispatch sequence of ONE forward call from a rocprofv3 rocpd database: the
-launches between two consecutive `prep_kernel` dispatches (default: the last
+launches between two consecutive `prep_assemble_kernel` dispatches (default: the last
 complete call), one line per dispatch with its duration and the gap to the
 previous one, plus a summary grouped by (kernel, grid).
 Usage: rocpd_sequence.py results.db [call_index_from_end=2]"""
@@ -18,7 +18,11 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     rows = db.execute("select name, start, end, grid_x, grid_y, workgroup_x from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if "prep_kernel" in r[0]]
+    # a forward call starts with prep_assemble_kernel (prep_kernel in older builds; a chain's pocket frame also runs
+    # one prep_kernel, which is not a call boundary)
+    marks = [i for i, r in enumerate(rows) if "prep_assemble_kernel" in r[0]]
+    if not marks:
+        marks = [i for i, r in enumerate(rows) if "prep_kernel" in r[0]]
     if len(marks) < back + 1:
         sys.exit("not enough forward calls in the trace")
     lo, hi = marks[-back - 1], marks[-back]
