@@ -597,11 +597,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   const int n_frame_rows = split0 ? (int)e->frame_n3 : 0;
   const int n_ghost = (split0 && prune) ? n_frame_rows : 0;
   const int64_t ghost_slots = (split0 && prune) ? e->ghost_slots : 0;
-  if (split0 && e->ghost_dirty) {
-    int rc = ghost_setup(e, s);
-    if (rc) return rc;
-  }
-  if (!split0) e->ghost_dirty = true;     // this call may write over the ghost rows
+  // (the ghost rows are kept valid by dsbdd_dynamics_forward, which also covers the calls that replay a graph)
   constexpr int LV = kLevels - 1;                       // "everything"
   auto radius_of = [&](int g) {
     const int bw = G_stages - g, fw = g + 1;
@@ -991,6 +987,20 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
   if (ext_row && (!ext_col || ext_n_edges < 0 || ext_n_edges > e->cap_edges))
     return fail(DSBDD_ERR_CAPACITY, "external edge list exceeds edge capacity");
   hipStream_t s = static_cast<hipStream_t>(stream);
+
+  // Ghost rows of a pocket frame (set once per chain) share the node arrays with the real nodes: a call the frame
+  // does not apply to (other sizes, teacher-forced edges) may write over them -- eagerly or through a replayed
+  // graph --, so they are re-written from the pristine frame data before the next framed call, whichever way it runs.
+  {
+    const bool framed = e->frame && !e->cfg.update_pocket_coords && !ext_row && n_lig == e->frame_nlig &&
+                        n_pocket == e->frame_npoc && batch == e->frame_batch;
+    if (!framed) {
+      e->ghost_dirty = true;
+    } else if (e->ghost_dirty) {
+      int rc = ghost_setup(e, s);
+      if (rc) return rc;
+    }
+  }
 
   // eager path: graphs off, timing / tracing hooks active (they enqueue event records and
   // copies that must not be frozen into a graph), or teacher-forced edges (test-only)

@@ -510,3 +510,31 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
         with oracle_threads():
             o1, _, _ = eo.dynamics_forward(sd, cfg, *a1[:2], t, *a1[3:], edges=e1)
         assert excess(one, o1) <= 0
+
+
+def test_frame_survives_unrelated_calls_on_the_same_engine():
+    """The frame's ghost rows live behind the real nodes in the engine's node arrays.  A call the frame does not apply
+    to (here: a larger batch, eager and through its own replayed graph) writes over them; the next framed call --
+    a graph replay -- must see them restored (dsbdd_dynamics_forward re-writes them from the pristine frame data)."""
+    from diffsbdd_amd.engine import edge_capacity
+    cfg, dd, xl, xp, t, ml, mp = bench_problem("crossdock_fullatom_cond", 4)
+    sd = W.random_state_dict(cfg, 0)
+    d = dev()
+    nl, n0 = len(ml) // 4, len(mp) // 4
+    m = make_dynamics(cfg, sd)
+    eng = m.engine()
+    big = [v.to(d) for v in (xl, xp, t[:1], ml, mp)]
+    cap_big = edge_capacity(big[3], big[4], 4)
+    small = [v.to(d) for v in (xl[:2 * nl], xp[:2 * n0], t[:1], ml[:2 * nl], mp[:2 * n0])]
+    eng.ensure_workspace(len(ml), len(mp), 4, cap_big)          # one workspace for both problem sizes
+    cap = edge_capacity(small[3], small[4], 2)
+    eng.set_pocket_frame(small[1][:, :3].contiguous(), small[4], torch.full((2,), n0).to(d), 2 * nl, 2, cap, False)
+    first = [m.forward_async(*small, batch=2, edge_cap=cap_big, want_pocket=False)[0].clone() for _ in range(3)]
+    assert eng.last_plan()[0] == [1, 2, 3, 3, 2, 1]
+    other = [m.forward_async(*big, batch=4, edge_cap=cap_big, want_pocket=False)[0].clone() for _ in range(3)]
+    assert eng.last_plan()[0] == [4, 4, 4, 3, 2, 1]            # the frame does not apply to this size
+    again = [m.forward_async(*small, batch=2, edge_cap=cap_big, want_pocket=False)[0].clone() for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(first[0], first[2]) and torch.equal(other[0], other[2])
+    assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[0])
+    eng.clear_pocket_frame()
