@@ -89,6 +89,8 @@ struct dsbdd_engine {
     int seen = 0;                 // 1st call runs eagerly (warm-up), 2nd captures, then replay
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    std::vector<int> plan_radius, plan_ghost;   // what dsbdd_engine_last_plan reports after a replay of this graph
+    int plan_timed_level = 0;
   };
   std::vector<GraphEntry> graphs;
   int use_graph = 1;
@@ -1035,6 +1037,7 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
   if (g->exec) {
     ++e->n_replay;
     HIP_TRY(hipGraphLaunch(g->exec, s));
+    e->plan_radius = g->plan_radius; e->plan_ghost = g->plan_ghost; e->plan_timed_level = g->plan_timed_level;
     return DSBDD_OK;
   }
   ++e->n_eager;
@@ -1064,6 +1067,7 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
   }
   g->graph = graph;
   g->exec = exec;
+  g->plan_radius = e->plan_radius; g->plan_ghost = e->plan_ghost; g->plan_timed_level = e->plan_timed_level;
   ++e->n_capture;
   HIP_TRY(hipGraphLaunch(g->exec, s));
   return DSBDD_OK;
