@@ -180,19 +180,16 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
 constexpr int kMaxGroup = 3;
 struct NodeGroupArgs { NodeLinearArgs p[kMaxGroup]; };
 
+// One 128-row x (32*CT)-column output tile, computed by the calling workgroup.
 template <int CT>
-__global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga) {
+__device__ __forceinline__ void node_gemm_tile(const NodeLinearArgs& p, const int m0, const int n0, const int M,
+                                               float* sB) {
   constexpr int BN = 32 * CT, BK = (CT == 1 ? 64 : 128 / CT), NG = BK / 8;
   constexpr int BI = BK * BN / 4 / kThreads;          // float4 DMA pieces per thread per slice
   constexpr int RQ = BN / 4;                          // float4 per slice row
-  __shared__ float sB[2 * BK * BN];
-  const NodeLinearArgs& p = ga.p[blockIdx.z];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, j = lane & 31;
-  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
   const int K = p.K1 + p.K2;
-  const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
-  if (m0 >= M || n0 >= p.N) return;   // uniform per workgroup
 
   auto streamB = [&](int ks, int buf) {
 #ifdef DSBDD_DIAG_NODE_NODMA
@@ -292,6 +289,33 @@ __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(
   }
 }
 
+
+// Tile schedule.  The workgroup ids of a problem are one-dimensional: first the FULL tiles (128 rows x 32*CT columns,
+// column tile fastest), then the row tiles at the end of the matrix as HALF-width tiles (32*CT/2 columns, two per
+// full tile).  With `balance` = number of CUs the full tiles are the largest multiple of `balance` that fits: a
+// problem of 620 full tiles on 256 CUs (2.42 per CU: some CUs would run 3, most 2) becomes 512 full + 216 half tiles
+// = at most 2.5 per CU.  Every output element is computed by exactly one workgroup with the same k order in both tile
+// shapes, so the schedule never changes a bit of the result.  (A problem with fewer tiles than CUs runs entirely on
+// half tiles: twice as many, half as long workgroups -- what the 32-column heuristic did for small launches.)
+template <int CT>
+__global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga, int balance) {
+  constexpr int BN = 32 * CT, BK = (CT == 1 ? 64 : 128 / CT);
+  __shared__ float sB[2 * BK * BN];                   // (the half-width variant needs the same or less)
+  const NodeLinearArgs& p = ga.p[blockIdx.z];
+  const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
+  const int m_tiles = (M + 127) / 128, gy = p.N / BN;
+  int n_full = m_tiles;                               // row tiles computed as full-width tiles
+  if (CT > 1 && balance > 0) n_full = (m_tiles * gy / balance) * balance / gy;
+  const int id = blockIdx.x;
+  if (id < n_full * gy) {
+    node_gemm_tile<CT>(p, (id / gy) * 128, (id % gy) * BN, M, sB);
+  } else if (CT > 1) {
+    const int id2 = id - n_full * gy, rt = n_full + id2 / (2 * gy);
+    if (rt >= m_tiles) return;                        // uniform per workgroup
+    node_gemm_tile<(CT > 1 ? CT / 2 : 1)>(p, rt * 128, (id2 % (2 * gy)) * (BN / 2), M, sB);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The tiny two-layer MLPs at both ends of the denoiser (atom / residue encoders and decoders, dynamics.py:27-49:
 // 10..128 -> 20..40 -> 10..128 features): out = W1 . SiLU(W0 . in + b0) + b1 per node, both layers in one launch on the
@@ -380,6 +404,22 @@ inline int node_ct_override() {
   return v;
 }
 
+// Number of CUs the tile schedule of node_gemm_kernel balances over (DSBDD_NODE_BALANCE=0: full-width tiles only).
+inline int node_balance() {
+  static const int v = [] {
+    const char* s = getenv("DSBDD_NODE_BALANCE");
+    if (s) return atoi(s);
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+      return 0;
+    int p = 1;                       // the schedule needs a power of two (it must be a multiple of the column tiles)
+    while (2 * p <= cu) p *= 2;
+    return p;
+  }();
+  return v;
+}
+
 // One launch for up to kMaxGroup eligible problems (all must accept the same CT).
 // Returns hipErrorInvalidValue when the group cannot share a launch.
 inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int n) {
@@ -396,16 +436,19 @@ inline hipError_t launch_node_group(hipStream_t s, const NodeLinearArgs* a, int 
   for (int i = 0; i < n; ++i)
     if (gemm_ct(a[i], ct) != ct) return hipErrorInvalidValue;
   NodeGroupArgs ga{};
-  int gx = 0, gy = 0;
+  int balance = ct > 1 ? node_balance() : 0;
+  for (int i = 0; i < n && balance > 0; ++i)          // the half-width tiles are the ct / 2 kernel's: same constraints
+    if (gemm_ct(a[i], ct / 2) != ct / 2 || balance % (a[i].N / (32 * ct)) != 0) balance = 0;
+  int gx = 0;
   for (int i = 0; i < n; ++i) {
     ga.p[i] = a[i];
-    gx = max(gx, (a[i].M + 127) / 128);
-    gy = max(gy, a[i].N / (32 * ct));
+    // one-dimensional workgroup ids per problem (node_gemm_kernel): worst case every row tile as half-width tiles
+    gx = max(gx, ((a[i].M + 127) / 128) * (a[i].N / (32 * ct)) * (balance > 0 ? 2 : 1));
   }
-  dim3 grid(gx, gy, n), block(kThreads);
-  if (ct == 4)      hipLaunchKernelGGL((node_gemm_kernel<4>), grid, block, 0, s, ga);
-  else if (ct == 2) hipLaunchKernelGGL((node_gemm_kernel<2>), grid, block, 0, s, ga);
-  else              hipLaunchKernelGGL((node_gemm_kernel<1>), grid, block, 0, s, ga);
+  dim3 grid(gx, 1, n), block(kThreads);
+  if (ct == 4)      hipLaunchKernelGGL((node_gemm_kernel<4>), grid, block, 0, s, ga, balance);
+  else if (ct == 2) hipLaunchKernelGGL((node_gemm_kernel<2>), grid, block, 0, s, ga, balance);
+  else              hipLaunchKernelGGL((node_gemm_kernel<1>), grid, block, 0, s, ga, balance);
   return hipGetLastError();
 }
 
