@@ -292,9 +292,8 @@ __device__ __forceinline__ void node_gemm_tile(const NodeLinearArgs& p, const in
 
 // Tile schedule.  The workgroup ids of a problem are one-dimensional: first the FULL tiles (128 rows x 32*CT columns,
 // column tile fastest), then the row tiles at the end of the matrix as HALF-width tiles (32*CT/2 columns, two per
-// full tile).  With `balance` = number of CUs the full tiles are the largest multiple of `balance` that fits: a
-// problem of 620 full tiles on 256 CUs (2.42 per CU: some CUs would run 3, most 2) becomes 512 full + 216 half tiles
-// = at most 2.5 per CU.  Every output element is computed by exactly one workgroup with the same k order in both tile
+// full tile).  The full tiles are the largest multiple of `balance` (two per CU) that fits: a problem of 620 full
+// tiles on 256 CUs (2.42 per CU: some CUs would run 3, most 2) becomes 512 full + 216 half tiles = at most 2.5 per CU.  Every output element is computed by exactly one workgroup with the same k order in both tile
 // shapes, so the schedule never changes a bit of the result.  (A problem with fewer tiles than CUs runs entirely on
 // half tiles: twice as many, half as long workgroups -- what the 32-column heuristic did for small launches.)
 template <int CT>
@@ -404,7 +403,9 @@ inline int node_ct_override() {
   return v;
 }
 
-// Number of CUs the tile schedule of node_gemm_kernel balances over (DSBDD_NODE_BALANCE=0: full-width tiles only).
+// Granularity of the full-tile count in node_gemm_kernel's tile schedule: two workgroups per CU (measured 34.51 /
+// 34.56 / 34.60 ligands/s for 0.5 / 1 / 2 per CU; 4 per CU -- nearly everything on half tiles -- 34.07; off 33.37).
+// DSBDD_NODE_BALANCE overrides (0: full-width tiles only).
 inline int node_balance() {
   static const int v = [] {
     const char* s = getenv("DSBDD_NODE_BALANCE");
@@ -415,7 +416,7 @@ inline int node_balance() {
       return 0;
     int p = 1;                       // the schedule needs a power of two (it must be a multiple of the column tiles)
     while (2 * p <= cu) p *= 2;
-    return p;
+    return 2 * p;
   }();
   return v;
 }
