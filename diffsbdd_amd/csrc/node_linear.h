@@ -391,7 +391,8 @@ inline int gemm_ct(const NodeLinearArgs& a, int forced_ct, bool allow_small = tr
   // few rows (e.g. the C-alpha workloads, M ~ 2k): 32-column tiles make twice as many, half as long
   // workgroups -- the launch is bounded by one workgroup's latency, not by throughput
   if (allow_small && (long)((a.M + 127) / 128) * (a.N / 64) < 128 && fits(1)) return 1;
-  if (a.N >= 512 && fits(4)) return 4;
+  // 64-column tiles also for the wide projections (N = 512 / 1024): with the balanced tile schedule they measured
+  // 34.77 vs 34.54 ligands/s against 128-column tiles
   return fits(2) ? 2 : (fits(4) ? 4 : 0);
 }
 
