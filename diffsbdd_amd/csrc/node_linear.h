@@ -173,18 +173,30 @@ __global__ __launch_bounds__(kThreads) void node_linear_kernel(NodeLinearArgs p)
 //     L1 miss (every row opens a new 128-byte line every 32 k) has 64 MFMAs to land;
 //   * the weight slice [BK][32*CT] is streamed by global_load_lds (double buffered, one
 //     barrier per K step); workgroup = 4 waves x 32 rows = 128 rows x 32*CT columns;
-//   * BK = 128 / CT keeps 64 MFMAs per wave between barriers for both tile widths;
+//   * K step per tile width: node_bk() below (short steps measured best);
 //   * up to three independent problems share one launch (blockIdx.z): the small
 //     ligand-row / active-subset projections of the coordinate MLPs ride along with
 //     the next block's P|Q projection instead of running alone on a fraction of the CUs.
 constexpr int kMaxGroup = 3;
 struct NodeGroupArgs { NodeLinearArgs p[kMaxGroup]; };
 
+// K step (rows of a weight slice) per tile width.  Measured with the balanced schedule, same box, ligands/s:
+// 64 / 64: 34.83, 32 / 32: 35.10, 16 / 32: 35.21, 128 / 64: 32.7 -- short steps (16 MFMAs per wave between
+// barriers, 8 KB of LDS per workgroup) beat long ones here: the launches are a few tiles per CU, so what counts is
+// how soon a workgroup's first MFMA issues and how many workgroups a CU holds, not the barrier count.
+#ifndef DSBDD_NODE_BK2
+#define DSBDD_NODE_BK2 16        // 64-column tile
+#endif
+#ifndef DSBDD_NODE_BK1
+#define DSBDD_NODE_BK1 32        // 32-column (half) tile
+#endif
+constexpr int node_bk(int ct) { return ct == 1 ? DSBDD_NODE_BK1 : (ct == 2 ? DSBDD_NODE_BK2 : 128 / ct); }
+
 // One 128-row x (32*CT)-column output tile, computed by the calling workgroup.
 template <int CT>
 __device__ __forceinline__ void node_gemm_tile(const NodeLinearArgs& p, const int m0, const int n0, const int M,
                                                float* sB) {
-  constexpr int BN = 32 * CT, BK = (CT == 1 ? 64 : 128 / CT), NG = BK / 8;
+  constexpr int BN = 32 * CT, BK = node_bk(CT), NG = BK / 8;
   constexpr int BI = BK * BN / 4 / kThreads;          // float4 DMA pieces per thread per slice
   constexpr int RQ = BN / 4;                          // float4 per slice row
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -298,8 +310,10 @@ __device__ __forceinline__ void node_gemm_tile(const NodeLinearArgs& p, const in
 // half tiles: twice as many, half as long workgroups -- what the 32-column heuristic did for small launches.)
 template <int CT>
 __global__ __launch_bounds__(kThreads, (CT == 4 ? 3 : 4)) void node_gemm_kernel(NodeGroupArgs ga, int balance) {
-  constexpr int BN = 32 * CT, BK = (CT == 1 ? 64 : 128 / CT);
-  __shared__ float sB[2 * BK * BN];                   // (the half-width variant needs the same or less)
+  constexpr int BN = 32 * CT, BK = node_bk(CT);
+  constexpr int LDSF = 2 * BK * BN > 2 * node_bk(CT > 1 ? CT / 2 : 1) * (BN / 2) ? 2 * BK * BN
+                                                                                 : 2 * node_bk(CT > 1 ? CT / 2 : 1) * (BN / 2);
+  __shared__ float sB[LDSF];                          // room for either tile shape
   const NodeLinearArgs& p = ga.p[blockIdx.z];
   const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
   const int m_tiles = (M + 127) / 128, gy = p.N / BN;
@@ -384,7 +398,7 @@ inline bool vec_ok(const NodeLinearArgs& a) {
 inline int gemm_ct(const NodeLinearArgs& a, int forced_ct, bool allow_small = true) {
   if (!vec_ok(a) || a.ldw % 4 != 0 || !aligned16(a.WT) || a.K1 <= 0) return 0;
   auto fits = [&](int ct) {
-    const int bk = ct == 1 ? 64 : 128 / ct, bn = 32 * ct;
+    const int bk = node_bk(ct), bn = 32 * ct;
     return a.K1 % bk == 0 && a.K2 % bk == 0 && a.N % bn == 0;
   };
   if (forced_ct && fits(forced_ct)) return forced_ct;
