@@ -311,3 +311,44 @@ def tile_protocol_aggregate(values, erow, row_ptr, deg):
             v = (v + head[T]).astype(np.float32)
         out[i] = v
     return out
+
+
+# ---------------------------------------------------------------------------
+# Host models of two device-side schedules (index arithmetic only)
+# ---------------------------------------------------------------------------
+def node_gemm_schedule(M, N, ct, balance, grid_x=None):
+    """Which output block every workgroup id of node_gemm_kernel<ct> computes (csrc/node_linear.h, "Tile schedule"):
+    list of (row0, col0, n_cols) per id, None for ids that exit.  Rows come in tiles of 128, full tiles are
+    32*ct columns wide, the row tiles after the first n_full are computed as two half-width tiles each."""
+    bn = 32 * ct
+    m_tiles, gy = (M + 127) // 128, N // bn
+    n_full = m_tiles
+    if ct > 1 and balance > 0:
+        n_full = (m_tiles * gy // balance) * balance // gy
+    if grid_x is None:
+        grid_x = m_tiles * gy * (2 if (ct > 1 and balance > 0) else 1)
+    out = []
+    for wid in range(grid_x):
+        if wid < n_full * gy:
+            out.append(((wid // gy) * 128, (wid % gy) * bn, bn))
+        elif ct > 1:
+            id2 = wid - n_full * gy
+            rt = n_full + id2 // (2 * gy)
+            out.append(None if rt >= m_tiles else (rt * 128, (id2 % (2 * gy)) * (bn // 2), bn // 2))
+        else:
+            out.append(None)
+    return out, n_full
+
+
+def stage_plan(n_stages, cone, levels=5):
+    """Radius and ghost flag of every message stage of a ligand-output-only call (csrc/engine.hip forward_impl):
+    backward cone G - g, with the forward cone min(g + 1, G - g); radii are capped at levels - 1 ("every row"); the
+    canonical pocket is evaluated while a later stage still reads rows the previous one did not compute."""
+    lv = levels - 1
+    radius = [min((min(n_stages - g, g + 1) if cone else n_stages - g), lv) for g in range(n_stages)]
+    last = -1
+    if cone:
+        for g in range(n_stages - 1):
+            if min(radius[g + 1] + 1, lv) > radius[g]:
+                last = g
+    return radius, [int(g <= last) for g in range(n_stages)]

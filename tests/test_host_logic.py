@@ -383,3 +383,57 @@ def test_pocket_groups_and_frame_layout():
                 [0, 1, 0, 3, 9]):       # not a sample of the batch
         with pytest.raises(ValueError):
             frame_layout(sizes, torch.tensor(bad), mask)
+
+
+def test_node_gemm_tile_schedule_covers_every_output_once():
+    """Host model of node_gemm_kernel's workgroup-id -> tile mapping (tests/_emulate.node_gemm_schedule mirrors
+    csrc/node_linear.h): every (row tile, 32-column block) of the output is produced by exactly one workgroup for any
+    row count (it is read on the device), the full tiles are a multiple of the balance granularity, and the benchmark's
+    620-tile problem becomes 512 full + 216 half tiles."""
+    for M, N, ct, balance in [(19776, 256, 2, 512), (19776, 512, 2, 512), (19776, 1024, 4, 512), (3640, 256, 2, 512),
+                              (1, 256, 2, 512), (128, 64, 2, 512), (19776, 256, 2, 0), (19776, 256, 1, 512),
+                              (65536, 512, 2, 512), (11545, 256, 2, 256), (5000, 192, 2, 512)]:
+        # the host launches for the row CAPACITY (here: up to 1.5x the rows the device finds)
+        cap_tiles = ((int(M * 1.5) + 127) // 128)
+        grid = cap_tiles * (N // (32 * ct)) * (2 if (ct > 1 and balance > 0) else 1)
+        sched, n_full = em.node_gemm_schedule(M, N, ct, balance, grid)
+        m_tiles = (M + 127) // 128
+        seen = np.zeros((m_tiles, N // 32), dtype=int)
+        for blk in sched:
+            if blk is None:
+                continue
+            r0, c0, w = blk
+            assert r0 % 128 == 0 and r0 // 128 < m_tiles and c0 + w <= N
+            seen[r0 // 128, c0 // 32:(c0 + w) // 32] += 1
+        assert (seen == 1).all(), (M, N, ct, balance)
+        gy = N // (32 * ct)
+        if ct > 1 and balance > 0:
+            assert (n_full * gy) % balance == 0 and (m_tiles - n_full) * gy < balance
+        else:
+            assert n_full == m_tiles
+    sched, n_full = em.node_gemm_schedule(19776, 256, 2, 512)
+    real = [b for b in sched if b is not None]
+    assert n_full == 128 and sum(1 for b in real if b[2] == 64) == 512 and sum(1 for b in real if b[2] == 32) == 216
+    # dispatch order: all full tiles first, column tile fastest
+    assert [b[2] for b in real[:512]] == [64] * 512 and [b[1] for b in real[:4]] == [0, 64, 128, 192]
+
+
+def test_stage_plan_model():
+    """Host model of the per-stage plan (tests/_emulate.stage_plan mirrors engine.hip; the GPU tests compare
+    dsbdd_engine_last_plan with the same formulas): a row evaluated by stage g + 1 is either computed by stage g or
+    canonical, the last stage computes hop <= 1, and without the forward cone the first stages compute everything."""
+    assert em.stage_plan(6, True) == ([1, 2, 3, 3, 2, 1], [1, 1, 1, 0, 0, 0])
+    assert em.stage_plan(6, False) == ([4, 4, 4, 3, 2, 1], [0] * 6)
+    assert em.stage_plan(2, True) == ([1, 1], [1, 0])            # stage 1 reads hop 2, which stage 0 did not compute
+    assert em.stage_plan(4, True) == ([1, 2, 2, 1], [1, 1, 0, 0])
+    assert em.stage_plan(10, True)[0] == [1, 2, 3, 4, 4, 4, 4, 3, 2, 1]
+    for G in range(1, 13):
+        for cone in (False, True):
+            radius, ghost = em.stage_plan(G, cone)
+            assert radius[-1] == 1 and all(1 <= r <= 4 for r in radius)
+            for g in range(G - 1):
+                # stage g + 1 reads level <= radius[g + 1] + 1: computed by stage g, or taken from the canonical pocket
+                need = min(radius[g + 1] + 1, 4)
+                assert need <= radius[g] or ghost[g] == 1
+                assert radius[g + 1] >= radius[g] - 1          # the backward cone shrinks by one hop per stage
+            assert not cone or ghost == sorted(ghost, reverse=True)       # ghosts only in the leading stages
