@@ -55,26 +55,7 @@ WORKLOADS = {
 }
 
 
-def load_pocket(key, batch, device):
-    z = np.load(os.path.join(ROOT, "diffsbdd_amd", "data", "pocket_3rfm.npz"))
-    n_types = 20 if key == "ca" else 10
-    return prepare_pocket(z[key + "_x"], z[key + "_types"], n_types, repeats=batch, device=device)
-
-
-def anchor_ligand(batch, n_lig, atom_nf, device):
-    """The pose the 'anchored' chains hold on to: the 3rfm ligand's own atom positions inside the pocket
-    (14 heavy atoms), filled up to n_lig atoms with jittered copies (seeded), random atom types."""
-    z = np.load(os.path.join(ROOT, "diffsbdd_amd", "data", "pocket_3rfm.npz"))
-    rng = np.random.RandomState(7)
-    base = z["ligand_x"].astype(np.float32)
-    extra = max(n_lig - len(base), 0)
-    pose = np.concatenate([base, base[rng.randint(0, len(base), extra)] + rng.normal(scale=0.9, size=(extra, 3))])[:n_lig]
-    types = rng.randint(0, atom_nf, n_lig)
-    x = torch.from_numpy(np.tile(pose, (batch, 1)).astype(np.float32)).to(device)
-    one_hot = torch.zeros(batch * n_lig, atom_nf, device=device)
-    one_hot[torch.arange(batch * n_lig), torch.from_numpy(np.tile(types, batch))] = 1.0
-    return {"x": x, "one_hot": one_hot, "size": torch.full((batch,), n_lig, dtype=torch.int64, device=device),
-            "mask": torch.repeat_interleave(torch.arange(batch, device=device), n_lig)}
+load_pocket, anchor_ligand = synthetic.load_pocket, synthetic.anchor_ligand
 
 
 def build_model(arch, device):

@@ -201,6 +201,23 @@ class ConditionalDDPM(EnVariationalDiffusion):
         out_pocket[0] = torch.cat([x_pocket, h_pocket], dim=1)
         return out_lig.squeeze(0), out_pocket.squeeze(0), lig_mask, pm
 
+    def _inpaint_iteration(self, s, co, z_lig, xh_pocket, zk_tmp, xh0_lig, com_pocket_0, fixed_f, lm, pm, n, status,
+                           resample):
+        """One (s, u) iteration of the RePaint loop (conditional_model.py:600-660), in place on z_lig / xh_pocket
+        (stable pointers: the engine replays its graph): the unknown part takes one reverse step (which moves the
+        pocket with the ligand COM), then ONE kernel noises the known part to level s around the moved pocket,
+        aligns the COM of the fixed atoms, blends, and (between resamplings) applies q(z_t | z_s)."""
+        self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
+        dl = self.n_dims + self.atom_nf
+        n1 = self._randn(lm, dl, n)
+        n2 = self._randn(lm, dl, n) if resample else None
+        _lib.check(_lib.load().dsbdd_cond_repaint_update(
+            self._cs(z_lig), z_lig.data_ptr(), xh_pocket.data_ptr(), zk_tmp.data_ptr(), xh0_lig.data_ptr(),
+            com_pocket_0.data_ptr(), fixed_f.data_ptr(), n1.data_ptr(), n2.data_ptr() if resample else None,
+            lm.data_ptr(), pm.data_ptr(), lm.numel(), pm.numel(), n, self.atom_nf, self.residue_nf,
+            float(co.alpha[s]), float(co.sigma_t[s]), float(co.alpha_ts[s]), float(co.sigma_ts[s]),
+            int(resample), self._remove_com), "dsbdd_cond_repaint_update")
+
     # ---- RePaint-style inpainting (conditional_model.py:557-686) ---------------------------------------
     @torch.no_grad()
     @_chain
@@ -238,24 +255,10 @@ class ConditionalDDPM(EnVariationalDiffusion):
         out_pocket = torch.zeros((return_frames,) + xh_pocket.size(), device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         co = self._coefs(timesteps)
-        lib = _lib.load()
-        dl = self.n_dims + self.atom_nf
         for s in reversed(range(0, timesteps)):
             for u in range(resamplings):
-                # z_lig / xh_pocket are updated in place (stable pointers: the engine replays its graph).
-                # unknown part: one reverse step (moves the pocket with the ligand COM) ...
-                self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
-                # ... then known part noised to level s around the moved pocket, COM alignment of the
-                # fixed atoms, blend, and (between resamplings) q(z_t | z_s): one kernel
-                resample = u < resamplings - 1
-                n1 = self._randn(lm, dl, n)
-                n2 = self._randn(lm, dl, n) if resample else None
-                _lib.check(lib.dsbdd_cond_repaint_update(
-                    self._cs(z_lig), z_lig.data_ptr(), xh_pocket.data_ptr(), zk_tmp.data_ptr(), xh0_lig.data_ptr(),
-                    com_pocket_0.data_ptr(), fixed_f.data_ptr(), n1.data_ptr(), n2.data_ptr() if resample else None,
-                    lm.data_ptr(), pm.data_ptr(), lm.numel(), pm.numel(), n, self.atom_nf, self.residue_nf,
-                    float(co.alpha[s]), float(co.sigma_t[s]), float(co.alpha_ts[s]), float(co.sigma_ts[s]),
-                    int(resample), self._remove_com), "dsbdd_cond_repaint_update")
+                self._inpaint_iteration(s, co, z_lig, xh_pocket, zk_tmp, xh0_lig, com_pocket_0, fixed_f, lm, pm, n,
+                                        status, resample=u < resamplings - 1)
                 if u == resamplings - 1 and (s * return_frames) % timesteps == 0:
                     idx = (s * return_frames) // timesteps
                     out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_lig, xh_pocket)

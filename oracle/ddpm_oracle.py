@@ -275,6 +275,33 @@ def cond_sample_p_zt_given_zs(m, zs_lig, xh0_pocket, lig_mask, pocket_mask, g_t,
     return cond_sample_normal_zero_com(m, mu, xh0_pocket, s_ts, lig_mask, pocket_mask, noise, n)
 
 
+def cond_inpaint_iteration(m, s, timesteps, z_lig, xh_pocket, x0_lig, h0_lig, com_pocket_0, lig_fixed, lm, pm,
+                           noise, resample=False):
+    """One (s, u) iteration of ConditionalDDPM.inpaint's loop body, conditional_model.py:600-660: reverse step
+    of the unknown part, the known part noised to level s around the moved pocket, COM alignment over the fixed
+    atoms, blend, and (between resamplings) q(z_t | z_s).  x0_lig / h0_lig: the normalised known ligand."""
+    nd = m.n_dims
+    n = com_pocket_0.shape[0]
+    fixed = lig_fixed.bool().view(-1)
+    lf = lig_fixed.view(-1, 1).to(z_lig.dtype)
+    s_arr = torch.full((n, 1), float(s)) / timesteps
+    t_arr = torch.full((n, 1), float(s + 1)) / timesteps
+    g_t, g_s = m.g(t_arr), m.g(s_arr)
+    z_unknown, xh_pocket = cond_sample_p_zs_given_zt(m, s_arr, t_arr, z_lig, xh_pocket, lm, pm, noise)
+    com_pocket = _seg_mean(xh_pocket[:, :nd], pm, n)
+    xh_ligand = torch.cat([x0_lig + (com_pocket - com_pocket_0)[lm], h0_lig], 1)
+    z_known, xh_pocket, _ = cond_noised_representation(m, xh_ligand, xh_pocket, lm, pm, g_s, noise, n)
+    com_noised = _seg_mean(z_known[fixed][:, :nd], lm[fixed], n)
+    com_denoised = _seg_mean(z_unknown[fixed][:, :nd], lm[fixed], n)
+    dx = com_denoised - com_noised
+    z_known = torch.cat([z_known[:, :nd] + dx[lm], z_known[:, nd:]], 1)
+    xh_pocket = torch.cat([xh_pocket[:, :nd] + dx[pm], xh_pocket[:, nd:]], 1)
+    z_lig = z_known * lf + z_unknown * (1 - lf)
+    if resample:
+        z_lig, xh_pocket = cond_sample_p_zt_given_zs(m, z_lig, xh_pocket, lm, pm, g_t, g_s, noise, n)
+    return z_lig, xh_pocket
+
+
 def cond_inpaint(m, ligand, pocket, lig_fixed, noise, resamplings=1, timesteps=None,
                  center="ligand"):
     """ConditionalDDPM.inpaint, conditional_model.py:557-686 (return_frames=1)."""
@@ -298,28 +325,11 @@ def cond_inpaint(m, ligand, pocket, lig_fixed, noise, resamplings=1, timesteps=N
     mu = torch.cat((mean_known, torch.zeros((n, m.atom_nf))), 1)[lm]
     z_lig, xh_pocket = cond_sample_normal_zero_com(
         m, mu, xh0_pocket, torch.ones((n, 1)), lm, pm, noise, n)
-    lf = lig_fixed.to(z_lig.dtype)
     for s in reversed(range(timesteps)):
         for u in range(resamplings):
-            s_arr = torch.full((n, 1), float(s)) / timesteps
-            t_arr = torch.full((n, 1), float(s + 1)) / timesteps
-            g_t, g_s = m.g(t_arr), m.g(s_arr)
-            z_unknown, xh_pocket = cond_sample_p_zs_given_zt(
-                m, s_arr, t_arr, z_lig, xh_pocket, lm, pm, noise)
-            com_pocket = _seg_mean(xh_pocket[:, :nd], pm, n)
-            xh_ligand = torch.cat(
-                [ligand["x"] + (com_pocket - com_pocket_0)[lm], xh_ligand[:, nd:]], 1)
-            z_known, xh_pocket, _ = cond_noised_representation(
-                m, xh_ligand, xh_pocket, lm, pm, g_s, noise, n)
-            com_noised = _seg_mean(z_known[fixed][:, :nd], lm[fixed], n)
-            com_denoised = _seg_mean(z_unknown[fixed][:, :nd], lm[fixed], n)
-            dx = com_denoised - com_noised
-            z_known = torch.cat([z_known[:, :nd] + dx[lm], z_known[:, nd:]], 1)
-            xh_pocket = torch.cat([xh_pocket[:, :nd] + dx[pm], xh_pocket[:, nd:]], 1)
-            z_lig = z_known * lf + z_unknown * (1 - lf)
-            if u < resamplings - 1:
-                z_lig, xh_pocket = cond_sample_p_zt_given_zs(
-                    m, z_lig, xh_pocket, lm, pm, g_t, g_s, noise, n)
+            z_lig, xh_pocket = cond_inpaint_iteration(
+                m, s, timesteps, z_lig, xh_pocket, ligand["x"], xh_ligand[:, nd:], com_pocket_0, lig_fixed, lm, pm,
+                noise, resample=u < resamplings - 1)
     x_lig, h_lig, x_p, h_p = cond_sample_p_xh_given_z0(m, z_lig, xh_pocket, lm, pm, n, noise)
     return torch.cat([x_lig, h_lig], 1), torch.cat([x_p, h_p], 1), lm, pm
 

@@ -266,8 +266,10 @@ def _hop_levels(row, col, n_lig, n_nodes, n_levels=5):
     ("small_cond", 6, True),              # two blocks: block 0 is a pruned stage AND split by the pocket frame
     ("small_cond", 6, "shared"),
     ("small_variant", 6, False),          # two sublayers per block, ligand cutoff, E(3) variant
+    ("crossdock_fullatom_cond", 8, "shared8"),  # the same with the persistent edge grid capped at 8 workgroups
+                                                # (DSBDD_EDGE_MAX_WG): ghost rows x several tiles per workgroup
 ])
-def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
+def test_ligand_only_call_evaluates_live_rows(arch, B, frame, monkeypatch):
     """A pocket-conditioned call that returns the ligand part only (what ConditionalDDPM's chains ask for,
     conditional_model.py:268-272) evaluates, per message stage, the rows the ligand output depends on -- prefixes
     of the level-ordered edge list (csrc/graph.h).  (i) the level structures against a numpy BFS over the
@@ -280,6 +282,9 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame):
     nl, n0 = len(ml) // B, len(mp) // B
     sizes = torch.full((B,), n0)
 
+    if frame == "shared8":
+        monkeypatch.setenv("DSBDD_EDGE_MAX_WG", "8")      # read when the engine is created (make_dynamics below)
+        frame = "shared"
     shared = frame == "shared"
     from diffsbdd_amd import _lib
     if shared:      # identical pockets: every sample's pocket is EXACTLY sample 0's plus a translation (what a chain has)
@@ -538,3 +543,92 @@ def test_frame_survives_unrelated_calls_on_the_same_engine():
     assert torch.equal(first[0], first[2]) and torch.equal(other[0], other[2])
     assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[0])
     eng.clear_pocket_frame()
+
+
+@pytest.mark.parametrize("B,n_lig,mode,n_steps", [
+    (64, 23, "inpaint", 3),      # bench.py's headline plan at its size
+    (64, 23, "sample", 2),       # the secondary (free-running) leg's step at the same size
+    (3, 14, "inpaint2", 4),      # small batch, resamplings = 2: the q(z_t | z_s) jump inside the fused kernel
+])
+def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps):
+    """The EXACT engine plan bench.py times, against the oracle at the size it is timed at: B identical 3rfm
+    full-atom pockets (prepare_pocket(repeats=B) -> one representative: shared pocket frame + forward cone),
+    the anchored ligand pose, ligand output only, one t for the batch -- message-stage radii [1,2,3,3,2,1] with the
+    canonical pocket on ghost rows for the first three, and at B = 64 E > 512 * 128 (several tiles per workgroup).
+    Teacher-forced iterations of ConditionalDDPM.inpaint's loop body (`_cond_step` + `dsbdd_cond_repaint_update`,
+    conditional_model.py:432-464,600-660; mode 'sample': the reverse step of sample_given_pocket alone): the
+    oracle's state goes into both sides every step (copied into the SAME device tensors, so the second call
+    captures the hipGraph and the later ones replay it), the same injected noise, the device-built radius graph
+    handed to the oracle; z_lig and the moved pocket within 1e-4 per step."""
+    from diffsbdd_amd import synthetic
+    arch = "crossdock_fullatom_cond"
+    cfg, dd = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, 0)
+    T = dd["timesteps"]
+    d = dev()
+    dl = 3 + cfg["atom_nf"]
+    model = _make_ddpm(arch, sd)
+    om = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], T, dd["noise_schedule"],
+                        dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
+    # the benchmark's inputs (bench.py: load_pocket + anchor_ligand), once per side
+    o_lig, o_poc = do.normalize(om, synthetic.anchor_ligand(B, n_lig, cfg["atom_nf"], "cpu"),
+                                synthetic.load_pocket("fa", B, "cpu"))
+    lm_c, pm_c = o_lig["mask"], o_poc["mask"]
+    ligand, pocket = model.normalize(synthetic.anchor_ligand(B, n_lig, cfg["atom_nf"], d),
+                                     synthetic.load_pocket("fa", B, d))
+    N = len(lm_c) + len(pm_c)
+    try:
+        lm, pm = model._begin_chain(ligand["mask"], pocket["mask"], B, pocket=pocket)      # sets the shared frame
+        assert model._framed
+        fixed_c = torch.ones(B * n_lig)
+        fixed_f = fixed_c.to(d)
+        com0 = model._seg_mean3(pocket["x"], pm, B)
+        com0_c = do._seg_mean(o_poc["x"], pm_c, B)
+        xh0_lig = torch.cat([ligand["x"], ligand["one_hot"]], 1).contiguous()
+        s0 = 120                                                       # alpha ~ 0.93: the pose sits inside the pocket
+        g_t = om.g(torch.full((B, 1), float(s0 + 1)) / T)
+        z_o, xp_o, _ = do.cond_noised_representation(
+            om, torch.cat([o_lig["x"], o_lig["one_hot"]], 1), torch.cat([o_poc["x"], o_poc["one_hot"]], 1),
+            lm_c, pm_c, g_t, do.NoiseTape(5), B)
+        z_d, xp_d = z_o.to(d).contiguous(), xp_o.to(d).contiguous()
+        zk_tmp = torch.empty_like(z_d)
+        status = torch.zeros(1, dtype=torch.int32, device=d)
+        co = model._coefs(T)
+        eng = model.dynamics.engine()
+        worst = -1.0
+        for k in range(n_steps):
+            s = s0 - k
+            resample = mode == "inpaint2" and k % 2 == 0
+            z_d.copy_(z_o); xp_d.copy_(xp_o)                           # teacher forcing, stable pointers
+            pre = do.NoiseTape(40 + k)
+            model.set_noise_source(do.NoiseReplay([pre((B * n_lig, dl)) for _ in range(3)]))
+            if mode == "sample":
+                model._cond_step(s, co, z_d, xp_d, lm, pm, B, status)
+            else:
+                model._inpaint_iteration(s, co, z_d, xp_d, zk_tmp, xh0_lig, com0, fixed_f, lm, pm, B, status, resample)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            radius, ghost, _ = eng.last_plan()
+            assert radius == [1, 2, 3, 3, 2, 1] and ghost == [1, 1, 1, 0, 0, 0], (radius, ghost)
+            er, ec = eng.last_edges(N)
+            if B == 64:
+                assert er.numel() > RESIDENT_TILES * 128, er.numel()
+            om.edge_hook = lambda i, e=torch.stack([er, ec]): e
+            with oracle_threads():
+                if mode == "sample":
+                    sa, ta = torch.full((B, 1), float(s)) / T, torch.full((B, 1), float(s + 1)) / T
+                    z_o, xp_o = do.cond_sample_p_zs_given_zt(om, sa, ta, z_o, xp_o, lm_c, pm_c, do.NoiseTape(40 + k))
+                else:
+                    z_o, xp_o = do.cond_inpaint_iteration(om, s, T, z_o, xp_o, o_lig["x"], o_lig["one_hot"], com0_c,
+                                                          fixed_c, lm_c, pm_c, do.NoiseTape(40 + k), resample=resample)
+            e_l, e_p = excess(z_d, z_o), excess(xp_d, xp_o)
+            print(f"[bench plan B={B} {mode}, step s={s}] E={er.numel()} excess over 1e-4: lig {e_l:.2e} pocket "
+                  f"{e_p:.2e}; max |diff| lig {(z_d.cpu() - z_o).abs().max().item():.2e}")
+            worst = max(worst, e_l, e_p)
+        replays, captures, eager = eng.graph_stats()
+        if n_steps >= 3:
+            assert captures >= 1 and replays >= 1, (replays, captures, eager)    # the replayed graph was compared too
+        assert worst <= 0, worst                                       # 1e-4 per timestep
+    finally:
+        model.set_noise_source(None)
+        model._end_chain()
