@@ -58,6 +58,57 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// ---- cross-lane helpers of the wave-private epilogue (gfx950: v_permlane{16,32}_swap, DPP) -----------------
+// Lane exchanges never go through the LDS crossbar (ds_bpermute, what __shfl_xor compiles to): the two swaps move a
+// whole 16- / 32-lane row between two registers in one VALU instruction, the rest are DPP operands.
+__device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {   // lane i <-> 7 - i inside every group of 8
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_ror8(float v) {   // lane i <-> i ^ 8 inside every row of 16
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
+}
+// p: this lane keeps it when its row (16 lanes) is even; q: kept when odd.  Returns own kept value + the partner row's
+// (lane ^ 16) value of the same register.
+__device__ __forceinline__ float pair_sum_rows16(float p, float q) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the same across the two 32-lane halves: half 0 gets p(own) + p(lane + 32), half 1 gets q(lane - 32) + q(own)
+__device__ __forceinline__ float pair_sum_halves(float p, float q) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Sum of 16 per-lane values over the 32 lanes of a half-wave as a reduce-scatter: every step halves the number of
+// registers a lane carries (16 + 8 + 4 + 2 + 1 exchanges instead of 5 x 16 for a butterfly on every register).
+// On return lane j of either half holds the total of register  rs_index(j) = j >> 1.
+__device__ __forceinline__ float reduce16_half_wave(const float (&part)[16], int j) {
+  float k8[8], k4[4], k2[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k8[i] = pair_sum_rows16(part[i], part[i + 8]);          // lanes ^ 16: keep [8 b4, +8)
+  const bool b3 = (j >> 3) & 1, b2 = (j >> 2) & 1, b1 = (j >> 1) & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                                       // lanes ^ 8: keep [.. + 4 b3, +4)
+    const float send = b3 ? k8[i] : k8[i + 4], keep = b3 ? k8[i + 4] : k8[i];
+    k4[i] = keep + dpp_ror8(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                                                       // lane i <-> 7 - i: keep [.. + 2 b2, +2)
+    const float send = b2 ? k4[i] : k4[i + 2], keep = b2 ? k4[i + 2] : k4[i];
+    k2[i] = keep + dpp_half_mirror(send);
+  }
+  const float send = b1 ? k2[0] : k2[1], keep = b1 ? k2[1] : k2[0];                   // lanes ^ 2: keep [.. + b1]
+  const float k1 = keep + dpp_xor2(send);
+  return k1 + dpp_xor1(k1);                                                           // lanes ^ 1: both hold the total
+}
+
 template <int H, int MODE, bool BPERM>
 __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   using L = WaveLayout<H, MODE>;
@@ -241,11 +292,15 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     const bool tile_ends = q == n_pass - 1;
     const int qn = tile_ends ? 0 : q + 1;                  // MLP pass of the next unit
 
+    // the accumulators start from the second layer's bias (one fmaf chain per output starting at b2: the bias add
+    // of the epilogue costs nothing)
     f32x16 acc[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int c = 0; c < CT; ++c) {
+      const float bv = vq[5 * H + feat(c)];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[c][r] = bv;
+    }
 
 #pragma unroll 1
     for (int kt = 0; kt < NK; ++kt) {
@@ -346,13 +401,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     } else
 #endif
     if (MODE == MODE_GCL) {
-      // messages m = SiLU(acc + b2)   (egnn_new.py:18-19)
+      // messages m = SiLU(acc)   (egnn_new.py:18-19; the bias is already in the accumulators)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const float bv = vq[5 * H + feat(c)];
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = silu(acc[c][r] + bv);
-      }
+        for (int r = 0; r < 16; ++r) acc[c][r] = silu(acc[c][r]);
       if (p.attention) {   // att = sigmoid(w_a . m + b_a); a half-wave holds complete rows
         float part[16];
 #pragma unroll
@@ -363,36 +416,44 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) part[r] += acc[c][r] * aw;
         }
+        // reduce-scatter over the half-wave: lane j ends with the dot product of accumulator register j >> 1,
+        // takes ONE sigmoid, and the 16 gates of the half come back through 64 bytes of LDS (broadcast reads)
+        const float gate = sigmoidf_fast(reduce16_half_wave(part, j) + att_b);
+        s_phi[16 * half + (j >> 1)] = gate;
+        wave_lds_fence();
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) part[r] += __shfl_xor(part[r], o);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] = sigmoidf_fast(part[r] + att_b);
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 g4 = *reinterpret_cast<const float4*>(s_phi + 16 * half + 4 * q4);
+          part[4 * q4] = g4.x; part[4 * q4 + 1] = g4.y; part[4 * q4 + 2] = g4.z; part[4 * q4 + 3] = g4.w;
+        }
+        wave_lds_fence();   // the words are rewritten by the next tile
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[c][r] *= part[r];       // mij * att, egnn_new.py:40
       }
-      // segmented sums in edge order; accumulator register rr of half h is row
-      // 8*(rr>>2) + 4*h + (rr&3): rows alternate between the halves in groups of 4
-      // Walk the 32 rows once (row ids are wave-uniform scalars), carrying the CT
-      // column sums of this lane; sub-block gb (rows 4gb..4gb+3) lives in half gb&1.
+      // Segmented sums over the tile's 32 rows.  Accumulator register rr of half h is row 8*(rr>>2) + 4*h + (rr&3):
+      // the rows alternate between the halves in groups of 4.  Every half adds up ITS rows of the running segment in
+      // edge order; when the segment ends (row ids are wave-uniform scalars: a scalar branch) the two halves' partial
+      // sums are added (half 0's + half 1's) and each half stores the column tiles it received -- a fixed order that
+      // depends on the tile's edges only.
+      // aggregation protocol (edge_mlp.h): the first segment of the tile goes to agg_head[tile]
+      // when its row continues from the previous wave tile, every other segment is the start of
+      // its row and goes to agg[row]; plain stores, each address written by exactly one wave
+      static_assert(CT % 2 == 0, "column tiles are exchanged in pairs");
       float sum[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) sum[c] = 0.f;
       int cur = -1;
-      // aggregation protocol (edge_mlp.h): the first segment of the tile goes to agg_head[tile]
-      // when its row continues from the previous wave tile, every other segment is the start of
-      // its row and goes to agg[row]; plain stores, each address written by exactly one wave
       const int row0 = __builtin_amdgcn_readlane(my_r, 0);
       bool to_head = row0 >= 0 && row0 == my_prev;
-      auto flush = [&](int owner) {                        // the owning half holds the full sums
+      auto flush = [&]() {
         if (cur >= 0) {
-          if (half == owner) {
-            float* dst = to_head ? p.agg_head + (size_t)my_wt * H : p.agg + (size_t)cur * H;
+          float* dst = to_head ? p.agg_head + (size_t)my_wt * H : p.agg + (size_t)cur * H;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) dst[feat(c)] = sum[c] * inv_norm;
+          for (int c = 0; c < CT / 2; ++c) {
+            const float tot = pair_sum_halves(sum[c], sum[c + CT / 2]);     // half 0: tile c, half 1: tile c + CT/2
+            dst[feat(c + half * (CT / 2))] = tot * inv_norm;
           }
           to_head = false;
         }
@@ -400,18 +461,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
       for (int gb = 0; gb < 8; ++gb) {
         const int hh = gb & 1;
-        if (gb > 0) {                                      // baton: running sums move to the owning half
-#pragma unroll
-          for (int c = 0; c < CT; ++c) {
-            const float other = __shfl_xor(sum[c], 32);
-            if (half == hh) sum[c] = other;
-          }
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int rn = __builtin_amdgcn_readlane(my_r, 4 * gb + i);
           if (rn != cur) {                                 // scalar compare / branch
-            flush(hh);
+            flush();
             cur = rn;
 #pragma unroll
             for (int c = 0; c < CT; ++c) sum[c] = 0.f;
@@ -422,26 +476,20 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           }
         }
       }
-      flush(1);
+      flush();
     } else {
-      // scalar head: phi = w3 . SiLU(acc + b2)   (egnn_new.py:80-92)
+      // scalar head: phi = w3 . SiLU(acc)   (egnn_new.py:80-92; the bias is already in the accumulators)
       float part[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const float bv = vq[5 * H + feat(c)], wv = vq[6 * H + feat(c)];
+        const float wv = vq[6 * H + feat(c)];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] += silu(acc[c][r] + bv) * wv;
+        for (int r = 0; r < 16; ++r) part[r] += silu(acc[c][r]) * wv;
       }
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] += __shfl_xor(part[r], o);
-      if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_phi[mfma_row(r, lane)] = part[r];
-      }
+      // lane j of a half ends with the total of accumulator register j >> 1 = edge mfma_row(j >> 1, lane)
+      s_phi[mfma_row(j >> 1, lane)] = reduce16_half_wave(part, j);
       wave_lds_fence();
       const float ph = s_phi[j];                            // this lane's edge
       wave_lds_fence();

@@ -1,0 +1,239 @@
+// Standalone timing harness for the hot kernels (no torch: a run costs seconds on the GPU box).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DVARIANT flags] tools/microbench.hip -o tools/bin/mb_<tag>
+//   tools/bin/mb_<tag> [B] [reps]
+//
+// Builds a synthetic batch with the geometry of the benchmark workload (B samples x (23 ligand + 286 pocket)
+// nodes, 5 A radius graph on uniformly random points at the density of a protein pocket, ligand-ligand complete,
+// (sample, node set) segments 32-aligned with inactive padding entries, rows sorted) and times
+//   * edge_wave_kernel<256, MODE_GCL>   on the whole list, on the ligand-endpoint prefix and on a 28 % prefix
+//   * edge_wave_kernel<256, MODE_COORD> on the ligand-row prefix (two MLPs, one workgroup per (tile, MLP))
+//   * the node GEMMs of one block (layer 1, layer 2, grouped projections) at 19.8 k / 11.5 k / 3.6 k rows
+// with HIP events over `reps` back-to-back launches, and prints a checksum of every output so that variants of a
+// kernel (compile-time flags) can be compared for equality.  Test / measurement infrastructure, not product code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../diffsbdd_amd/csrc/common.h"
+#include "../diffsbdd_amd/csrc/edge_mlp.h"
+#include "../diffsbdd_amd/csrc/edge_wave.h"
+#include "../diffsbdd_amd/csrc/graph.h"
+#include "../diffsbdd_amd/csrc/node_linear.h"
+
+using namespace dsbdd;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <class T>
+static T* dev(const std::vector<T>& v) {
+  T* p = nullptr;
+  CK(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+template <class T>
+static T* dev_zero(size_t n) {
+  T* p = nullptr;
+  CK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+  CK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  return p;
+}
+static double checksum(const float* d, size_t n) {
+  std::vector<float> h(n);
+  CK(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+  double s = 0.0;
+  for (size_t i = 0; i < n; ++i) s += (double)h[i] * (double)((i % 977) + 1);
+  return s;
+}
+static std::vector<float> rnd(std::mt19937& g, size_t n, float scale) {
+  std::uniform_real_distribution<float> u(-scale, scale);
+  std::vector<float> v(n);
+  for (auto& x : v) x = u(g);
+  return v;
+}
+
+template <class F>
+static float time_us(F&& launch, int reps) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(b, 0));
+  CK(hipEventSynchronize(b));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipGetLastError());
+  return ms * 1e3f / reps;
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 64;
+  const int reps = argc > 2 ? atoi(argv[2]) : 20;
+  constexpr int H = 256;
+  const int nl = 23, np = 286;
+  const int n_lig = B * nl, n_poc = B * np, N = n_lig + n_poc;
+  std::mt19937 g(1234);
+
+  // ---- geometry: ligand in the middle of a box of pocket atoms -------------------------------------------
+  std::vector<float> x(3 * (size_t)N);
+  std::uniform_real_distribution<float> box(0.f, 17.5f), mid(6.5f, 11.0f);
+  for (int b = 0; b < B; ++b) {
+    for (int i = 0; i < nl; ++i) for (int k = 0; k < 3; ++k) x[3 * (size_t)(b * nl + i) + k] = mid(g) + 40.f * b;
+    for (int i = 0; i < np; ++i) for (int k = 0; k < 3; ++k) x[3 * (size_t)(n_lig + b * np + i) + k] = box(g) + 40.f * b;
+  }
+  auto d2 = [&](int i, int j) {
+    float s = 0.f;
+    for (int k = 0; k < 3; ++k) { const float d = x[3 * (size_t)i + k] - x[3 * (size_t)j + k]; s += d * d; }
+    return s;
+  };
+  std::vector<int> erow, ecol, node_batch(N);
+  std::vector<float> ed0;
+  std::vector<int> row_ptr(N + 1, 0), deg(N, 0);
+  auto pad = [&]() { while (erow.size() % 32) { erow.push_back(-1); ecol.push_back(0); ed0.push_back(0.f); } };
+  auto add_rows = [&](int first, int count, int b, bool lig_rows) {
+    for (int i = first; i < first + count; ++i) {
+      node_batch[i] = b;
+      row_ptr[i] = (int)erow.size();
+      for (int j = b * nl; j < (b + 1) * nl; ++j)
+        if (lig_rows || d2(i, j) <= 25.f) { erow.push_back(i); ecol.push_back(j); ed0.push_back(d2(i, j)); }
+      for (int j = n_lig + b * np; j < n_lig + (b + 1) * np; ++j)
+        if (d2(i, j) <= 25.f) { erow.push_back(i); ecol.push_back(j); ed0.push_back(d2(i, j)); }
+      deg[i] = (int)erow.size() - row_ptr[i];
+    }
+    pad();
+  };
+  for (int b = 0; b < B; ++b) add_rows(b * nl, nl, b, true);
+  const int E_lig = (int)erow.size();                    // ligand-row prefix (update_coords_mask)
+  for (int b = 0; b < B; ++b) add_rows(n_lig + b * np, np, b, false);
+  const int E = (int)erow.size();
+  row_ptr[N] = E;
+  long real = 0;
+  for (int r : erow) real += r >= 0;
+  printf("# B=%d N=%d E=%d slots (%ld edges, %.1f per node), ligand-row prefix %d slots, tiles(128)=%d\n", B, N, E, real,
+         (double)real / N, E_lig, (E + 127) / 128);
+
+  int *d_erow = dev(erow), *d_ecol = dev(ecol), *d_nb = dev(node_batch);
+  float* d_ed0 = dev(ed0);
+  float* d_x = dev(x);
+  std::vector<int> counts = {E, E_lig, (int)(0.28 * E) / 32 * 32, (int)(0.69 * E) / 32 * 32};
+  int* d_counts = dev(counts);
+  int* d_tile_ctr = dev_zero<int>(kTileCtrInts);
+  int* d_rowptr = dev(row_ptr);
+  int* d_deg = dev(deg);
+
+  // ---- weights / projections ------------------------------------------------------------------------------
+  const float ws = 1.f / 16.f;
+  float* d_pq = dev(rnd(g, (size_t)N * 4 * H, 1.0f));     // up to 4H columns (coordinate stage layout)
+  auto mk = [&](size_t n, float s) { return dev(rnd(g, n, s)); };
+  struct Mlp { float *wd, *wd0, *tab, *w2t, *b2, *w2tp; } m[2];
+  for (int q = 0; q < 2; ++q) {
+    m[q] = {mk(H, 0.05f), mk(H, 0.05f), mk(3 * H, 0.3f), mk((size_t)H * H, ws), mk(H, 0.1f), dev_zero<float>((size_t)H * H)};
+    hipLaunchKernelGGL(permute_w2t_kernel, dim3((H * H + 255) / 256), dim3(256), 0, 0, (const float*)m[q].w2t, m[q].w2tp, H);
+  }
+  float *d_attw = mk(H, ws), *d_attb = mk(1, 0.1f), *d_w3 = mk(H, ws);
+  float* d_agg = dev_zero<float>((size_t)N * H);
+  float* d_head = dev_zero<float>((size_t)(E / 32 + 2) * H);
+  float* d_xagg = dev_zero<float>((size_t)2 * N * 3);
+  float* d_xhead = dev_zero<float>((size_t)2 * (E / 32 + 2) * 4);
+  float* d_mean = dev(std::vector<float>(3 * (size_t)B, 8.75f));
+  CK(hipDeviceSynchronize());
+
+  auto edge_args = [&](int mode, int count_idx) {
+    EdgeArgs a{};
+    a.erow = d_erow; a.ecol = d_ecol; a.ed0 = d_ed0; a.e_count = d_counts + count_idx; a.e_cap = E;
+    a.x = d_x; a.n_lig = n_lig; a.tile_ctr = d_tile_ctr; a.norm_factor = 100.f; a.wt_base = 0;
+    if (mode == MODE_GCL) {
+      a.ldpq = 2 * H;
+      a.mlp[0] = EdgeMlpW{d_pq, d_pq + H, m[0].wd, m[0].wd0, m[0].tab, m[0].w2t, m[0].b2, m[0].w2tp};
+      a.mlp[1] = a.mlp[0];
+      a.att_w = d_attw; a.att_b = d_attb; a.attention = 1; a.agg = d_agg; a.agg_head = d_head;
+    } else {
+      a.ldpq = 4 * H;
+      a.mlp[0] = EdgeMlpW{d_pq + 2 * H, d_pq, m[0].wd, m[0].wd0, m[0].tab, m[0].w2t, m[0].b2, m[0].w2tp};
+      a.mlp[1] = EdgeMlpW{d_pq + 3 * H, d_pq + H, m[1].wd, m[1].wd0, m[1].tab, m[1].w2t, m[1].b2, m[1].w2tp};
+      a.w3 = d_w3; a.node_batch = d_nb; a.mean = d_mean; a.norm_constant = 1.f; a.coords_range = 15.f;
+      a.use_tanh = 1; a.n_mlp = 2; a.xagg = d_xagg; a.xagg_head = d_xhead; a.xagg_stride = (size_t)N * 3;
+      a.xhead_stride = (size_t)(E / 32 + 2) * 4; a.pass_split = 1;
+    }
+    return a;
+  };
+  int n_cu = 256;
+  { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) n_cu = p.multiProcessorCount; }
+  auto grid_of = [&](int mode, int edges) {
+    long tiles = (edges + 127) / 128, gmax = 2L * n_cu;
+    long gg = mode == MODE_COORD ? 2 * tiles : tiles;
+    if (gg > gmax) gg = gmax;
+    const int q8 = mode == MODE_COORD ? 16 : 8;
+    return (int)std::max<long>((gg + q8 - 1) / q8 * q8, q8);
+  };
+  printf("| kernel | edges / rows | us / launch | TFLOP/s | frac of 157.3 | checksum |\n|---|---|---|---|---|---|\n");
+#ifndef MB_SKIP_EDGE
+  const char* names[4] = {"GCL whole list", "GCL ligand-row prefix", "GCL 28 % prefix", "GCL 69 % prefix"};
+  for (int ci : {0, 3, 2, 1}) {
+    EdgeArgs a = edge_args(MODE_GCL, ci);
+    const int grid = grid_of(MODE_GCL, counts[ci]);
+    CK(hipMemset(d_agg, 0, (size_t)N * H * 4)); CK(hipMemset(d_head, 0, (size_t)(E / 32 + 2) * H * 4));
+    const float us = time_us([&] { hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, true>), dim3(grid), dim3(kThreads), 0, 0, a); }, reps);
+    const double fl = 2.0 * counts[ci] * ((double)H * H + 4.0 * H);
+    printf("| %s (grid %d) | %d | %.1f | %.1f | %.3f | %.6e |\n", names[ci], grid, counts[ci], us, fl / us / 1e6, fl / us / 1e6 / 157.3,
+           checksum(d_agg, (size_t)N * H) + checksum(d_head, (size_t)(counts[ci] / 32) * H));
+  }
+  {
+    EdgeArgs a = edge_args(MODE_COORD, 1);
+    const int grid = grid_of(MODE_COORD, E_lig);
+    const float us = time_us([&] { hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, true>), dim3(grid), dim3(kThreads), 0, 0, a); }, reps);
+    const double fl = 2.0 * 2.0 * E_lig * ((double)H * H + 3.0 * H);
+    printf("| COORD ligand-row prefix, 2 MLPs (grid %d) | %d | %.1f | %.1f | %.3f | %.6e |\n", grid, E_lig, us, fl / us / 1e6,
+           fl / us / 1e6 / 157.3, checksum(d_xagg, (size_t)2 * N * 3) + checksum(d_xhead, (size_t)2 * (E / 32 + 2) * 4));
+  }
+#endif
+#ifndef MB_SKIP_NODE
+  // ---- node GEMMs of one block ----------------------------------------------------------------------------
+  float* d_h = dev(rnd(g, (size_t)N * H, 1.0f));
+  float* d_aggc = dev(rnd(g, (size_t)N * H, 1.0f));
+  float* d_t1 = dev_zero<float>((size_t)N * H);
+  float* d_hn = dev_zero<float>((size_t)N * H);
+  float* d_pqg = dev_zero<float>((size_t)N * 2 * H);
+  float* d_pqc = dev_zero<float>((size_t)N * 4 * H);
+  float *W1 = mk((size_t)2 * H * H, ws), *b1 = mk(H, 0.1f), *W2 = mk((size_t)H * H, ws), *b2n = mk(H, 0.1f);
+  float *Wpq = mk((size_t)H * 2 * H, ws), *Wc = mk((size_t)H * 4 * H, ws);
+  std::vector<int> perm(N);
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  std::shuffle(perm.begin() + n_lig, perm.end(), g);      // gathered row lists: ligand rows first, then pocket rows in level order
+  int* d_rows = dev(perm);
+  std::vector<int> mcounts = {N, 11545, 3639, n_lig};
+  int* d_mcounts = dev(mcounts);
+  for (int mi = 0; mi < 3; ++mi) {
+    const int M = mcounts[mi];
+    const int* ridx = mi == 0 ? nullptr : d_rows;
+    const int* mc = mi == 0 ? nullptr : d_mcounts + mi;
+    NodeLinearArgs n1{d_h, H, H, d_aggc, H, H, W1, H, b1, nullptr, 0, d_t1, H, N, H, 1, ridx, mc};
+    NodeLinearArgs n2{d_t1, H, H, nullptr, 0, 0, W2, H, b2n, d_hn, H, d_hn, H, N, H, 0, ridx, mc};
+    NodeLinearArgs grp[3] = {
+        {d_hn, H, H, nullptr, 0, 0, Wc, 4 * H, nullptr, nullptr, 0, d_pqc, 4 * H, N, 2 * H, 0, d_rows, d_mcounts + 2},
+        {d_hn, H, H, nullptr, 0, 0, Wc + 2 * H, 4 * H, nullptr, nullptr, 0, d_pqc + 2 * H, 4 * H, n_lig, 2 * H, 0, nullptr, nullptr},
+        {d_hn, H, H, nullptr, 0, 0, Wpq, 2 * H, nullptr, nullptr, 0, d_pqg, 2 * H, N, 2 * H, 0, ridx, mc}};
+    CK(hipMemset(d_hn, 0, (size_t)N * H * 4));
+    const float u1 = time_us([&] { (void)launch_node_linear(0, n1); }, reps);
+    const float u2 = time_us([&] { (void)launch_node_linear(0, n2); }, reps);
+    const float u3 = time_us([&] { (void)launch_node_group(0, grp, 3); }, reps);
+    const double f1 = 2.0 * M * 2.0 * H * H, f2 = 2.0 * M * (double)H * H,
+                 f3 = 2.0 * ((double)M * H * 2 * H + 3639.0 * H * 2 * H + (double)n_lig * H * 2 * H);
+    printf("| node MLP layer 1 (K=512,N=256) | %d | %.1f | %.1f | %.3f | %.6e |\n", M, u1, f1 / u1 / 1e6, f1 / u1 / 1e6 / 157.3, checksum(d_t1, (size_t)N * H));
+    printf("| node MLP layer 2 (K=256,N=256,+res) | %d | %.1f | %.1f | %.3f | - |\n", M, u2, f2 / u2 / 1e6, f2 / u2 / 1e6 / 157.3);
+    printf("| grouped projections (Qc|Qx act, Pc|Px lig, next P|Q) | %d | %.1f | %.1f | %.3f | %.6e |\n", M, u3, f3 / u3 / 1e6, f3 / u3 / 1e6 / 157.3,
+           checksum(d_pqg, (size_t)N * 2 * H) + checksum(d_pqc, (size_t)N * 4 * H));
+    printf("| = node phase of one block | %d | %.1f | %.1f | %.3f | |\n", M, u1 + u2 + u3, (f1 + f2 + f3) / (u1 + u2 + u3) / 1e6,
+           (f1 + f2 + f3) / (u1 + u2 + u3) / 1e6 / 157.3);
+  }
+#endif
+  return 0;
+}
