@@ -65,6 +65,8 @@ struct EdgeArgs {
                           // the radius graph overflowed (status bit 1 is then set by edges_kernel)
   const float* x;         // [N][3] current coordinates
   int n_lig;              // nodes < n_lig are ligand nodes (edge types, dynamics.py:119-124)
+  int n_nodes;            // rows of P / Q / x / agg (ghost rows included): list entries outside [0, n_nodes) are treated
+                          // as inactive -- after an edge-capacity overflow parts of a list were never written
   int ldpq;
   EdgeMlpW mlp[2];
   // MODE_GCL
@@ -96,11 +98,12 @@ enum { MODE_GCL = 0, MODE_COORD = 1 };
 // at degree ~17) are left untouched.  Costs what the zero fill of the atomic version cost.
 __global__ __launch_bounds__(kThreads) void agg_complete_kernel(float* agg, const float* agg_head,
                                                                 const int* row_ptr, const int* deg,
-                                                                int n_rows, int H) {
+                                                                int n_rows, int H, int max_tile) {
   const int row = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= n_rows) return;
   const int d = deg[row], s = row_ptr[row];
-  const int t0 = s >> 5, t1 = (s + d - 1) >> 5;
+  // (max_tile: last slot of agg_head -- after an edge-capacity overflow row_ptr describes edges that were never stored)
+  const int t0 = s >> 5, t1 = min((s + d - 1) >> 5, max_tile);
   if (d > 0 && t1 == t0) return;
   for (int k = 4 * lane; k < H; k += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -126,18 +129,18 @@ __global__ __launch_bounds__(kThreads) void agg_complete_kernel(float* agg, cons
 __global__ __launch_bounds__(kThreads) void agg_complete2_kernel(
     float* agg, const float* head_a, const int* row_ptr_a, const int* deg_a, const float* agg_b,
     const float* head_b, const int* row_ptr_b, const int* deg_b, const int* twin_local, int twin_base,
-    int n_lig, int n_rows, int H, int n_ghost) {
+    int n_lig, int n_rows, int H, int n_ghost, int max_tile) {
   const int row = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= n_rows + n_ghost) return;
   const bool ghost = row >= n_rows;        // rows of the canonical pocket: the B part of pocket atom row - n_rows only
   const int da = ghost ? 0 : deg_a[row], sa = ghost ? 0 : row_ptr_a[row];
-  const int a0 = sa >> 5, a1 = (sa + da - 1) >> 5;
+  const int a0 = sa >> 5, a1 = min((sa + da - 1) >> 5, max_tile);
   int db = 0, sb = 0, tw = 0;
   if (row >= n_lig) {
     const int tl = ghost ? row - n_rows : twin_local[row - n_lig];
     db = deg_b[tl]; sb = row_ptr_b[tl]; tw = twin_base + tl;
   }
-  const int b0 = sb >> 5, b1 = (sb + db - 1) >> 5;
+  const int b0 = sb >> 5, b1 = min((sb + db - 1) >> 5, max_tile);
   for (int k = 4 * lane; k < H; k += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (da > 0) {

@@ -232,7 +232,10 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   auto fetch_idx = [&](int tile) {
     const int e0 = tile * BMB + w * BMW, e = e0 + j;
     nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = p.wt_base + tile * 4 + w;
-    if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
+    if (e < E) {
+      nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e];
+      if ((unsigned)nx_r >= (unsigned)p.n_nodes || (unsigned)nx_c >= (unsigned)p.n_nodes) { nx_r = -1; nx_c = 0; }
+    }
     if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1];
   };
   auto fetch_x = [&]() {

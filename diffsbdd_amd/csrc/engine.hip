@@ -16,6 +16,7 @@
 #include "edge_wave.h"
 #include "graph.h"
 #include "molecule.h"
+#include "node_chain.h"
 #include "node_linear.h"
 
 using namespace dsbdd;
@@ -74,6 +75,11 @@ struct dsbdd_engine {
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   bool w2tp_ready = false;   // lane-grouped W2^T copies in the workspace are current
+  // row-owning node-phase kernel (node_chain.h): lane-major packed copies of the node-level weights in the workspace
+  float* wchain = nullptr;
+  bool wchain_ready = false;
+  int chain = 1;             // DSBDD_NODE_CHAIN=0: the three-launch node phase (node_linear.h) everywhere
+  int64_t chain_min_rows = 0;      // (test hook; the choice of kernel must not depend on the batch size: bitwise batch invariance)
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
   int profile = 0;        // 0 off, k: the GCL launches of every k-th forward call are timed with HIP events
@@ -131,7 +137,7 @@ static int eq_slot(const dsbdd_config& c, int block, int which) {
 }
 
 struct WsLayout {
-  size_t off[64];
+  size_t off[72];
   size_t total;
 };
 
@@ -164,7 +170,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * 4, (size_t)kLevels * B * 4, (size_t)kLevels * B * 4,                              // 50 lvl 51 seg_rows 52 seg_edges
       (size_t)(kLevels * B + 1) * 4, (size_t)(kLevels * B + 1) * 4, 64, 64,                         // 53 node_base 54 edge_base 55 lvl_cnt 56 lvl_end
       (size_t)NG * 4, (size_t)(NG + 1) * 4, (size_t)EL * 4, (size_t)EL * 4, (size_t)EL * 4,         // 57 lvl_list 58 row_ptrL 59-61 erowL ecolL ed0L
-      128, (size_t)N * 4};                                                                          // 62 lvl_stats 63 frame_rows
+      128, (size_t)N * 4,                                                                           // 62 lvl_stats 63 frame_rows
+      (size_t)c.n_layers * ((size_t)c.inv_sublayers * 5 * H * H + (size_t)H * PQ) * 4 + 4096};      // 64 packed node-phase weights
   WsLayout L;
   size_t o = 0;
   const int n = sizeof(sizes) / sizeof(sizes[0]);
@@ -213,6 +220,10 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (prn && atoi(prn) == 0) e->prune = 0;
   const char* cn = getenv("DSBDD_CONE");
   if (cn && atoi(cn) == 0) e->cone = 0;
+  const char* nch = getenv("DSBDD_NODE_CHAIN");
+  if (nch && atoi(nch) == 0) e->chain = 0;
+  const char* ncm = getenv("DSBDD_NODE_CHAIN_MIN_ROWS");
+  if (ncm && atoi(ncm) >= 0) e->chain_min_rows = atoi(ncm);
   const char* mwg = getenv("DSBDD_EDGE_MAX_WG");
   if (mwg && atoi(mwg) > 0) e->edge_max_wg = atoi(mwg);
   *out = e;
@@ -249,6 +260,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
   }
   e->drop_graphs();
   e->w2tp_ready = false;
+  e->wchain_ready = false;
   e->has_weights = true;
   return DSBDD_OK;
 }
@@ -301,6 +313,8 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->twin = (int*)(b + L.off[46]);
   e->xframe = (float*)(b + L.off[47]); e->aggB = (float*)(b + L.off[48]); e->agg_headB = (float*)(b + L.off[49]);
   e->frame_rows = (int*)(b + L.off[63]);
+  e->wchain = (float*)(b + L.off[64]);
+  e->wchain_ready = false;
   e->frame = false;               // a pocket frame lives in the workspace
   e->ghost_dirty = true;
   e->w2tp_ready = false;
@@ -760,6 +774,31 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       }
     e->w2tp_ready = true;
   }
+  // packed weights of the row-owning node-phase kernel: per (block, sublayer) node MLP layer 1 [2H -> H], layer 2
+  // [H -> H] and the message stage's first-layer projection [H -> 2H]; per block the coordinate projections [H -> PQ]
+  const bool use_chain = e->chain && (H == 256 || H == 128) && N >= e->chain_min_rows;
+  const size_t chain_blk = (size_t)c.inv_sublayers * 5 * H * H + (size_t)H * PQ;
+  auto chain_w = [&](int blk, int sub, int which) -> const float* {   // which: 0 N1, 1 N2, 2 E1 (P|Q), 3 coordinate (sub ignored)
+    const float* base = e->wchain + (size_t)blk * chain_blk;
+    if (which == 3) return base + (size_t)c.inv_sublayers * 5 * H * H;
+    return base + (size_t)sub * 5 * H * H + (which == 0 ? 0 : (which == 1 ? 2 * H * H : 3 * H * H));
+  };
+  if (use_chain && !e->wchain_ready) {
+    auto pack = [&](const float* WT, int ldw, int K, int Ncols, const float* dst) {
+      hipLaunchKernelGGL(pack_b16_kernel, dim3((K * Ncols + 255) / 256), dim3(256), 0, s, WT, ldw, K, Ncols,
+                         const_cast<float*>(dst));
+    };
+    for (int blk = 0; blk < c.n_layers; ++blk) {
+      for (int sub = 0; sub < c.inv_sublayers; ++sub) {
+        pack(W[gcl_slot(c, blk, sub, DSBDD_GCL_N1_WT)], H, 2 * H, H, chain_w(blk, sub, 0));
+        pack(W[gcl_slot(c, blk, sub, DSBDD_GCL_N2_WT)], H, H, H, chain_w(blk, sub, 1));
+        pack(W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, H, 2 * H, chain_w(blk, sub, 2));
+      }
+      pack(W[eq_slot(c, blk, DSBDD_EQ_C1_WT)], PQ, H, PQ, chain_w(blk, 0, 3));
+    }
+    HIP_TRY(hipGetLastError());
+    e->wchain_ready = true;
+  }
   auto gcl_pq = [&](int blk, int sub) {
     NodeLinearArgs a{e->h, H, H, nullptr, 0, 0, W[gcl_slot(c, blk, sub, DSBDD_GCL_E1_WT)], 2 * H, nullptr,
                      nullptr, 0, e->pqg, 2 * H, (int)N, 2 * H, 0, nullptr, nullptr};
@@ -767,7 +806,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     rows_of(radius_of(g) + 1, g <= g_ghost_last && g > 0, a);    // the stage reads its neighbours one level out
     return a;
   };
-  bool pqg_ready = false;
+  bool pqg_ready = false, chained_pq = false, chained_coord = false;
   for (int blk = 0; blk < c.n_layers; ++blk) {
     if (n_mlp == 2 && (blk == 0 || !subset)) {   // coord2cross needs the per-sample mean of the block's input x
                                                  // (pocket-conditioning mode, later blocks: computed by the
@@ -780,6 +819,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       auto G = [&](int which) { return W[gcl_slot(c, blk, sub, which)]; };
       // P | Q projections of the edge MLP's first layer (those of a block's first sublayer
       // were launched together with the previous block's coordinate projections)
+      if (sub > 0 && chained_pq) pqg_ready = true;           // produced by the previous sublayer's node-phase launch
       if (!pqg_ready) {
         const bool rows0 = split0 && blk == 0 && sub == 0;
         NodeLinearArgs grp0[2];
@@ -809,7 +849,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.erow = L_row + begin; ea.ecol = L_col + begin; ea.ed0 = L_d0 + begin;
       ea.e_count = !prune ? e_all : (ghost ? e->lvl_end + radius : e->lvl_end + kLevels + radius);
       ea.e_cap = L_cap - (int)begin; ea.wt_base = (int)(begin / 32); ea.x = e->x;
-      ea.n_lig = nlig; ea.ldpq = 2 * H;
+      ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
@@ -832,7 +872,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + n_ghost + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
                            (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,
-                           (const int*)e->deg3, (const int*)e->twin, N, nlig, N, H, cone ? n_ghost : 0);
+                           (const int*)e->deg3, (const int*)e->twin, N, nlig, N, H, cone ? n_ghost : 0, (int)e->cap_tiles - 1);
         HIP_TRY(hipGetLastError());
       } else {
         // (timed: the launches over the whole list only, so that every timed launch is the same work)
@@ -846,7 +886,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
         const int n_rows = N + (ghost ? n_ghost : 0);
         hipLaunchKernelGGL(agg_complete_kernel, dim3((n_rows + 3) / 4), dim3(kThreads), 0, s, e->agg,
-                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, n_rows, H);
+                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, n_rows, H, (int)e->cap_tiles - 1);
         HIP_TRY(hipGetLastError());
       }
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
@@ -855,14 +895,59 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       NodeLinearArgs n2{e->t1, H, H, nullptr, 0, 0, G(DSBDD_GCL_N2_WT), H, G(DSBDD_GCL_N2_B), e->h, H, e->h, H,
                         (int)N, H, 0, nullptr, nullptr};
       rows_of(radius, ghost, n1); rows_of(radius, ghost, n2);
-      HIP_TRY(launch_node_linear(s, n1));
-      HIP_TRY(launch_node_linear(s, n2));
+      chained_pq = false; chained_coord = false;
+      bool fill_pq = false;
+      if (use_chain) {
+        // one launch: the node MLP and every projection of the new h whose rows are a contiguous part of the MLP's
+        // row list (node_chain.h) -- the coordinate projections (after the block's last sublayer), the next message
+        // stage's P|Q when it reads exactly the rows this stage computes
+        NodeChainArgs ca{};
+        ca.row_idx = n1.row_idx; ca.m_count = n1.m_count; ca.M = n1.M; ca.do_mlp = 1;
+        ca.h = e->h; ca.agg = e->agg;
+        ca.W1p = chain_w(blk, sub, 0); ca.b1 = G(DSBDD_GCL_N1_B);
+        ca.W2p = chain_w(blk, sub, 1); ca.b2 = G(DSBDD_GCL_N2_B);
+        const bool last_sub = sub + 1 == c.inv_sublayers;
+        const int first = ghost ? n_ghost : 0;               // the ghost rows lead the list of a ghost stage
+        if (last_sub) {
+          const int QW = n_mlp * H;
+          const float* wc = chain_w(blk, 0, 3);
+          if (!subset) {
+            ca.proj[ca.n_proj++] = ChainProj{wc, e->pq, PQ, PQ, nullptr, 0};
+            chained_coord = true;
+          } else if (prune && n1.row_idx) {                  // active / ligand rows = prefixes of the level list
+            ca.proj[ca.n_proj++] = ChainProj{wc, e->pq, PQ, QW, act_count, first};
+            ca.proj[ca.n_proj++] = ChainProj{wc + (size_t)(QW / 16) * (H / 16) * 256, e->pq + QW, PQ, QW,
+                                             e->lvl_cnt + kLevels, first};
+            chained_coord = true;
+          }
+        }
+        const bool has_next = !last_sub || blk + 1 < c.n_layers;
+        if (has_next) {
+          const int nb = last_sub ? blk + 1 : blk, ns = last_sub ? 0 : sub + 1;
+          const NodeLinearArgs nx = gcl_pq(nb, ns);
+          // the next stage's P|Q rides along when it reads exactly the rows this stage computes -- or, in a ghost stage,
+          // those plus rows that are about to take the canonical values: the ghost rows' P|Q is computed here and
+          // copied together with their h (canon_fill_kernel)
+          const bool same_rows = nx.row_idx == n1.row_idx && nx.m_count == n1.m_count && nx.M == n1.M;
+          if (same_rows || ghost) {
+            ca.proj[ca.n_proj++] = ChainProj{chain_w(nb, ns, 2), e->pqg, 2 * H, 2 * H, nullptr, 0};
+            chained_pq = true;
+            fill_pq = ghost && !same_rows;
+          }
+        }
+        HIP_TRY(launch_node_chain(s, ca, H, e->n_cu));
+      } else {
+        HIP_TRY(launch_node_linear(s, n1));
+        HIP_TRY(launch_node_linear(s, n2));
+      }
       if (ghost) {
-        // the rows the next stage reads but this one did not compute: canonical values
+        // the rows the next stage reads but this one did not compute: canonical values (and their P|Q, see above)
         const int hi = radius_of(g + 1) + 1 < LV ? radius_of(g + 1) + 1 : LV;
         if (hi > radius) {
           hipLaunchKernelGGL(canon_fill_kernel, dim3((N - nlig + 3) / 4), dim3(kThreads), 0, s, e->h,
-                             (const int*)e->lvl, (const int*)e->twin, nlig, N, N, radius, hi, H);
+                             (const int*)e->lvl, (const int*)e->twin, nlig, N, N, radius, hi, H,
+                             fill_pq ? e->pqg : (float*)nullptr, 2 * H);
+          fill_pq = false;
           HIP_TRY(hipGetLastError());
         }
       }
@@ -874,27 +959,46 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       const int QW = n_mlp * H;   // width of the Q (column-node) part
       NodeLinearArgs grp[kMaxGroup];
       int ng = 0;
-      if (subset) {
-        grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
-                                   (int)N, QW, 0, act_rows, act_count};
-        grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT) + QW, PQ, nullptr, nullptr, 0,
-                                   e->pq + QW, PQ, (int)n_lig, QW, 0, nullptr, nullptr};
-      } else {
-        grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
-                                   (int)N, PQ, 0, nullptr, nullptr};
+      if (!chained_coord) {
+        if (subset) {
+          grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
+                                     (int)N, QW, 0, act_rows, act_count};
+          grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT) + QW, PQ, nullptr, nullptr, 0,
+                                     e->pq + QW, PQ, (int)n_lig, QW, 0, nullptr, nullptr};
+        } else {
+          grp[ng++] = NodeLinearArgs{e->h, H, H, nullptr, 0, 0, Q(DSBDD_EQ_C1_WT), PQ, nullptr, nullptr, 0, e->pq, PQ,
+                                     (int)N, PQ, 0, nullptr, nullptr};
+        }
       }
-      if (blk + 1 < c.n_layers) grp[ng++] = gcl_pq(blk + 1, 0);
-      if (e->node_group && launch_node_group(s, grp, ng) == hipSuccess) {
-        pqg_ready = blk + 1 < c.n_layers;
-      } else {
-        (void)hipGetLastError();
-        const int nc = ng - (blk + 1 < c.n_layers ? 1 : 0);   // the coordinate projections only
-        for (int i = 0; i < nc; ++i) HIP_TRY(launch_node_linear(s, grp[i]));
+      const int n_coord = ng;
+      const bool want_next = blk + 1 < c.n_layers && !chained_pq;
+      if (chained_pq && blk + 1 < c.n_layers) pqg_ready = true;
+      if (want_next && use_chain) {
+        // the next stage reads more rows than this one computed (ascending radii of the forward cone: the rest were
+        // filled with canonical values above): its P|Q as a launch of its own, rows streamed from global memory
+        const NodeLinearArgs nx = gcl_pq(blk + 1, 0);
+        NodeChainArgs ca{};
+        ca.row_idx = nx.row_idx; ca.m_count = nx.m_count; ca.M = nx.M; ca.do_mlp = 0; ca.h = e->h;
+        ca.n_proj = 1;
+        ca.proj[0] = ChainProj{chain_w(blk + 1, 0, 2), e->pqg, 2 * H, 2 * H, nullptr, 0};
+        HIP_TRY(launch_node_chain(s, ca, H, e->n_cu));
+        pqg_ready = true;
+      } else if (want_next) {
+        grp[ng++] = gcl_pq(blk + 1, 0);
       }
+      if (ng > 0) {
+        if (e->node_group && launch_node_group(s, grp, ng) == hipSuccess) {
+          if (ng > n_coord) pqg_ready = true;
+        } else {
+          (void)hipGetLastError();
+          for (int i = 0; i < n_coord; ++i) HIP_TRY(launch_node_linear(s, grp[i]));   // the coordinate projections only
+        }
+      }
+      chained_pq = false;
       EdgeArgs ea{};
       ea.erow = L_row + ghost_slots; ea.ecol = L_col + ghost_slots; ea.ed0 = L_d0 + ghost_slots; ea.e_count = e_upd;
       ea.e_cap = L_cap - (int)ghost_slots; ea.wt_base = (int)(ghost_slots / 32); ea.x = e->x;
-      ea.n_lig = nlig; ea.ldpq = PQ;
+      ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
                            Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers)};
       if (n_mlp == 2)
@@ -920,14 +1024,14 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
           if (n_upd > 0) {
             hipLaunchKernelGGL(coord_update_kernel, dim3((3 * n_upd + 255) / 256), dim3(256), 0, s, e->x,
                                (const float*)e->xagg, (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride,
-                               L_ptr, (const int*)e->deg, 3 * n_upd);
+                               L_ptr, (const int*)e->deg, 3 * n_upd, (int)e->cap_tiles - 1);
             HIP_TRY(hipGetLastError());
           }
         } else if (n_upd > 0 || next_mean) {
           hipLaunchKernelGGL(coord_update_mean_kernel, dim3(B), dim3(kThreads), 0, s, e->x, (const float*)e->xagg,
                              (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride, L_ptr,
                              (const int*)e->deg, n_upd, (const int*)e->lig_off, (const int*)e->poc_off, nlig,
-                             next_mean ? e->mean : (float*)nullptr);
+                             next_mean ? e->mean : (float*)nullptr, (int)e->cap_tiles - 1);
           HIP_TRY(hipGetLastError());
         }
       }

@@ -468,14 +468,20 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(float* dst, const
 // ligand could not have influenced yet -- their value is the canonical pocket's (engine.hip, forward cone).
 __global__ __launch_bounds__(kThreads) void canon_fill_kernel(float* h, const int* lvl, const int* twin_local,
                                                               int n_lig, int n_nodes, int ghost_base, int lo,
-                                                              int hi, int H) {
+                                                              int hi, int H, float* pq = nullptr, int ldpq = 0) {
   const int i = n_lig + ((blockIdx.x * kThreads + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (i >= n_nodes) return;
   const int L = lvl[i];
   if (L <= lo || L > hi) return;
-  const float* src = h + (size_t)(ghost_base + twin_local[i - n_lig]) * H;
+  const int g = ghost_base + twin_local[i - n_lig];
+  const float* src = h + (size_t)g * H;
   float* dst = h + (size_t)i * H;
   for (int k = 4 * lane; k < H; k += 256) *reinterpret_cast<float4*>(dst + k) = ld4(src + k);
+  // pq: a projection of h that was computed for the ghost rows in the same launch as their h (the next message stage's
+  // P|Q): a row that takes the canonical h takes the canonical projection too -- the same bits a GEMM over it would give
+  if (pq)
+    for (int k = 4 * lane; k < ldpq; k += 256)
+      *reinterpret_cast<float4*>(pq + (size_t)i * ldpq + k) = ld4(pq + (size_t)g * ldpq + k);
 }
 
 __global__ void level_copy_kernel(LevelArgs a, int n_nodes) {
@@ -622,13 +628,13 @@ __global__ __launch_bounds__(kThreads) void sample_mean_kernel(const float* x, c
 // they are added here in tile order (fixed summation order, no atomics).
 __global__ void coord_update_kernel(float* x, const float* xagg, const float* xhead, int n_q,
                                     size_t xagg_stride, size_t xhead_stride, const int* row_ptr,
-                                    const int* deg, int n_upd3) {
+                                    const int* deg, int n_upd3, int max_tile) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_upd3) return;
   const int i = idx / 3, c = idx - 3 * i;
   const int d = deg[i];
   if (d == 0) return;
-  const int s = row_ptr[i], t0 = s >> 5, t1 = (s + d - 1) >> 5;
+  const int s = row_ptr[i], t0 = s >> 5, t1 = min((s + d - 1) >> 5, max_tile);   // (max_tile: see agg_complete_kernel)
   float tot = 0.f;
   for (int q = 0; q < n_q; ++q) {
     float a = xagg[q * xagg_stride + idx];
@@ -643,7 +649,8 @@ __global__ void coord_update_kernel(float* x, const float* xagg, const float* xh
 // The mean is reduced exactly like sample_mean_kernel does (same bits).
 __global__ __launch_bounds__(kThreads) void coord_update_mean_kernel(
     float* x, const float* xagg, const float* xhead, int n_q, size_t xagg_stride, size_t xhead_stride,
-    const int* row_ptr, const int* deg, int n_upd, const int* lig_off, const int* poc_off, int n_lig, float* mean) {
+    const int* row_ptr, const int* deg, int n_upd, const int* lig_off, const int* poc_off, int n_lig, float* mean,
+    int max_tile) {
   __shared__ float red[3][kThreads];
   const int b = blockIdx.x, t = threadIdx.x;
   const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void coord_update_mean_kernel(
       const int i = k / 3, c = k - 3 * i;
       const int d = deg[i];
       if (d == 0) continue;
-      const int s = row_ptr[i], t0 = s >> 5, t1 = (s + d - 1) >> 5;
+      const int s = row_ptr[i], t0 = s >> 5, t1 = min((s + d - 1) >> 5, max_tile);
       float tot = 0.f;
       for (int q = 0; q < n_q; ++q) {
         float v = xagg[q * xagg_stride + k];

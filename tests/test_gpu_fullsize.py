@@ -632,3 +632,64 @@ def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps):
     finally:
         model.set_noise_source(None)
         model._end_chain()
+
+
+@pytest.mark.parametrize("arch,B,frame", [
+    ("small_cond", 6, "shared"),               # H = 64: the chain kernel does not apply (three-launch path on both sides)
+    ("small_variant", 6, False),               # H = 128, two sublayers (the next sublayer's P|Q rides the chain), E(3)
+    ("crossdock_fullatom_cond", 8, "shared"),  # H = 256: ghost rows in front of the level list, cone radii 1,2,3,3,2,1
+    ("crossdock_fullatom_cond", 8, False),     # backward cone only
+    ("crossdock_ca_cond", 8, False),
+])
+@pytest.mark.parametrize("want_pocket", [False, True])
+def test_node_chain_kernel_vs_three_launches_and_oracle(arch, B, frame, want_pocket, monkeypatch):
+    """The row-owning node-phase kernel (csrc/node_chain.h: node MLP + the projections of the new h in one launch,
+    16-row tiles dealt out by cost) against the three-launch node phase (csrc/node_linear.h) on the same call --
+    different MFMA shapes, i.e. a different summation order inside every 16-k group: 2e-5 -- and against the oracle
+    (1e-4).  DSBDD_NODE_CHAIN_MIN_ROWS=0 forces the kernel onto problems far below its default row threshold, so that
+    every row-tile count (1 .. 6), ragged ends, ghost-row offsets and the projection-only launches are exercised."""
+    from diffsbdd_amd.engine import edge_capacity
+    cfg, dd, xl, xp, t, ml, mp = bench_problem(arch, B)
+    sd = W.random_state_dict(cfg, 0)
+    d = dev()
+    n0 = len(mp) // B
+    sizes = torch.full((B,), n0)
+    shared = frame == "shared"
+    if shared:
+        raw = xp[:n0, :3].repeat(B, 1)
+        delta = (xp[:, :3] - raw).view(B, n0, 3)[:, 0]
+        xp = torch.cat([raw + delta[mp], xp[:, 3:]], 1)
+    else:
+        raw = xp[:, :3]
+
+    def run(chain):
+        if chain:
+            monkeypatch.setenv("DSBDD_NODE_CHAIN_MIN_ROWS", "0")
+            monkeypatch.delenv("DSBDD_NODE_CHAIN", raising=False)
+        else:
+            monkeypatch.setenv("DSBDD_NODE_CHAIN", "0")
+        m = make_dynamics(cfg, sd)
+        eng = m.engine()
+        a = [v.to(d) for v in (xl, xp, t[:1] if shared else t, ml, mp)]
+        cap = edge_capacity(a[3], a[4], B)
+        if frame:
+            eng.set_pocket_frame(raw.to(d), a[4], sizes.to(d), a[0].shape[0], B, cap, shared)
+        outs = [m.forward_async(*a, batch=B, edge_cap=cap, want_pocket=want_pocket) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(int(o[2].item()) == 0 for o in outs)
+        assert torch.equal(outs[0][0], outs[2][0])                       # eager = replayed graph
+        er, ec = eng.last_edges(a[0].shape[0] + a[1].shape[0])
+        if frame:
+            eng.clear_pocket_frame()
+        return outs[0][0], outs[0][1], torch.stack([er, ec])
+
+    c_l, c_p, edges = run(True)
+    o_l, o_p, _ = run(False)
+    assert (c_l - o_l).abs().max().item() < 2e-5
+    if want_pocket:
+        assert (c_p - o_p).abs().max().item() < 2e-5
+    with oracle_threads():
+        r_l, r_p, _ = eo.dynamics_forward(sd, cfg, xl, xp, t, ml, mp, edges=edges)
+    assert excess(c_l, r_l) <= 0
+    if want_pocket:
+        assert excess(c_p, r_p) <= 0

@@ -793,7 +793,17 @@ def test_edge_capacity_overflow_is_flagged_not_fatal(want_pocket):
     ok = m.forward_async(*args, batch=B, edge_cap=good, want_pocket=want_pocket)
     torch.cuda.synchronize()
     assert int(ok[2].item()) == 0
+    # the engine must not depend on what its workspace held before: fill it with garbage first (torch's caching
+    # allocator hands out used memory; stale list entries once sent the edge kernels to wild addresses here)
+    m3 = make_dynamics(c.cfg, c.state_dict())
+    m3.engine().ensure_workspace(args[0].shape[0], args[1].shape[0], B, good)
+    m3.engine().workspace.random_(0, 256)
+    ok3 = m3.forward_async(*args, batch=B, edge_cap=good, want_pocket=want_pocket)
+    torch.cuda.synchronize()
+    assert int(ok3[2].item()) == 0 and torch.equal(ok3[0], ok[0])
     m2 = make_dynamics(c.cfg, c.state_dict())
+    m2.engine().ensure_workspace(args[0].shape[0], args[1].shape[0], B, 256)
+    m2.engine().workspace.random_(0, 256)
     bad = m2.forward_async(*args, batch=B, edge_cap=256, want_pocket=want_pocket)
     torch.cuda.synchronize()
     assert int(bad[2].item()) & _lib.STATUS_EDGE_OVERFLOW

@@ -25,6 +25,7 @@
 #include "../diffsbdd_amd/csrc/edge_wave.h"
 #include "../diffsbdd_amd/csrc/graph.h"
 #include "../diffsbdd_amd/csrc/node_linear.h"
+#include "../diffsbdd_amd/csrc/node_chain.h"
 
 using namespace dsbdd;
 
@@ -149,7 +150,7 @@ int main(int argc, char** argv) {
   auto edge_args = [&](int mode, int count_idx) {
     EdgeArgs a{};
     a.erow = d_erow; a.ecol = d_ecol; a.ed0 = d_ed0; a.e_count = d_counts + count_idx; a.e_cap = E;
-    a.x = d_x; a.n_lig = n_lig; a.tile_ctr = d_tile_ctr; a.norm_factor = 100.f; a.wt_base = 0;
+    a.x = d_x; a.n_lig = n_lig; a.n_nodes = N; a.tile_ctr = d_tile_ctr; a.norm_factor = 100.f; a.wt_base = 0;
     if (mode == MODE_GCL) {
       a.ldpq = 2 * H;
       a.mlp[0] = EdgeMlpW{d_pq, d_pq + H, m[0].wd, m[0].wd0, m[0].tab, m[0].w2t, m[0].b2, m[0].w2tp};
@@ -203,7 +204,7 @@ int main(int argc, char** argv) {
   float* d_hn = dev_zero<float>((size_t)N * H);
   float* d_pqg = dev_zero<float>((size_t)N * 2 * H);
   float* d_pqc = dev_zero<float>((size_t)N * 4 * H);
-  float *W1 = mk((size_t)2 * H * H, ws), *b1 = mk(H, 0.1f), *W2 = mk((size_t)H * H, ws), *b2n = mk(H, 0.1f);
+  float *W1 = mk((size_t)2 * H * H, ws), *b1 = mk(H, 0.1f), *W2 = mk((size_t)H * H, ws * 0.02f), *b2n = mk(H, 0.002f);
   float *Wpq = mk((size_t)H * 2 * H, ws), *Wc = mk((size_t)H * 4 * H, ws);
   std::vector<int> perm(N);
   for (int i = 0; i < N; ++i) perm[i] = i;
@@ -211,28 +212,68 @@ int main(int argc, char** argv) {
   int* d_rows = dev(perm);
   std::vector<int> mcounts = {N, 11545, 3639, n_lig};
   int* d_mcounts = dev(mcounts);
+  // packed weights of the row-owning chain kernel (node_chain.h)
+  auto pack = [&](const float* WT, int ldw, int K, int Ncols) {
+    float* d = dev_zero<float>((size_t)K * Ncols + 1024);
+    hipLaunchKernelGGL(pack_b16_kernel, dim3((K * Ncols + 255) / 256), dim3(256), 0, 0, WT, ldw, K, Ncols, d);
+    return d;
+  };
+  float *W1p = pack(W1, H, 2 * H, H), *W2p = pack(W2, H, H, H), *Wpqp = pack(Wpq, 2 * H, H, 2 * H), *Wcp = pack(Wc, 4 * H, H, 4 * H);
+  float* d_h0 = dev(rnd(g, (size_t)N * H, 1.0f));
+  float* d_hc = dev_zero<float>((size_t)N * H);
+  float* d_pqg2 = dev_zero<float>((size_t)N * 2 * H);
+  float* d_pqc2 = dev_zero<float>((size_t)N * 4 * H);
+  auto maxdiff = [&](const float* a, const float* b, size_t n) {
+    std::vector<float> ha(n), hb(n);
+    CK(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
+    double m = 0, ref = 0;
+    for (size_t k = 0; k < n; ++k) { m = std::max(m, (double)std::fabs(ha[k] - hb[k])); ref = std::max(ref, (double)std::fabs(ha[k])); }
+    if (!(m == m)) m = 1e30;
+    return m / std::max(ref, 1e-30);
+  };
   for (int mi = 0; mi < 3; ++mi) {
     const int M = mcounts[mi];
     const int* ridx = mi == 0 ? nullptr : d_rows;
     const int* mc = mi == 0 ? nullptr : d_mcounts + mi;
-    NodeLinearArgs n1{d_h, H, H, d_aggc, H, H, W1, H, b1, nullptr, 0, d_t1, H, N, H, 1, ridx, mc};
+    NodeLinearArgs n1{d_hn, H, H, d_aggc, H, H, W1, H, b1, nullptr, 0, d_t1, H, N, H, 1, ridx, mc};
     NodeLinearArgs n2{d_t1, H, H, nullptr, 0, 0, W2, H, b2n, d_hn, H, d_hn, H, N, H, 0, ridx, mc};
     NodeLinearArgs grp[3] = {
         {d_hn, H, H, nullptr, 0, 0, Wc, 4 * H, nullptr, nullptr, 0, d_pqc, 4 * H, N, 2 * H, 0, d_rows, d_mcounts + 2},
         {d_hn, H, H, nullptr, 0, 0, Wc + 2 * H, 4 * H, nullptr, nullptr, 0, d_pqc + 2 * H, 4 * H, n_lig, 2 * H, 0, nullptr, nullptr},
         {d_hn, H, H, nullptr, 0, 0, Wpq, 2 * H, nullptr, nullptr, 0, d_pqg, 2 * H, N, 2 * H, 0, ridx, mc}};
-    CK(hipMemset(d_hn, 0, (size_t)N * H * 4));
+    NodeChainArgs ca{};
+    ca.row_idx = d_rows; ca.m_count = d_mcounts + mi; ca.M = N; ca.do_mlp = 1; ca.h = d_hc; ca.agg = d_aggc;
+    ca.W1p = W1p; ca.b1 = b1; ca.W2p = W2p; ca.b2 = b2n; ca.n_proj = 3;
+    ca.proj[0] = ChainProj{Wcp, d_pqc2, 4 * H, 2 * H, d_mcounts + 2, 0};                                          // Qc|Qx: active rows
+    ca.proj[1] = ChainProj{Wcp + (size_t)(2 * H / 16) * (H / 16) * 256, d_pqc2 + 2 * H, 4 * H, 2 * H, d_mcounts + 3, 0};   // Pc|Px: ligand rows
+    ca.proj[2] = ChainProj{Wpqp, d_pqg2, 2 * H, 2 * H, nullptr, 0};                                                // next P|Q: all rows
+    // ---- one clean run of either path from the same input: results must agree (fp32 summation order differs) ----
+    CK(hipMemcpy(d_hn, d_h0, (size_t)N * H * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(d_hc, d_h0, (size_t)N * H * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemset(d_pqg, 0, (size_t)N * 2 * H * 4)); CK(hipMemset(d_pqc, 0, (size_t)N * 4 * H * 4));
+    CK(hipMemset(d_pqg2, 0, (size_t)N * 2 * H * 4)); CK(hipMemset(d_pqc2, 0, (size_t)N * 4 * H * 4));
+    (void)launch_node_linear(0, n1); (void)launch_node_linear(0, n2); (void)launch_node_group(0, grp, 3);
+    CK(launch_node_chain(0, ca, H, n_cu));
+    CK(hipDeviceSynchronize());
+    printf("| chain vs three launches, max |diff| / max |ref| (M = %d): h %.2e, next P|Q %.2e, coordinate projections %.2e | | | | | |\n", M,
+           maxdiff(d_hn, d_hc, (size_t)N * H), maxdiff(d_pqg, d_pqg2, (size_t)N * 2 * H), maxdiff(d_pqc, d_pqc2, (size_t)N * 4 * H));
     const float u1 = time_us([&] { (void)launch_node_linear(0, n1); }, reps);
     const float u2 = time_us([&] { (void)launch_node_linear(0, n2); }, reps);
     const float u3 = time_us([&] { (void)launch_node_group(0, grp, 3); }, reps);
+    const float uc = time_us([&] { (void)launch_node_chain(0, ca, H, n_cu); }, reps);
+    NodeChainArgs cm = ca; cm.n_proj = 0;
+    const float um = time_us([&] { (void)launch_node_chain(0, cm, H, n_cu); }, reps);
+    NodeChainArgs cp = ca; cp.do_mlp = 0;
+    const float up = time_us([&] { (void)launch_node_chain(0, cp, H, n_cu); }, reps);
     const double f1 = 2.0 * M * 2.0 * H * H, f2 = 2.0 * M * (double)H * H,
                  f3 = 2.0 * ((double)M * H * 2 * H + 3639.0 * H * 2 * H + (double)n_lig * H * 2 * H);
-    printf("| node MLP layer 1 (K=512,N=256) | %d | %.1f | %.1f | %.3f | %.6e |\n", M, u1, f1 / u1 / 1e6, f1 / u1 / 1e6 / 157.3, checksum(d_t1, (size_t)N * H));
-    printf("| node MLP layer 2 (K=256,N=256,+res) | %d | %.1f | %.1f | %.3f | - |\n", M, u2, f2 / u2 / 1e6, f2 / u2 / 1e6 / 157.3);
-    printf("| grouped projections (Qc|Qx act, Pc|Px lig, next P|Q) | %d | %.1f | %.1f | %.3f | %.6e |\n", M, u3, f3 / u3 / 1e6, f3 / u3 / 1e6 / 157.3,
-           checksum(d_pqg, (size_t)N * 2 * H) + checksum(d_pqc, (size_t)N * 4 * H));
-    printf("| = node phase of one block | %d | %.1f | %.1f | %.3f | |\n", M, u1 + u2 + u3, (f1 + f2 + f3) / (u1 + u2 + u3) / 1e6,
+    printf("| node MLP layer 1 (K=512,N=256) | %d | %.1f | %.1f | %.3f | |\n", M, u1, f1 / u1 / 1e6, f1 / u1 / 1e6 / 157.3);
+    printf("| node MLP layer 2 (K=256,N=256,+res) | %d | %.1f | %.1f | %.3f | |\n", M, u2, f2 / u2 / 1e6, f2 / u2 / 1e6 / 157.3);
+    printf("| grouped projections (Qc|Qx act, Pc|Px lig, next P|Q) | %d | %.1f | %.1f | %.3f | |\n", M, u3, f3 / u3 / 1e6, f3 / u3 / 1e6 / 157.3);
+    printf("| = node phase of one block, three launches | %d | %.1f | %.1f | %.3f | |\n", M, u1 + u2 + u3, (f1 + f2 + f3) / (u1 + u2 + u3) / 1e6,
            (f1 + f2 + f3) / (u1 + u2 + u3) / 1e6 / 157.3);
+    printf("| **node_chain: MLP + 3 projections, one launch** | %d | %.1f | %.1f | %.3f | |\n", M, uc, (f1 + f2 + f3) / uc / 1e6, (f1 + f2 + f3) / uc / 1e6 / 157.3);
+    printf("| node_chain: MLP only | %d | %.1f | %.1f | %.3f | |\n", M, um, (f1 + f2) / um / 1e6, (f1 + f2) / um / 1e6 / 157.3);
+    printf("| node_chain: projections only (h from global) | %d | %.1f | %.1f | %.3f | |\n", M, up, f3 / up / 1e6, f3 / up / 1e6 / 157.3);
   }
 #endif
   return 0;
