@@ -43,6 +43,7 @@ from diffsbdd_amd.pocket import prepare_pocket  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / fp32 vector peak
 HBM_PEAK_GBPS = 8000.0
+PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"
 METRIC = "sampled ligands/sec (500-step DDPM, fullatom_cond) at 1/2/4/8 MI355X"
 
 WORKLOADS = {
@@ -114,6 +115,55 @@ def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
             "torch_threads": torch.get_num_threads()}
 
 
+def cpu_config0(max_threads=32):
+    """BASELINE.json configs[0] end to end on the host, NOT extrapolated: crossdock_ca_cond, one
+    pocket (3rfm), n_samples = 4, 50 DDPM steps -- the oracle's `sample_given_pocket` from z_T to the molecules."""
+    from oracle import ddpm_oracle as do
+    torch.set_num_threads(min(os.cpu_count() or 1, max_threads))
+    cfg, dd = synthetic.arch_cfg("crossdock_ca_cond")
+    sd = synthetic.random_state_dict(cfg, seed=0)
+    m = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
+                       dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
+    m.exact_dist = False
+    pocket = load_pocket("ca", 4, "cpu")
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        do.cond_sample_given_pocket(m, pocket, torch.full((4,), 23), do.NoiseTape(1), timesteps=50)
+    dt = time.perf_counter() - t0
+    return {"value": 4 / dt, "unit": "ligands/s", "seconds": dt, "kind": "port",
+            "sample": "crossdock_ca_cond, 1 pocket (3rfm) x 4 samples x 23 ligand atoms, 50 DDPM steps + final decode = 51 "
+                      "EGNN calls, whole chain timed (not extrapolated)", "torch_threads": torch.get_num_threads()}
+
+
+def call_flops(cfg, lv, plan, N, E, joint):
+    """Algorithmic FLOP of one EGNNDynamics.forward as the engine evaluates it (F_min restricted to
+    the rows every stage computes): lv = mean node / edge counts per hop level (engine.level_stats), plan = the
+    stages' radii.  Without level statistics (joint model, calls that return the pocket part): every row in every stage."""
+    H, L, S = cfg["hidden_nf"], cfg["n_layers"], cfg["inv_sublayers"]
+    A = 2 + (cfg.get("edge_embedding_dim") or 0)
+    n_mlp = 1 if cfg["reflection_equivariant"] else 2
+    G = L * S
+    radii = plan[0] if plan and plan[0] else [4] * G
+    if lv is None:
+        nodes, edges = [N] * 5, [E] * 5
+        e_upd, n_act, n_lig = (E, N, N) if joint else (E, N, N)
+    else:
+        nodes, edges = lv["nodes"], lv["edges"]
+        e_upd, n_act, n_lig = edges[0], nodes[1], nodes[0]
+    mac = 0.0
+    for g in range(G):
+        r = min(radii[g], 4)
+        mac += edges[r] * (H * H + (A + 2) * H)                    # message stage
+        mac += nodes[r] * 3 * H * H                                # node MLP
+        nxt = min(min(radii[g + 1], 4) + 1, 4) if g + 1 < G else None
+        if nxt is not None:
+            mac += nodes[nxt] * 2 * H * H                          # next stage's P|Q
+    mac += nodes[min(min(radii[0], 4) + 1, 4)] * 2 * H * H         # block 0's P|Q
+    mac += L * (e_upd * n_mlp * (H * H + (A + 1) * H) + (n_act + n_lig) * n_mlp * H * H)   # coordinate stages
+    mac += 2 * N * (cfg["joint_nf"] + 1) * H                       # embedding in / out
+    return 2.0 * mac
+
+
 def self_launch(n):
     """Re-exec this script under torch.distributed.run with n ranks on this node
     (rendezvous on 127.0.0.1 and a free port); returns the job's exit code."""
@@ -147,9 +197,11 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the HIP-event timing of the dominant kernel (roofline = null); the engine "
                          "then replays its captured hipGraph instead of launching eagerly")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="concurrent sub-batches per GPU (diffsbdd_amd/streams.py); 0 = the default (1: splitting "
-                         "was measured slower, host-bound graph submission)")
+    ap.add_argument("--pockets", default="same", choices=["same", "mixed"],
+                    help="'same' (default, BASELINE configs[2]): one pocket repeated over the batch, what "
+                         "prepare_pocket(repeats=n) hands the samplers; 'mixed' (SURVEY.md 8d, heterogeneous variant): "
+                         "3rfm and 5ndu alternating, every sample under its own random rigid rotation (seed 0) -- "
+                         "no two pockets of the batch are identical")
     ap.add_argument("--states", default="anchored", choices=["anchored", "free"],
                     help="pocket-conditioned workloads: 'anchored' (default, the headline) keeps every step's ligand "
                          "state on the forward process of a pose inside the pocket -- ConditionalDDPM.inpaint with "
@@ -158,6 +210,9 @@ def main():
                          "of the pocket (fewer ligand-pocket contacts, cheaper calls).  The other one is reported "
                          "as a secondary figure.")
     ap.add_argument("--no-other-leg", action="store_true", help="skip the secondary figure (the other state model)")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed chains of the secondary figure")
+    ap.add_argument("--no-config0", action="store_true",
+                    help="skip the end-to-end CPU run of BASELINE configs[0] (C-alpha, 4 samples, 50 steps)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -186,11 +241,11 @@ def main():
     n_lig = torch.full((B,), args.n_lig, dtype=torch.int64)
     lo = rank * B                                   # weak scaling: every rank owns B global samples
     eng = model.dynamics.engine()
-    from diffsbdd_amd.streams import StreamReplicas, auto_streams
-    n_streams = args.streams or (1 if joint else auto_streams(B * args.n_lig + pocket0["x"].shape[0], B))
-    replicas = StreamReplicas(model, n_streams) if (n_streams > 1 and not joint) else None
-
+    replicas, n_streams = None, 1
     anchor = None if joint else anchor_ligand(B, args.n_lig, cfg["atom_nf"], device)
+    if args.pockets == "mixed":
+        pocket0, anchor_m = synthetic.mixed_pockets(key, B, args.n_lig, cfg["atom_nf"], device)
+        anchor = None if joint else anchor_m
 
     def chain(seed, states=None):
         states = states or args.states
@@ -208,9 +263,6 @@ def main():
             out_l, out_p, lm, pm = model.inpaint(ligand, pocket, torch.zeros(B * args.n_lig, device=device),
                                                  torch.ones(pocket["x"].shape[0], device=device),
                                                  resamplings=2, jump_length=1, timesteps=T)
-        elif replicas is not None:
-            out_l, out_p, lm, pm = replicas.sample_given_pocket(pocket, n_lig, timesteps=T, seed=seed,
-                                                                sample_offset=lo)
         else:
             out_l, out_p, lm, pm = model.sample_given_pocket(pocket, n_lig, timesteps=T)
         return sharding.gather_ligands(out_l, lm, lo)
@@ -246,21 +298,23 @@ def main():
     kern_ms, kern_n = (eng.profile_read() if not args.no_kernel_timing else (0.0, 0))
     eng.profile(False, 0)
     lv_main = eng.level_stats(since=lv0)
-    e_main = eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]) if replicas is None else None
+    e_main = eng.edge_count(B * args.n_lig + pocket0["x"].shape[0])
     timed_level = eng.last_plan()[2]
-    # secondary figure: the other state model of the pocket-conditioned chain (one warm-up, one timed chain)
+    plan_main = eng.last_plan()
+    # secondary figure: the other state model of the pocket-conditioned chain (one warm-up, --other-steps timed chains)
     other = None
-    if not joint and replicas is None and world == 1 and not args.no_other_leg:
+    if not joint and world == 1 and not args.no_other_leg:
         o_states = "free" if args.states == "anchored" else "anchored"
         chain(300, o_states)
         sync()
         lv1 = eng.level_stats(raw=True)
         t1 = time.perf_counter()
-        chain(301, o_states)
+        for k in range(args.other_steps):
+            chain(301 + k, o_states)
         sync()
-        dt = time.perf_counter() - t1
-        other = {"states": o_states, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3, "steps": 1,
-                 "live_levels": eng.level_stats(since=lv1)}
+        dt = (time.perf_counter() - t1) / args.other_steps
+        other = {"states": o_states, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3,
+                 "steps": args.other_steps, "live_levels": eng.level_stats(since=lv1)}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -271,33 +325,31 @@ def main():
 
     if rank == 0:
         N = B * args.n_lig + pocket0["x"].shape[0]
-        if replicas is None:
-            E = E_timed = e_main          # edges of the main leg's last call
-            # the timed launches are those of the largest radius of the call's plan (csrc/engine.hip): the rows of
-            # level <= timed_level, a prefix of the edge list whose mean length the engine accumulated
-            if lv_main is not None and timed_level < 4:
-                E_timed = lv_main["edges"][timed_level]
-        else:   # the timed engine (replica 0) runs the first sub-batch only
-            per = (B + n_streams - 1) // n_streams
-            subs = [min(per, B - i * per) for i in range(n_streams) if B - i * per > 0]
-            n_sub = [b * (args.n_lig + pocket0["x"].shape[0] // B) for b in subs]
-            counts = [r.dynamics.engine().edge_count(n) for r, n in zip(replicas.replicas, n_sub)]
-            E, E_timed = sum(counts), counts[0]
+        E = E_timed = e_main              # edges of the main leg's last call
+        # the timed launches are those of the largest radius of the call's plan (csrc/engine.hip): the rows of
+        # level <= timed_level, a prefix of the edge list whose mean length the engine accumulated
+        if lv_main is not None and timed_level < 4:
+            E_timed = lv_main["edges"][timed_level]
         H = cfg["hidden_nf"]
         A = 2 + (cfg.get("edge_embedding_dim") or 0)
         flops_per_launch = 2.0 * E_timed * (H * H + (A + 2) * H)
         avg_ms = kern_ms / max(kern_n, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if kern_n else None
         # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
-        N_timed = N if replicas is None else n_sub[0]
-        bytes_per_launch = 4.0 * (N_timed * 2 * H + H * H + 3 * E_timed + 3 * N_timed + N_timed * H)
+        bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E_timed + 3 * N + N * H)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2f_pmc_traffic.json")
-        if args.workload == "crossdock_fullatom_cond" and B == 64 and args.states == "anchored" and os.path.isfile(tpath):
+        tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+        if args.workload == "crossdock_fullatom_cond" and B == 64 and args.states == "anchored" and \
+                args.pockets == "same" and os.path.isfile(tpath):
             # PMC counters cannot be read from inside this process; the figure is the one measured
             # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r2f_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc, gfx950-corrected)"
+        # algorithmic work of a WHOLE call from what the stages evaluated (mean over the timed chains): SURVEY.md 8d's
+        # F_min restricted to the rows / edges of every stage's radius
+        call = call_flops(cfg, lv_main, plan_main, N, E, joint)
+        whole = call * n_calls * args.steps / elapsed / 1e12 if call else None
         roofline = {
             "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
             "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -308,8 +360,13 @@ def main():
             # timed = the message-stage launches that run over the WHOLE edge list (same work every launch).
             # Pocket-conditioned chains: block 0 is split by the pocket frame and the last stages run on prefixes
             # of the level-ordered list (csrc/graph.h), so fewer than n_layers launches per call qualify.
-            "timed_launch_kind": ("full edge list" if replicas is not None or lv_main is None or timed_level >= 4
+            "timed_launch_kind": ("full edge list" if lv_main is None or timed_level >= 4
                                   else f"rows of hop level <= {timed_level} (the call's largest message-stage launches)"),
+            # share of the timed region's wall time spent in the timed launches (timed on every k-th call only)
+            "kernel_share_of_wall": (kern_ms * args.time_every / (elapsed * 1e3)) if kern_n else None,
+            # the same roofline over the WHOLE call: algorithmic FLOP of everything a call evaluates / wall time
+            "whole_call_tflops": whole, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
+            "algorithmic_flops_per_call": call, "stage_radii": plan_main[0], "stage_ghost": plan_main[1],
             # mean over the calls of the chain: nodes / edge-list slots with hop level <= r (r = 0: ligand rows,
             # r = 4: everything); message stage g of G evaluates level <= G - g
             "live_levels": lv_main,
@@ -320,22 +377,24 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not joint:
             cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, steps=args.cpu_steps,
                                max_threads=args.cpu_threads)
+            if not args.no_config0:
+                cpu["config0"] = cpu_config0(max_threads=args.cpu_threads)
         value = n_ligands_total / elapsed
+        pocket_desc = (f"3rfm {key} pocket, {pocket0['x'].shape[0] // B} nodes" if args.pockets == "same" else
+                       f"3rfm / 5ndu {key} pockets alternating, each under its own rigid rotation: no two identical")
         line = {
             "metric": METRIC, "value": value, "unit": "ligands/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {B} pockets/GPU (3rfm {key} pocket, "
-                                   f"{pocket0['x'].shape[0] // B} nodes) x {args.n_lig} ligand atoms, "
+            "config": {"workload": f"{args.workload}: {B} pockets/GPU ({pocket_desc}) x {args.n_lig} ligand atoms, "
                                    f"T={T} reverse steps" + (" (RePaint, resamplings=2)" if joint else "") +
                                    f" + final decode = {n_calls} EGNN calls per chain" +
                                    ("" if joint else (", ligand states anchored to the forward process of a pose in "
                                                       "the pocket (inpaint, all atoms known)" if args.states == "anchored"
-                                                      and replicas is None else ", free-running on random weights")),
-                       "states": None if joint else (args.states if replicas is None else "free"),
+                                                      else ", free-running on random weights")),
+                       "states": None if joint else args.states, "pockets": args.pockets,
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
-                       "streams_per_gpu": n_streams,
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
             "roofline": roofline, "cpu_baseline": cpu, "other_states": other,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,

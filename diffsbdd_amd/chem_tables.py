@@ -31,6 +31,11 @@ F F 142 0 0
 """
 MARGINS_PM = (3.0, 2.0, 1.0)   # margin1, margin2, margin3 (constants.py:17)
 
+# highest number of covalent bonds (sum of bond orders) an element takes: the reference's `allowed_bonds`
+# (constants.py:19-22; where it lists alternatives -- P, Hg, Bi -- the largest one)
+MAX_VALENCE = {"H": 1, "C": 4, "N": 3, "O": 2, "F": 1, "B": 3, "Al": 3, "Si": 4, "P": 5, "S": 4, "Cl": 1, "As": 3,
+               "Br": 1, "I": 1, "Hg": 2, "Bi": 5}
+
 _LIGAND_ELEMENTS = ["C", "N", "O", "S", "B", "Br", "Cl", "P", "I", "F"]
 _AMINO_ACIDS = list("ACDEFGHIKLMNPQRSTVWY")
 # dataset -> (ligand atom decoder, pocket decoder for the CA representation)

@@ -75,6 +75,8 @@ class ConditionalDDPM(EnVariationalDiffusion):
         """In place (csrc/ddpm.h cond_affine_noise_kernel): z_lig <- a z_lig + sigma eps, then the ligand
         COM is removed from ligand and pocket.  The sampling loops use this instead of the tensor
         formulas below: one launch, fixed summation order."""
+        if lig_mask.numel() == 0:
+            return                                  # no ligand atoms: nothing to draw, no centre of mass to remove
         if noise is None:
             noise = self._randn(lig_mask, self.n_dims + self.atom_nf, batch)
         _lib.check(_lib.load().dsbdd_cond_affine_noise(

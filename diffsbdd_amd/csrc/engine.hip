@@ -61,7 +61,7 @@ struct dsbdd_engine {
   int prune = 1;                        // DSBDD_PRUNE=0: evaluate every row in every stage
   // forward cone (identical pockets): the first message stages evaluate only the rows the ligand can have influenced;
   // the rest take the values of the canonical pocket, computed once on ghost rows N .. N + n_ghost
-  int cone = 1;                         // DSBDD_CONE=0: off
+  int cone = 1;                         // DSBDD_CONE=0: off, 1: when the cost model says it pays (default), 2: always
   int64_t ghost_slots = 0;              // slots of the ghost segment at the front of the level-ordered list
   // plan of the last forward (host side): radius and ghost use of every message stage, level of the timed launches
   std::vector<int> plan_radius, plan_ghost;
@@ -219,7 +219,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
   const char* cn = getenv("DSBDD_CONE");
-  if (cn && atoi(cn) == 0) e->cone = 0;
+  if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
   const char* nch = getenv("DSBDD_NODE_CHAIN");
   if (nch && atoi(nch) == 0) e->chain = 0;
   const char* ncm = getenv("DSBDD_NODE_CHAIN_MIN_ROWS");
@@ -409,7 +409,7 @@ int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value) {
   if (!e) return fail(DSBDD_ERR_ARG, "null argument");
   switch (which) {
     case DSBDD_OPT_PRUNE: e->prune = value ? 1 : 0; break;
-    case DSBDD_OPT_CONE: e->cone = value ? 1 : 0; break;
+    case DSBDD_OPT_CONE: e->cone = value <= 0 ? 0 : (value >= 2 ? 2 : 1); break;   // 0 off, 1 by the cost model, 2 always
     default: return fail(DSBDD_ERR_ARG, "unknown option");
   }
   e->drop_graphs();
@@ -607,7 +607,14 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // a ligand node can differ from the ligand-free ("canonical") pocket network, which is evaluated once, on the ghost
   // rows N .. N + n_ghost (its stage-0 messages are the frame's pocket-pocket launch).  Stage g then computes the
   // rows of level <= min(g + 1, G - g); the rows the next stage reads beyond those get the canonical values.
-  const bool cone = prune && split0 && e->cone && t_count == 1 && G_stages >= 2;
+  // Cost model: the canonical network is extra work -- its G/2 ascending stages on every ghost row (the frame's pockets:
+  // frame_n3 rows, one per group of identical pockets) -- against the rows the cone's first stages skip.  On the
+  // benchmark pocket the skipped part is (1 - 0.28) + (1 - 0.69) + (1 - 0.97) = 1.06 edge lists per call and the
+  // pocket-pocket edges of the ghosts are 0.83 of a list per stage, so the cone pays while the frame holds less than
+  // 1.06 / (3 x 0.83) = 0.43 of the batch's pocket rows; measured: a batch of all-different pockets runs 25 % slower
+  // with the cone than without (profiles/README.md, "mixed pockets").  DSBDD_CONE=2 / option value 2 forces it on.
+  const bool cone_pays = e->cone >= 2 || 5 * e->frame_n3 <= 2 * (int64_t)n_pocket;
+  const bool cone = prune && split0 && e->cone && cone_pays && t_count == 1 && G_stages >= 2;
   // with a frame, the frame's pockets are the ghost rows N .. N + n_frame_rows; in the level-ordered list they own the
   // first n_ghost entries of lvl_list and the first ghost_slots edge slots
   const int n_frame_rows = split0 ? (int)e->frame_n3 : 0;

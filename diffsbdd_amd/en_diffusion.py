@@ -105,6 +105,59 @@ class PredefinedNoiseSchedule(nn.Module):
         return self.gamma[torch.round(t * self.timesteps).long()]
 
 
+class _PositiveLinear(nn.Module):
+    """Linear layer whose effective weight is softplus(weight) > 0 (en_diffusion.py:1030-1061)."""
+
+    def __init__(self, in_features, out_features, weight_init_offset=-2):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty((out_features, in_features)))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        with torch.no_grad():
+            self.weight.add_(weight_init_offset)
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return F.linear(x, F.softplus(self.weight), self.bias)
+
+
+class GammaNetwork(nn.Module):
+    """Learned monotone noise schedule of the VDM paper (`noise_schedule='learned'`, en_diffusion.py:1064-1102):
+    gamma(t) = gamma_0 + (gamma_1 - gamma_0) * (g(t) - g(0)) / (g(1) - g(0)), g(t) = l1(t) + l3(sigmoid(l2(l1(t))))
+    with positive weights.  Plain PyTorch (a 1 -> 1024 -> 1 network evaluated on T + 1 scalars: not on the hot path);
+    same parameter names as the reference, so a checkpoint trained with a learned schedule loads.  The samplers read
+    the schedule as a table `gamma[0..T]` like the predefined schedules: `.gamma` evaluates the network at t = k / T."""
+
+    def __init__(self, timesteps):
+        super().__init__()
+        self.timesteps = timesteps
+        self.l1 = _PositiveLinear(1, 1)
+        self.l2 = _PositiveLinear(1, 1024)
+        self.l3 = _PositiveLinear(1024, 1)
+        self.gamma_0 = nn.Parameter(torch.tensor([-5.]))
+        self.gamma_1 = nn.Parameter(torch.tensor([10.]))
+        self._table = None
+
+    def gamma_tilde(self, t):
+        l1_t = self.l1(t)
+        return l1_t + self.l3(torch.sigmoid(self.l2(l1_t)))
+
+    def forward(self, t):
+        g0, g1, gt = self.gamma_tilde(torch.zeros_like(t)), self.gamma_tilde(torch.ones_like(t)), self.gamma_tilde(t)
+        return self.gamma_0 + (self.gamma_1 - self.gamma_0) * (gt - g0) / (g1 - g0)
+
+    @property
+    def gamma(self):
+        """[T + 1] table of the current parameters (re-evaluated when a parameter changed)."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._table is None or self._table[0] != key:
+            with torch.no_grad():
+                t = torch.arange(self.timesteps + 1, device=self.gamma_0.device, dtype=torch.float32) / self.timesteps
+                self._table = (key, self.forward(t.view(-1, 1)).view(-1).contiguous())
+        return self._table[1]
+
+
 class DistributionNodes:
     """Joint categorical over (n_ligand_nodes, n_pocket_nodes) from a 2-D
     histogram; host side, once per batch (en_diffusion.py:958-1028)."""
@@ -203,11 +256,11 @@ class EnVariationalDiffusion(nn.Module):
         assert parametrization == 'eps'
         self.loss_type = loss_type
         if noise_schedule == 'learned':
-            raise NotImplementedError(
-                "noise_schedule='learned' (GammaNetwork) is a training-time feature and is not "
-                "part of the MI355X sampling path; the shipped configs use 'polynomial_2'")
-        self.gamma = PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps,
-                                             precision=noise_precision)
+            assert loss_type == 'vlb', 'A noise schedule can only be learned with a vlb objective.'
+            self.gamma = GammaNetwork(timesteps)
+        else:
+            self.gamma = PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps,
+                                                 precision=noise_precision)
         self.dynamics = dynamics
         self.atom_nf = atom_nf
         self.residue_nf = residue_nf
@@ -224,7 +277,8 @@ class EnVariationalDiffusion(nn.Module):
         # noise: None -> sharding-invariant keyed Philox on the GPU; a callable
         # (shape) -> tensor injects external noise (parity tests)
         self.noise_source = None
-        self._seed = None           # None: taken from torch's global RNG at the first draw
+        self._seed = None           # None: taken from torch's global RNG at the first draw of every sampling call
+        self._user_seeded = False   # seed() was called: the key and the draw counter persist across calls
         self._sample_offset = 0
         self._sample_ids = None
         self._draw = 0
@@ -241,9 +295,11 @@ class EnVariationalDiffusion(nn.Module):
         `sample_ids` (int64 [batch]) gives every sample of the batch an explicit
         global id instead (batches packed from several pockets, testset.py).
         Without a call to seed() the key is drawn from torch's global generator at
-        the first use, so `torch.manual_seed` controls the samples and unseeded
-        processes differ (the reference draws from the global generator too)."""
+        the start of EVERY sampling call (`_begin_chain`), so `torch.manual_seed` /
+        `pl.seed_everything` before a call control its samples, as they do for the
+        reference (which draws everything from the global generator)."""
         self._seed, self._sample_offset, self._draw = int(seed), int(sample_offset), 0
+        self._user_seeded = True
         self._sample_ids = None if sample_ids is None else torch.as_tensor(sample_ids, dtype=torch.int64)
 
     def _randn(self, mask, n_cols, batch, stream_id=0):
@@ -279,7 +335,10 @@ class EnVariationalDiffusion(nn.Module):
     def _seg_mean3(self, x, mask, batch):
         """Per-sample mean of x[:, :3] (scatter_mean semantics) with a fixed summation order
         (torch's index_add_ uses float atomics: neither reproducible nor sharding-invariant)."""
-        x = x.contiguous()
+        x = x.to(torch.float32).contiguous()
+        if not x.is_cuda:
+            raise _lib.HipLibraryError("_seg_mean3 runs on the HIP kernels: device tensors only (no CPU fallback)")
+        mask = mask.to(device=x.device, dtype=torch.int64).contiguous()     # the kernel reads raw int64 device memory
         out = torch.zeros((batch, 3), dtype=torch.float32, device=x.device)
         if x.shape[0] == 0:
             return out
@@ -522,6 +581,11 @@ class EnVariationalDiffusion(nn.Module):
             raise ValueError("NaN detected in EGNN output")
 
     share_identical_pockets = True   # evaluate block 0's pocket-pocket messages once for a batch of identical pockets
+    # forward cone of the engine (csrc/engine.hip): 1 = when the engine's cost model says it pays (few distinct pockets
+    # in the batch), 2 = always, 0 = never.  Cone on / off differ in rounding (the canonical pocket is evaluated on the
+    # raw pocket coordinates), so a driver that wants bit-identical molecules for ANY packing of pockets into batches
+    # pins the mode (testset.TestSetDriver uses 2); None leaves the engine's setting (DSBDD_CONE) alone.
+    cone_mode = None
     frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
                                      # extra launches of the split cost more than their few pocket-pocket edges
 
@@ -535,6 +599,8 @@ class EnVariationalDiffusion(nn.Module):
         messages are evaluated for one sample only; results are bit-identical either way."""
         from .engine import edge_capacity
         dev = self._hip_device(None)
+        if not getattr(self, "_user_seeded", False):
+            self._seed, self._draw = None, 0          # a fresh key from torch's generator for this call
         lm = lig_mask.to(device=dev, dtype=torch.int64).contiguous()
         pm = pocket_mask.to(device=dev, dtype=torch.int64).contiguous()
         cap = edge_capacity(lm, pm, batch)
@@ -550,6 +616,8 @@ class EnVariationalDiffusion(nn.Module):
             if self.share_identical_pockets:
                 rep = self._pocket_groups(x, pocket['one_hot'].to(dev), sizes, batch)
             self.dynamics.engine().set_pocket_frame(x, pm, sizes, lm.numel(), batch, cap, representative=rep)
+            if self.cone_mode is not None:
+                self.dynamics.engine().set_option(_lib.OPT_CONE, int(self.cone_mode))
             self._framed = True
         return lm, pm
 

@@ -401,7 +401,14 @@ class HipEngine:
         return list(r[:n.value]), list(g[:n.value]), tl.value
 
     def set_option(self, which, value):
+        """Engine switches (include/diffsbdd_hip.h DSBDD_OPT_*).  Setting a value again is free; a change drops the
+        captured graphs."""
+        if not hasattr(self, "_options"):
+            self._options = {}
+        if self._options.get(which) == int(value):
+            return
         _lib.check(self.lib.dsbdd_engine_set_option(self.handle, which, int(value)))
+        self._options[which] = int(value)
 
     def _read(self, ptr, count, dtype):
         import numpy as np

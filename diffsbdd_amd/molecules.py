@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .chem_tables import dataset_info
+from .chem_tables import MAX_VALENCE, dataset_info
 
 
 @dataclass
@@ -61,7 +61,24 @@ class Molecule:
         new_index = {a: k for k, a in enumerate(keep)}
         bonds = [(new_index[i], new_index[j], o) for i, j, o in self.bonds
                  if i in new_index and j in new_index]
-        return Molecule(self.positions[keep], [self.symbols[a] for a in keep], bonds)
+        m = Molecule(self.positions[keep], [self.symbols[a] for a in keep], bonds)
+        m.n_generated_atoms = self.num_atoms          # size of the sample the fragment was cut from
+        return m
+
+    def valences(self):
+        """Sum of bond orders per atom."""
+        v = [0] * self.num_atoms
+        for i, j, o in self.bonds:
+            v[i] += o
+            v[j] += o
+        return v
+
+    def valence_violations(self):
+        """Atoms that carry more bonds than their element allows (`allowed_bonds`, constants.py:19-22) -- what makes
+        RDKit's sanitisation reject a molecule built from the distance tables (process_molecule(sanitize=True),
+        analysis/molecule_builder.py:176-181).  Elements without an entry are not checked."""
+        return [a for a, (s, v) in enumerate(zip(self.symbols, self.valences()))
+                if s in MAX_VALENCE and v > MAX_VALENCE[s]]
 
     def to_sdf_block(self, name=""):
         """V2000 mol block + `$$$$` record separator."""
@@ -161,3 +178,26 @@ def build_molecules(x, atom_type, lig_mask, info, largest_frag=False):
         mols.append(m.largest_fragment() if largest_frag else m)
         o += n
     return mols
+
+
+def is_valid_molecule(mol, min_atoms=1, max_fragments=None, total_atoms=None, min_fragment_fraction=0.0):
+    """The acceptance filter of the test-set driver when RDKit is absent (testset.TestSetDriver; the reference accepts
+    what `process_molecule` returns, test.py:99-135, analysis/molecule_builder.py:162-214): a molecule built from the
+    GPU bond-order matrix passes when
+      * it exists and has at least `min_atoms` atoms,
+      * no atom exceeds its element's valence (the failure RDKit's sanitisation reports for distance-table bonds),
+      * it is connected -- after `largest_frag` it is by construction; `min_fragment_fraction` additionally asks the
+        kept fragment to hold that share of the `total_atoms` the sample generated (0 = the reference's behaviour:
+        any largest fragment is accepted),
+      * (`max_fragments`) it has at most that many fragments when the fragments were kept (`--all_frags`)."""
+    if mol is None or mol.num_atoms < min_atoms:
+        return False
+    if mol.valence_violations():
+        return False
+    if max_fragments is not None and len(mol.fragments()) > max_fragments:
+        return False
+    if min_fragment_fraction > 0.0:
+        n_all = total_atoms if total_atoms is not None else getattr(mol, "n_generated_atoms", mol.num_atoms)
+        if mol.num_atoms < min_fragment_fraction * n_all:
+            return False
+    return True

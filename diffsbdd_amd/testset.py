@@ -112,16 +112,33 @@ def assign_to_ranks(jobs: List[PocketJob], world: int):
     return parts
 
 
+class IterationLimit(RuntimeError):
+    """A pocket used up its sample budget (test.py:101-104).  `jobs`: all jobs with what they collected so far."""
+
+    def __init__(self, msg, jobs):
+        super().__init__(msg)
+        self.jobs = jobs
+
+
+def default_is_valid(m):
+    """Molecules (molecules.Molecule) go through the valence / connectivity filter of molecules.is_valid_molecule;
+    anything else (a caller's own result objects) only has to exist."""
+    from .molecules import Molecule, is_valid_molecule
+    return is_valid_molecule(m) if isinstance(m, Molecule) else m is not None
+
+
 class TestSetDriver:
     """Runs `sample_batch(plan, batch_no) -> list of per-plan-entry molecule lists` until every job
-    has `n_samples` molecules that pass `is_valid` (or MAXITER rounds were spent on it)."""
+    has `n_samples` molecules that pass `is_valid`.  Budget per pocket as in the reference (test.py:101-104: at most
+    MAXITER rounds of `batch_size` samples each): a job may GENERATE max_rounds * batch_size samples -- counted in
+    samples, because a round here hands a pocket only its deficit, not a whole batch."""
 
     __test__ = False    # not a pytest class
 
     def __init__(self, sample_batch: Callable, batch_size: int, is_valid: Callable = None,
                  oversample: float = 1.0, max_rounds: int = MAXITER, clock: Callable = time.perf_counter):
         self.sample_batch, self.batch_size = sample_batch, batch_size
-        self.is_valid = is_valid or (lambda m: m is not None)
+        self.is_valid = is_valid or default_is_valid
         self.oversample, self.max_rounds, self.clock = oversample, max_rounds, clock
         self.batches = []          # [(wall seconds, [(job name, slots)])]
 
@@ -132,11 +149,19 @@ class TestSetDriver:
         while True:
             open_jobs = [j for j in queue if j.deficit > 0]
             for j in open_jobs:
-                if j.rounds >= self.max_rounds:                      # test.py:101-104
-                    raise RuntimeError(f"{j.name}: maximum number of iterations has been exceeded")
+                if j.n_generated >= self.max_rounds * self.batch_size:        # test.py:101-104, in samples
+                    for k in jobs:
+                        k.valid = k.valid[:k.n_samples]
+                    raise IterationLimit(f"{j.name}: maximum number of iterations has been exceeded "
+                                         f"({j.n_generated} samples generated, {len(j.valid)} of {j.n_samples} accepted)", jobs)
             if not open_jobs:
                 break
-            plan = plan_batch(open_jobs, self.batch_size, self.oversample)
+            # ask for more than the deficit when the filter rejects a share of the molecules: the observed pass rate
+            # of the jobs in the queue scales the request (at least `oversample`, at most 4x)
+            gen_n = sum(j.n_generated for j in open_jobs)
+            rate = sum(len(j.valid) for j in open_jobs) / gen_n if gen_n else 1.0
+            over = max(self.oversample, min(4.0, 1.0 / max(rate, 0.25))) if gen_n else self.oversample
+            plan = plan_batch(open_jobs, self.batch_size, over)
             t0 = self.clock()
             results = self.sample_batch(plan, len(self.batches))
             dt = self.clock() - t0
@@ -155,7 +180,9 @@ class TestSetDriver:
 
     # ---- the reference's output files (test.py:139-186) ---------------------------------------
     @staticmethod
-    def write_outputs(jobs, outdir, write_sdf):
+    def write_outputs(jobs, outdir, write_sdf, summary=None):
+        """`summary`: [(name, seconds)] of ALL ranks' pockets for `pocket_times.txt` (the rank that passes it writes
+        the file; None = this call's jobs, the single-process case)."""
         for sub in ("raw", "processed", "pocket_times"):
             os.makedirs(os.path.join(outdir, sub), exist_ok=True)
         for j in jobs:
@@ -165,9 +192,12 @@ class TestSetDriver:
             write_sdf(os.path.join(outdir, "processed", f"{j.name}_gen.sdf"), j.valid)
             with open(os.path.join(outdir, "pocket_times", f"{j.name}.txt"), "w") as f:
                 f.write(f"{j.name} {j.seconds}")
-        with open(os.path.join(outdir, "pocket_times.txt"), "w") as f:
-            for j in jobs:
-                f.write(f"{j.name} {j.seconds}\n")
+        if summary is None:
+            summary = [(j.name, j.seconds) for j in jobs]
+        if summary is not False:
+            with open(os.path.join(outdir, "pocket_times.txt"), "w") as f:
+                for name, sec in summary:
+                    f.write(f"{name} {sec}\n")
 
 
 def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bias=0, n_nodes_min=0, **kwargs):
@@ -175,6 +205,8 @@ def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bia
     the GPU (LigandGenerator.generate_for_pockets).  Global sample id of slot k of a job's r-th round =
     index * 2^20 + (samples generated for the job so far) + k: independent of the packing."""
     import torch
+    gen.ddpm.cone_mode = 2     # bit-identical molecules for any packing: the engine's forward cone must not switch
+                               # with the number of distinct pockets in a batch (en_diffusion.cone_mode)
 
     def ligand_sizes(job, ids):
         """Ligand sizes of the slots `ids` of one job: fixed, or drawn from p(n_lig | n_pocket)
@@ -263,13 +295,27 @@ def main(argv=None):
     driver = TestSetDriver(make_hip_sampler(gen, a.timesteps, a.seed, largest_frag=not a.all_frags,
                                             n_nodes_bias=a.n_nodes_bias, n_nodes_min=a.n_nodes_min, **extra),
                            a.batch_size)
-    driver.run(mine)
-    TestSetDriver.write_outputs(mine, a.outdir, write_sdf)
-    secs = [j.seconds for j in mine]
-    if secs:
+    failed = None
+    try:
+        driver.run(mine)
+    except IterationLimit as exc:          # keep what was collected (the reference loses the run here)
+        failed = exc
+    # pocket_times.txt lists every pocket of every rank (test.py:179-186): gathered to rank 0
+    times = [(j.name, j.seconds) for j in mine]
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, times)
+        times = [t for part in gathered for t in part]
+    order = {j.name: k for k, j in enumerate(jobs)}
+    times.sort(key=lambda t: order.get(t[0], 0))
+    TestSetDriver.write_outputs(mine, a.outdir, write_sdf, summary=times if rank == 0 else False)
+    if rank == 0 and times:
+        secs = [t[1] for t in times]
         mean = sum(secs) / len(secs)
         std = (sum((s - mean) ** 2 for s in secs) / len(secs)) ** 0.5
-        print(f"[rank {rank}] Time per pocket: {mean:.3f} \\pm {std:.2f}")
+        print(f"Time per pocket: {mean:.3f} \\pm {std:.2f}")
+    if failed is not None:
+        raise SystemExit(f"[rank {rank}] {failed}")
 
 
 if __name__ == "__main__":

@@ -433,6 +433,7 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
     atoms; samples 0 and 3 share one: two samples, one representative), ligands of different sizes including a sample
     WITHOUT ligand atoms (all of its pocket rows are unreachable: level 4), and single-sample batches.
     Ligand eps against the oracle (1e-4) and the all-rows call (2e-5); levels against the BFS."""
+    from diffsbdd_amd import _lib
     from diffsbdd_amd.engine import edge_capacity
     from diffsbdd_amd.pocket import prepare_pocket
     cfg, dd = W.arch_cfg("crossdock_fullatom_cond")
@@ -464,7 +465,7 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
 
     raw_all = torch.cat(raws)
 
-    def run(sel, want_pocket, shared=False, rep=None):
+    def run(sel, want_pocket, shared=False, rep=None, cone=2):
         keep_l = torch.isin(ml_all, torch.tensor(sel))
         keep_p = torch.isin(mp_all, torch.tensor(sel))
         remap = torch.full((B,), -1, dtype=torch.long)
@@ -475,6 +476,7 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
         eng = m.engine()
         cap = edge_capacity(a[3], a[4], len(sel))
         szs = torch.tensor([sizes_p[s] for s in sel])
+        eng.set_option(_lib.OPT_CONE, cone)      # 2: on whatever the engine's cost model says (1 = by the cost model)
         if rep is None:      # every sample its own representative, frame = the current coordinates
             eng.set_pocket_frame(a[1][:, :3].contiguous(), a[4], szs.to(d), a[0].shape[0], len(sel), cap, shared)
         else:                # groups of identical pockets: the frame is the raw (untranslated) pocket
@@ -493,6 +495,11 @@ def test_ligand_only_call_with_ragged_and_empty_samples():
     full, edges, _, _, a_cpu = run([0, 1, 2, 3], True)
     lig, _, lv, plan, _ = run([0, 1, 2, 3], False)
     assert plan[0] == [1, 2, 3, 3, 2, 1] and plan[1] == [1, 1, 1, 0, 0, 0]   # every pocket its own representative
+    # left to the engine's cost model the cone stays off here (as many ghost rows as pocket rows: the canonical network
+    # would cost more than the skipped rows save); same ligand output to rounding
+    auto, _, _, plan_a, _ = run([0, 1, 2, 3], False, cone=1)
+    assert plan_a[0] == [4, 4, 4, 3, 2, 1] and not any(plan_a[1])
+    assert (auto - lig).abs().max().item() < 2e-5
     n_l = len(ml_all)
     want = _hop_levels(edges[0].numpy(), edges[1].numpy(), n_l, n_l + len(mp_all))
     assert np.array_equal(lv["level"], want)
@@ -533,6 +540,8 @@ def test_frame_survives_unrelated_calls_on_the_same_engine():
     small = [v.to(d) for v in (xl[:2 * nl], xp[:2 * n0], t[:1], ml[:2 * nl], mp[:2 * n0])]
     eng.ensure_workspace(len(ml), len(mp), 4, cap_big)          # one workspace for both problem sizes
     cap = edge_capacity(small[3], small[4], 2)
+    from diffsbdd_amd import _lib
+    eng.set_option(_lib.OPT_CONE, 2)                            # (two samples, two representatives: force the cone)
     eng.set_pocket_frame(small[1][:, :3].contiguous(), small[4], torch.full((2,), n0).to(d), 2 * nl, 2, cap, False)
     first = [m.forward_async(*small, batch=2, edge_cap=cap_big, want_pocket=False)[0].clone() for _ in range(3)]
     assert eng.last_plan()[0] == [1, 2, 3, 3, 2, 1]

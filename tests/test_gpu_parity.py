@@ -650,29 +650,6 @@ def test_unsorted_masks_raise_and_manual_seed_controls_noise():
         model.sample_given_pocket(bad, n_lig, timesteps=2)
 
 
-def test_stream_replicas_equal_single_batch_bitwise():
-    """diffsbdd_amd/streams.py: the batch cut into concurrent sub-batches on several HIP streams
-    (own engine each, shared parameters) gives, bit for bit, the single-batch result."""
-    from diffsbdd_amd.conditional_model import ConditionalDDPM
-    from diffsbdd_amd.streams import StreamReplicas, auto_streams
-    cfg, dd, pocket = _bench_problem("crossdock_ca_cond", 10)
-    sd = W.random_state_dict(cfg, 0)
-    model = ConditionalDDPM(dynamics=make_dynamics(cfg, sd), atom_nf=10, residue_nf=20, n_dims=3,
-                            size_histogram=np.ones((4, 8)), timesteps=dd["timesteps"],
-                            noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
-                            loss_type="l2", norm_values=dd["norm_values"]).to(dev())
-    n_lig = torch.tensor([23, 11, 30, 23, 5, 17, 23, 23, 40, 8])
-    model.seed(99, sample_offset=3)
-    ref = model.sample_given_pocket({k: v.clone() for k, v in pocket.items()}, n_lig, timesteps=6)
-    for S in (2, 3, 4):
-        rep = StreamReplicas(model, S)
-        out = rep.sample_given_pocket({k: v.clone() for k, v in pocket.items()}, n_lig, timesteps=6, seed=99,
-                                      sample_offset=3)
-        for a, b in zip(out, ref):
-            assert torch.equal(a, b), S
-    assert auto_streams(32 * 59, 32) == 1 and auto_streams(64 * 309, 64) == 1    # opt-in only (measured slower)
-
-
 @pytest.mark.parametrize("name", ["loss_small_cond_eval", "loss_small_cond_train", "loss_small_joint_eval",
                                   "loss_small_joint_train"])
 def test_loss_terms_vs_oracle_and_reference_golden(name):

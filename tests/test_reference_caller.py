@@ -137,3 +137,32 @@ def test_reference_generate_ligands_drives_the_drop_in_sampler(lm, name, monkeyp
         assert seen["resamplings"] == 2 and float(seen["lig_fixed"].sum()) == 0
         assert float(seen["pocket_fixed"].sum()) == len(p["mask"])
         assert seen["ligand"]["x"].shape == (int(seen["n"].sum()), 3)
+
+
+def test_learned_noise_schedule_matches_the_reference_network():
+    """noise_schedule='learned' (the reference's DEFAULT constructor argument): our GammaNetwork carries the
+    reference's parameter names, loads its state_dict and returns its gamma(t) (en_diffusion.py:1030-1102);
+    the samplers' table is the network at t = k / T."""
+    import io
+    from contextlib import redirect_stdout
+    mods = ref_shim.import_reference()
+    ref_ed = mods["en_diffusion"] if isinstance(mods, dict) else mods[1]
+    from diffsbdd_amd.en_diffusion import EnVariationalDiffusion, GammaNetwork
+    torch.manual_seed(3)
+    with redirect_stdout(io.StringIO()):
+        ref = ref_ed.GammaNetwork()
+    ours = GammaNetwork(timesteps=40)
+    assert sorted(ours.state_dict().keys()) == sorted(ref.state_dict().keys())
+    ours.load_state_dict(ref.state_dict())
+    t = torch.rand(17, 1)
+    assert torch.allclose(ours(t), ref(t), atol=1e-6, rtol=1e-6)
+    tab = ours.gamma
+    assert tab.shape == (41,) and abs(tab[0].item() + 5.0) < 1e-5 and abs(tab[-1].item() - 10.0) < 1e-5
+    assert (tab[1:] >= tab[:-1]).all()                       # monotone
+    assert torch.allclose(tab, ref(torch.arange(41).float().view(-1, 1) / 40).view(-1), atol=1e-5)
+    # the DDPM accepts the schedule (vlb only, as the reference asserts)
+    dyn = torch.nn.Linear(1, 1)
+    dyn.update_pocket_coords = True
+    m = EnVariationalDiffusion(dynamics=dyn, atom_nf=10, residue_nf=10, n_dims=3, size_histogram=np.ones((4, 4)),
+                               timesteps=40, noise_schedule="learned", loss_type="vlb", norm_values=(1.0, 1.0))
+    assert "gamma.l2.weight" in m.state_dict() and m._coefs(40) is not None

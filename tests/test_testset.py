@@ -50,6 +50,48 @@ def test_scheduler_gives_up_like_the_reference():
         drv.run(jobs)
 
 
+def test_budget_counts_samples_and_oversampling_follows_the_pass_rate():
+    """The reference gives a pocket MAXITER rounds of batch_size samples (test.py:101-104).  Here a round hands a
+    pocket its deficit only, so the budget is counted in SAMPLES: with a filter that passes one molecule in five a
+    pocket still finishes (its deficit shrinks geometrically), the request is scaled by the observed pass rate,
+    and when the budget is exhausted the collected molecules survive in the exception."""
+    jobs = fake_jobs([50, 60], n_samples=20)
+    sizes = []
+
+    def sample_batch(plan, batch_no):
+        sizes.append(sum(n for _, n in plan))
+        return [[(job.index, job.n_generated + k) for k in range(n)] for job, n in plan]
+
+    drv = ts.TestSetDriver(sample_batch, batch_size=32, is_valid=lambda m: m[1] % 5 == 0, max_rounds=10)
+    done = drv.run(jobs)
+    assert all(len(j.valid) == 20 for j in done)
+    assert all(j.n_generated <= 10 * 32 for j in done) and max(j.rounds for j in done) > 3
+    # a filter nothing passes: the budget of max_rounds * batch_size samples per pocket ends the run, results are kept
+    jobs = fake_jobs([50], n_samples=4)
+    drv = ts.TestSetDriver(lambda plan, b: [[(0, k) for k in range(n)] for _, n in plan], batch_size=8,
+                           is_valid=lambda m: False, max_rounds=3)
+    with pytest.raises(ts.IterationLimit) as exc:
+        drv.run(jobs)
+    assert exc.value.jobs[0].n_generated >= 24 and len(exc.value.jobs[0].raw) == exc.value.jobs[0].n_generated
+
+
+def test_default_filter_rejects_overvalent_molecules():
+    """is_valid defaults to the valence / connectivity filter on molecules built from the bond-order matrix
+    (molecules.is_valid_molecule; allowed valences = the reference's constants.py:19-22)."""
+    from diffsbdd_amd.molecules import Molecule, is_valid_molecule
+    pos = np.zeros((5, 3), dtype=np.float32)
+    ok = Molecule(pos, ["C", "O", "N", "C", "F"], [(1, 0, 2), (2, 0, 1), (3, 2, 1), (4, 3, 1)])
+    assert ok.valences() == [3, 2, 2, 2, 1] and not ok.valence_violations() and ts.default_is_valid(ok)
+    bad = Molecule(pos, ["C", "O", "N", "C", "F"], [(1, 0, 2), (2, 0, 1), (3, 1, 1), (4, 3, 1)])   # O with 3 bonds
+    assert bad.valence_violations() == [1] and not ts.default_is_valid(bad)
+    assert not ts.default_is_valid(None) and ts.default_is_valid("anything else that exists")
+    two = Molecule(pos, ["C", "C", "C", "C", "C"], [(1, 0, 1), (2, 1, 1), (4, 3, 1)])
+    frag = two.largest_fragment()
+    assert frag.num_atoms == 3 and frag.n_generated_atoms == 5
+    assert is_valid_molecule(frag) and not is_valid_molecule(frag, min_fragment_fraction=0.8)
+    assert is_valid_molecule(two, max_fragments=2) and not is_valid_molecule(two, max_fragments=1)
+
+
 def test_rank_partition_balances_cost_and_outputs_follow_the_reference_layout(tmp_path):
     jobs = fake_jobs([300, 36, 280, 40, 310, 290, 35, 305, 295], n_samples=10)
     parts = ts.assign_to_ranks(jobs, 2)
@@ -67,6 +109,13 @@ def test_rank_partition_balances_cost_and_outputs_follow_the_reference_layout(tm
         assert os.path.isfile(tmp_path / "pocket_times" / f"{j.name}.txt")
     lines = (tmp_path / "pocket_times.txt").read_text().splitlines()
     assert [l.split()[0] for l in lines] == [j.name for j in done]
+    # several ranks: the summary of ALL pockets is written by the rank that is handed it, the others write none
+    all_times = [(j.name, 1.5) for j in jobs]
+    os.remove(tmp_path / "pocket_times.txt")
+    ts.TestSetDriver.write_outputs(done, str(tmp_path), lambda path, mols: None, summary=False)
+    assert not os.path.exists(tmp_path / "pocket_times.txt")
+    ts.TestSetDriver.write_outputs(done, str(tmp_path), lambda path, mols: None, summary=all_times)
+    assert len((tmp_path / "pocket_times.txt").read_text().splitlines()) == len(jobs)
 
 
 @pytest.mark.gpu

@@ -1,4 +1,6 @@
-"""Intra-GPU replicas: one sampling batch as several concurrent sub-batches (opt-in).
+"""REJECTED EXPERIMENT (round 2; kept under tools/ for the record, not part of the product package).
+
+Intra-GPU replicas: one sampling batch as several concurrent sub-batches.
 
 A launch needs far more than 256 workgroups to fill an MI355X (256 CUs in 8 XCDs).
 The C-alpha workloads (BASELINE.json configs[1]: 32 pockets, ~20 k edges per EGNN
@@ -9,15 +11,14 @@ segments + fixed summation order, csrc/edge_mlp.h; noise keyed by the global sam
 index), a batch can be cut into S contiguous sub-batches that run on S HIP streams
 -- each with its own engine (workspace, captured graph) but the same parameter
 tensors -- and the concatenated result is identical, bit for bit, to the single-batch
-run (tests/test_gpu_parity.py::test_stream_replicas_equal_single_batch_bitwise).
+run (verified in round 2).
 
 MEASURED (profiles/README.md, round 2): it does NOT pay inside one process.  A
 sub-batch call is as long as the full-batch call (latency-bound), and replaying the
 ~70-node captured graph costs ~0.57 ms of host time per call under the runtime's
 process-wide submission lock, so S streams become host-bound: 48.8 / 42.1 / 23.9 /
-13.9 ligands/s for S = 1 / 2 / 4 / 8 on the C-alpha workload.  The facility stays
-opt-in (`bench.py --streams S`); what the latency regime needs is fewer, larger
-launches per call, not more submitters.
+13.9 ligands/s for S = 1 / 2 / 4 / 8 on the C-alpha workload.  What the latency regime
+needs is fewer, larger launches per call, not more submitters.
 
 The reference has nothing comparable (one batch, one stream:
 /root/reference/lightning_modules.py:797-852).
