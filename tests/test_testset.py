@@ -148,7 +148,8 @@ def test_packed_sampling_is_independent_of_the_packing():
 
     def run(batch_size):
         jobs = ts.number_jobs([ts.PocketJob(n, residues[n], len(residues[n]), 6) for n in ("3rfm", "5ndu")])
-        drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=4, seed=5, largest_frag=False), batch_size)
+        drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=4, seed=5, largest_frag=False), batch_size,
+                               is_valid=lambda m: m is not None)     # (the packing is the subject, not the filter)
         return {j.name: j.valid for j in drv.run(jobs)}, len(drv.batches)
 
     a, na = run(12)
@@ -192,7 +193,8 @@ def test_packed_sampling_full_atom_pockets_is_independent_of_the_packing():
 
     def run(batch_size):
         jobs = ts.number_jobs([ts.PocketJob(n, residues[n], len(residues[n]), 6) for n in ("3rfm", "5ndu")])
-        drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=4, seed=5, largest_frag=False, n_nodes_min=2), batch_size)
+        drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=4, seed=5, largest_frag=False, n_nodes_min=2), batch_size,
+                               is_valid=lambda m: m is not None)
         out = {j.name: j.valid for j in drv.run(jobs)}
         return out, len(drv.batches), gen.ddpm.dynamics.engine().last_plan()
 

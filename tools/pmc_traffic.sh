@@ -5,7 +5,7 @@
 # gpurun_out/<TAG>_pmc_traffic.json (units / gfx950 correction as MI355X_MICROARCH.md "HBM" prescribes:
 # counter value = KiB; FETCH_SIZE under-counts wide reads 2x on gfx950 -> doubled, an upper bound).
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r2}
+TAG=${1:-r3}
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
