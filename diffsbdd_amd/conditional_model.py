@@ -329,8 +329,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
     def forward(self, ligand, pocket, return_info=False):
         """The reference's loss terms for the pocket-conditioned model (conditional_model.py:202-330):
         same 12-tuple as the joint model with error_t_pocket = loss_0_x_pocket = 0."""
-        self._loss_guard()
-        with torch.no_grad():
+        with self._loss_context():
             dev = self._hip_device(None)
             ligand, pocket = self._to_device(ligand, dev), self._to_device(pocket, dev)
             ligand, pocket = self.normalize(ligand, pocket)

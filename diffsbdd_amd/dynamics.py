@@ -11,10 +11,13 @@ output")` contract (dynamics.py:155-159), `get_edges` (dynamics.py:169-187) and
 the `state_dict` key names and shapes, so released checkpoints
 load with `strict=True`.
 
-What is different: the modules below are *parameter containers*; nothing calls
-their `forward`.  The arithmetic is the factorised algorithm described in
-csrc/edge_mlp.h.  There is no CPU / PyTorch fallback: tensors must live on a
-GPU and the HIP library must be built, otherwise the call raises.
+What is different: on the sampling path the modules below are *parameter
+containers*; nothing calls their `forward`.  The arithmetic is the factorised
+algorithm described in csrc/edge_mlp.h.  There is no CPU fallback: tensors must
+live on a GPU and the HIP library must be built, otherwise the call raises.
+Only the training step (training mode + autograd recording) evaluates the same
+function with differentiable GPU tensor operations on these modules
+(train_path.py); its radius graph still comes from the HIP builder.
 """
 from __future__ import annotations
 
@@ -153,17 +156,29 @@ class EGNNDynamics(nn.Module):
 
     # ---- engine management -------------------------------------------------
     def invalidate_engine(self):
-        """Call after changing parameters in place (load_state_dict and .to()
-        do it automatically): the packed kernel weights are rebuilt lazily."""
+        """The packed kernel weights are rebuilt lazily.  load_state_dict, .to() and in-place parameter updates
+        (optimiser steps; detected through the tensors' version counters) trigger it automatically."""
         self._engine = None
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._engine = None
+        self._plist = None
         return out
+
+    def _param_signature(self):
+        """Changes whenever a parameter was updated in place (optimiser step, manual edit under no_grad): the sum of
+        the tensors' version counters."""
+        if getattr(self, "_plist", None) is None:
+            self._plist = list(self.parameters())
+        return sum(p._version for p in self._plist)
 
     def engine(self) -> HipEngine:
         p = self.egnn.embedding.weight
+        sig = self._param_signature()
+        if self._engine is not None and sig != getattr(self, "_engine_sig", sig):
+            self._engine = None           # parameters changed since the kernel weights were packed: repack
+        self._engine_sig = sig
         if self._engine is None or self._engine.device != p.device:
             if p.device.type != 'cuda':
                 raise _lib.HipLibraryError(
@@ -173,10 +188,20 @@ class EGNNDynamics(nn.Module):
         return self._engine
 
     # ---- the reference API -------------------------------------------------
-    @torch.no_grad()
     def forward(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues):
         """dynamics.py:87-167.  Inputs are not modified.  Raises ValueError on NaN
-        in the predicted velocity (eval-mode behaviour of the reference)."""
+        in the predicted velocity (eval-mode behaviour of the reference).
+
+        Training mode with autograd recording (the training step, lightning_modules.py:337-363): the differentiable
+        GPU evaluation of train_path.py; everything else -- sampling, validation, any call under no_grad -- the
+        fused HIP kernels."""
+        if self.training and torch.is_grad_enabled():
+            from .train_path import dynamics_forward_autograd
+            return dynamics_forward_autograd(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+        with torch.no_grad():
+            return self._forward_hip(xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+
+    def _forward_hip(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues):
         eps_l, eps_p, status = self.forward_async(xh_atoms, xh_residues, t, mask_atoms, mask_residues)
         st = int(status.item())
         if st & _lib.STATUS_EDGE_OVERFLOW:

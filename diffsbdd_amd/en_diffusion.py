@@ -446,10 +446,10 @@ class EnVariationalDiffusion(nn.Module):
         return EnVariationalDiffusion.remove_mean_batch(x, torch.cat((lig_indices, pocket_indices)))
 
     # ---- loss terms (en_diffusion.py:109-262, 336-469) --------------------------------------
-    # The network evaluations run on the HIP kernels, which have no backward pass: the loss can be
-    # EVALUATED (validation_step, likelihood estimates) but not differentiated.  Calling forward()
-    # in training mode with autograd enabled raises instead of returning a loss that silently
-    # carries no gradient.
+    # Evaluation (eval mode / no_grad: validation_step, likelihood estimates): the network passes run on the HIP
+    # kernels.  Training step (training mode with autograd recording): the network passes go through the
+    # differentiable GPU path of train_path.py and every loss term carries its graph, so `loss.backward()` reaches the
+    # parameters (lightning_modules.py:337-363).
     t_int_source = None          # optional callable(batch) -> [B,1] float tensor (tests); default torch.randint
 
     def _draw_t_int(self, batch, device):
@@ -458,12 +458,10 @@ class EnVariationalDiffusion(nn.Module):
             return self.t_int_source(batch).to(device=device, dtype=torch.float32).view(batch, 1)
         return torch.randint(lowest_t, self.T + 1, size=(batch, 1), device=device).float()
 
-    def _loss_guard(self):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError(
-                "forward() evaluates the loss terms on the HIP kernels, which have no backward pass "
-                "(SURVEY.md 8f-3): call it in eval mode or under torch.no_grad(); training needs the "
-                "reference implementation")
+    def _loss_context(self):
+        """no_grad for evaluation; the autograd graph is kept for a training step."""
+        import contextlib
+        return contextlib.nullcontext() if (self.training and torch.is_grad_enabled()) else torch.no_grad()
 
     @staticmethod
     def gaussian_KL(q_mu_minus_p_mu_squared, q_sigma, p_sigma, d):
@@ -514,8 +512,7 @@ class EnVariationalDiffusion(nn.Module):
         """The reference's loss terms (en_diffusion.py:336-469), same 12-tuple (+ info):
         (delta_log_px, error_t_lig, error_t_pocket, SNR_weight, loss_0_x_ligand, loss_0_x_pocket,
          loss_0_h, neg_log_constants, kl_prior, log_pN, t_int, xh_lig_hat)."""
-        self._loss_guard()
-        with torch.no_grad():
+        with self._loss_context():
             dev = self._hip_device(None)
             ligand, pocket = self._to_device(ligand, dev), self._to_device(pocket, dev)
             ligand, pocket = self.normalize(ligand, pocket)

@@ -684,10 +684,77 @@ def test_loss_terms_vs_oracle_and_reference_golden(name):
         assert (v - gold).abs().max().item() <= 5e-3 * scale, (name, nme, (v - gold).abs().max().item())
     for k, v in info.items():
         assert abs(float(v) - float(c.t("info_" + k))) <= 5e-3 * max(1.0, abs(float(c.t("info_" + k)))), k
-    # the training step itself needs a backward pass, which the HIP kernels do not have: refuse loudly
+
+
+def _trainable_terms(terms):
+    """The terms of the 12-tuple that depend on the network (error_t_lig, error_t_pocket, loss_0_x_ligand,
+    loss_0_x_pocket, loss_0_h), reduced like the l2 objective of lightning_modules.py:262-275 up to constant factors."""
+    return sum(torch.as_tensor(terms[i]).float().mean() for i in (1, 2, 4, 5, 6))
+
+
+@pytest.mark.parametrize("name", ["loss_small_cond_train", "loss_small_joint_train"])
+def test_training_step_gradients_vs_oracle_autograd(name):
+    """SURVEY.md 8f-3, backward half: in training mode with autograd recording, `forward()` returns loss terms that
+    carry their graph (diffsbdd_amd/train_path.py) -- `loss.backward()` fills every parameter's .grad.  Against the
+    oracle differentiated by autograd on the CPU (same t_int, same noise): loss terms 1e-4, every parameter gradient
+    1e-4 relative to that gradient's largest entry.  Then three optimiser steps on the fixed batch lower the loss
+    (what `training_step` + AdamW do, lightning_modules.py:184,337-363)."""
+    from tests.test_oracle_golden import loss_inputs
+    c = Case(name)
+    cfg, dd = c.cfg, c.ddpm
+    model = make_ddpm(c)
+    model.size_distribution = type(model.size_distribution)(np.ones((12, 60)))
     model.train(True)
-    with pytest.raises(NotImplementedError, match="no backward pass"):
-        model(*loss_inputs(c))
+    model.set_noise_source(do.NoiseReplay(c.noise()))
+    model.t_int_source = lambda b: c.t("t_int")
+    terms = model(*loss_inputs(c))
+    loss = _trainable_terms(terms)
+    assert loss.requires_grad
+    loss.backward()
+    # the oracle, differentiated
+    sd = {k: v.clone().requires_grad_(True) for k, v in c.state_dict().items()}
+    om = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
+                        dd["noise_precision"], norm_values=dd["norm_values"], conditional=dd["conditional"])
+    ref = do.loss_terms(om, *loss_inputs(c), c.t("t_int"), do.NoiseReplay(c.noise()), True)
+    ref_loss = _trainable_terms(ref)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
+    ref_loss.backward()
+    n_checked = 0
+    for pname, p in model.dynamics.named_parameters():
+        g_ref = sd[pname].grad
+        if pname.endswith("coord_mlp.4.weight"):                 # one Parameter shared by both coordinate MLPs
+            twin = pname.replace("coord_mlp", "cross_product_mlp")
+            if twin in sd and sd[twin].grad is not None:
+                g_ref = g_ref + sd[twin].grad
+        if p.grad is None and g_ref is None:                      # (the conditional loss never reads the pocket decoder)
+            continue
+        assert p.grad is not None and g_ref is not None, pname
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        assert err <= 1e-4 * scale + 1e-7, (pname, err, scale)
+        n_checked += 1
+    assert n_checked >= 40
+    # a few optimiser steps on the same batch
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, amsgrad=True, weight_decay=1e-12)
+    losses = []
+    for _ in range(4):
+        model.set_noise_source(do.NoiseReplay(c.noise()))
+        opt.zero_grad()
+        l = _trainable_terms(model(*loss_inputs(c)))
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    assert losses[-1] < losses[0], losses
+    # evaluation on the updated parameters runs on the HIP kernels again (the engine repacks its weights)
+    # (the optimiser's in-place updates are noticed: the HIP evaluation packs the new weights.)  Same t_int and noise
+    # as the training passes, evaluated under no_grad in training mode = the fused kernels on the updated parameters
+    model.set_noise_source(do.NoiseReplay(c.noise()))
+    with torch.no_grad():
+        ev = _trainable_terms(model(*loss_inputs(c))).item()
+    model.set_noise_source(do.NoiseReplay(c.noise()))
+    chk = _trainable_terms(model(*loss_inputs(c))).item()        # autograd path, same parameters
+    assert abs(ev - chk) <= 1e-4 * max(1.0, abs(chk)), (ev, chk)
+    assert ev < losses[0]
 
 
 def _replay(c, prefix):

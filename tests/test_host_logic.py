@@ -261,22 +261,19 @@ def test_c_abi_argument_and_state_errors():
     assert lib.dsbdd_bond_orders(None, one, one, one, 0, 10, one, one, one, 3.0, 2.0, 1.0, 8, one) == _lib.ERR_ARG
 
 
-def test_training_forward_refuses_autograd_and_needs_a_gpu():
-    """forward() evaluates the loss terms on the HIP kernels (no backward pass): with
-    autograd on in training mode it raises before touching anything; in eval mode on a CPU module it
-    fails like every other entry point (no CPU fallback)."""
+def test_loss_forward_needs_a_gpu_in_both_modes():
+    """forward() evaluates the loss terms on the HIP kernels (eval / no_grad) or on the differentiable
+    GPU path (training step); a CPU module fails like every other entry point -- there is no CPU fallback."""
     cfg, dd = W.arch_cfg("small_cond")
     ddpm = ConditionalDDPM(dynamics=EGNNDynamics(**cfg), atom_nf=10, residue_nf=10, n_dims=3,
                            size_histogram=np.ones((4, 8)), timesteps=20, noise_schedule="polynomial_2",
                            noise_precision=5e-4, loss_type="l2", norm_values=(1., 4.))
     lig = {"x": torch.zeros(2, 3), "one_hot": torch.zeros(2, 10), "size": torch.tensor([2]), "mask": torch.zeros(2, dtype=torch.long)}
     poc = {"x": torch.zeros(3, 3), "one_hot": torch.zeros(3, 10), "size": torch.tensor([3]), "mask": torch.zeros(3, dtype=torch.long)}
-    ddpm.train()
-    with pytest.raises(NotImplementedError, match="no backward pass"):
-        ddpm(lig, poc)
-    ddpm.eval()
-    with pytest.raises(_lib.HipLibraryError):
-        ddpm(lig, poc)
+    for training in (True, False):
+        ddpm.train(training)
+        with pytest.raises(_lib.HipLibraryError):
+            ddpm({k: v.clone() for k, v in lig.items()}, {k: v.clone() for k, v in poc.items()})
 
 
 def test_aligned_edge_layout_and_atomic_free_aggregation_protocol():
