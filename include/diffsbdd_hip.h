@@ -208,7 +208,9 @@ int dsbdd_engine_graph_stats(const dsbdd_engine* e, int64_t* replays, int64_t* c
 int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghost, int32_t capacity,
                            int32_t* n_stages, int32_t* timed_level);
 
-/* Switches of the dead-row elimination (default on; environment: DSBDD_PRUNE=0 / DSBDD_CONE=0). */
+/* Switches of the dead-row elimination (environment: DSBDD_PRUNE, DSBDD_CONE).  DSBDD_OPT_PRUNE: 0 / 1.
+ * DSBDD_OPT_CONE: 0 = never, 1 = when the engine's cost model says the canonical-pocket network pays (default: the
+ * frame's representatives hold at most 0.4 of the batch's pocket rows), 2 = always.  Cone on / off agree to rounding. */
 enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1 };
 int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value);
 
