@@ -71,6 +71,7 @@ def build_model(arch, device):
                             size_histogram=np.ones((40, 400)), timesteps=dd["timesteps"],
                             noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
                             loss_type="l2", norm_values=dd["norm_values"]).to(device)
+    model.eval()
     return cfg, dd, model
 
 

@@ -783,7 +783,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   }
   // packed weights of the row-owning node-phase kernel: per (block, sublayer) node MLP layer 1 [2H -> H], layer 2
   // [H -> H] and the message stage's first-layer projection [H -> 2H]; per block the coordinate projections [H -> PQ]
-  const bool use_chain = e->chain && (H == 256 || H == 128) && N >= e->chain_min_rows;
+  const bool use_chain = e->chain && (H == 256 || H == 192 || H == 128) && N >= e->chain_min_rows;
   const size_t chain_blk = (size_t)c.inv_sublayers * 5 * H * H + (size_t)H * PQ;
   auto chain_w = [&](int blk, int sub, int which) -> const float* {   // which: 0 N1, 1 N2, 2 E1 (P|Q), 3 coordinate (sub ignored)
     const float* base = e->wchain + (size_t)blk * chain_blk;

@@ -197,6 +197,12 @@ class EGNNDynamics(nn.Module):
         fused HIP kernels."""
         if self.training and torch.is_grad_enabled():
             from .train_path import dynamics_forward_autograd
+            if not getattr(EGNNDynamics, "_warned_autograd", False):
+                EGNNDynamics._warned_autograd = True
+                import warnings
+                warnings.warn("EGNNDynamics.forward in training mode with autograd recording: the differentiable GPU "
+                              "path (train_path.py) is used; call .eval() or wrap the call in torch.no_grad() for the "
+                              "fused HIP kernels", stacklevel=2)
             return dynamics_forward_autograd(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
         with torch.no_grad():
             return self._forward_hip(xh_atoms, xh_residues, t, mask_atoms, mask_residues)

@@ -81,7 +81,7 @@ def make_dynamics(cfg, sd):
     from diffsbdd_amd.dynamics import EGNNDynamics
     m = EGNNDynamics(**cfg, device=dev())
     m.load_state_dict(sd)
-    return m
+    return m.eval()      # inference: the HIP kernels (training mode + autograd = the differentiable path, train_path.py)
 
 
 def edge_flips(ours, ref, n):
