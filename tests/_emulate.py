@@ -352,3 +352,59 @@ def stage_plan(n_stages, cone, levels=5):
             if min(radius[g + 1] + 1, lv) > radius[g]:
                 last = g
     return radius, [int(g <= last) for g in range(n_stages)]
+
+
+def node_chain_ranges(M, grid, do_mlp, projs, H=256, rows_max=96):
+    """Host model of node_chain_kernel's cost-weighted row split (csrc/node_chain.h).  projs: [(N columns, count or
+    None, first)].  Returns the list of (r0, tiles) pieces every workgroup walks, as [[(r0, tiles), ...] per workgroup],
+    plus (Mw, total cost, V)."""
+    w_mlp = 48 if do_mlp else 0
+    fst = [min(M, f) for _, _, f in projs]
+    cnt = [max(0, min(M - f, c) if c is not None else M - f) for (_, c, _), f in zip(projs, fst)]
+    wgt = [n * 16 // H for n, _, _ in projs]
+    Mw = M if do_mlp else 0
+    for f, c in zip(fst, cnt):
+        Mw = max(Mw, f + c)
+    if Mw <= 0:
+        return [[] for _ in range(grid)], (0, 0, 0)
+
+    def cost_to(r):
+        return w_mlp * min(r, Mw) + sum(w * max(0, min(r - f, c)) for w, f, c in zip(wgt, fst, cnt))
+
+    total = cost_to(Mw)
+    if total <= 0:
+        return [[] for _ in range(grid)], (Mw, 0, 0)
+    w_min = cost_to(1)
+    for f, c in zip(fst, cnt):
+        for r in (f, f + c):
+            if r < Mw:
+                w_min = min(w_min, cost_to(r + 1) - cost_to(r))
+    w_min = max(w_min, 1)
+    per_max = rows_max * w_min
+    V = -(-total // per_max)
+    V = -(-V // grid) * grid
+
+    def row_at(y):
+        lo, hi = 0, (Mw + 15) // 16
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if cost_to(mid * 16) < y:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo * 16
+
+    out = [[] for _ in range(grid)]
+    for wg in range(grid):
+        v = wg
+        while v < V:
+            r0 = 0 if v == 0 else row_at((total * v + V - 1) // V)
+            r1 = (Mw + 15) // 16 * 16 if v + 1 == V else row_at((total * (v + 1) + V - 1) // V)
+            nt, rs = (r1 - r0) // 16, r0
+            while nt > 0:
+                take = min(nt, rows_max // 16)
+                out[wg].append((rs, take))
+                rs += 16 * take
+                nt -= take
+            v += grid
+    return out, (Mw, total, V)

@@ -434,3 +434,50 @@ def test_stage_plan_model():
                 assert need <= radius[g] or ghost[g] == 1
                 assert radius[g + 1] >= radius[g] - 1          # the backward cone shrinks by one hop per stage
             assert not cone or ghost == sorted(ghost, reverse=True)       # ghosts only in the leading stages
+
+
+def test_node_chain_row_split_covers_every_tile_once_and_balances_cost():
+    """Host model of the row split of csrc/node_chain.h (tests/_emulate.node_chain_ranges mirrors the device code):
+    for the benchmark's stages and for random problems every 16-row tile of the work range belongs to exactly one piece,
+    no piece exceeds 96 rows, and no workgroup carries more than the mean cost plus one tile of the most expensive rows
+    (which is what makes 19.8 k rows a single round on 256 CUs)."""
+    rng = np.random.RandomState(0)
+    cases = [(19776, 256, True, [(512, 3639, 0), (512, 1472, 0), (512, None, 0)]),        # all rows, full chain
+             (18764 + 286, 256, True, [(512, 3639, 286), (512, 1472, 286), (512, None, 0)]),  # ghost rows in front
+             (11545, 256, True, [(512, 3639, 0), (512, 1472, 0)]), (3639, 256, True, [(512, 3639, 0), (512, 1472, 0)]),
+             (19776, 256, False, [(512, None, 0)]), (1888, 256, True, [(512, None, 0)]), (5, 256, True, []),
+             (40000, 256, True, [(512, None, 0)])]
+    for _ in range(40):
+        M = int(rng.randint(1, 30000))
+        projs = [(int(rng.choice([128, 256, 512, 768])), None if rng.rand() < 0.3 else int(rng.randint(0, M + 50)),
+                  int(rng.choice([0, 0, rng.randint(0, M + 1)]))) for _ in range(rng.randint(0, 4))]
+        cases.append((M, int(rng.choice([8, 104, 256, 304])), bool(rng.rand() < 0.7) or not projs, projs))
+    for M, grid, do_mlp, projs in cases:
+        pieces, (Mw, total, V) = em.node_chain_ranges(M, grid, do_mlp, projs)
+        if Mw == 0 or total == 0:
+            assert all(not p for p in pieces)
+            continue
+        n_tiles = (Mw + 15) // 16
+        seen = np.zeros(n_tiles, dtype=int)
+        for wg in pieces:
+            for r0, take in wg:
+                assert 1 <= take <= 6 and r0 % 16 == 0
+                seen[r0 // 16:r0 // 16 + take] += 1
+        assert (seen == 1).all(), (M, grid, do_mlp, projs)
+        assert V % grid == 0
+
+        def cost(r0, take):      # cost of the rows of a piece (same weights as the device code)
+            H, w_mlp = 256, 48 if do_mlp else 0
+            c = 0
+            for r in range(r0, min(r0 + 16 * take, Mw)):
+                c += w_mlp + sum((n * 16 // H) for n, cnt, f in projs
+                                 if min(M, f) <= r < min(M, f) + max(0, min(M - min(M, f), cnt) if cnt is not None else M - min(M, f)))
+            return c
+        if M <= 20000 and grid == 256:
+            loads = [sum(cost(*p) for p in wg) for wg in pieces]
+            w_max = (48 if do_mlp else 0) + sum(n * 16 // 256 for n, _, _ in projs)
+            # V / grid ranges per workgroup, each at most total / V plus one tile of the most expensive rows
+            assert max(loads) <= total / grid + (V // grid) * 16 * w_max + 1e-9
+    # the headline stage: one range per CU, 5 or 6 tiles each
+    pieces, (_, _, V) = em.node_chain_ranges(19776, 256, True, [(512, 3639, 0), (512, 1472, 0), (512, None, 0)])
+    assert V == 256 and all(len(p) == 1 for p in pieces) and {t for p in pieces for _, t in p} <= {1, 2, 3, 4, 5, 6}
