@@ -71,6 +71,9 @@ struct dsbdd_engine {
   bool frame = false;
   int64_t frame_nlig = 0, frame_npoc = 0, frame_batch = 0, frame_n3 = 0, frame_cap3 = 0;
   bool ghost_dirty = true;              // the ghost rows / ghost list segment must be (re)written before the next framed call
+  bool h0_pocket_valid = false;         // the pocket rows of h0 hold this chain's encoded pocket features (a frame fixes the
+                                        // pocket of a chain: coordinates up to translation AND features, which never change in
+                                        // pocket-conditioning mode) -> framed calls after the first run the ligand encoder only
   int64_t cap_tiles = 0;                // wave tiles (32 edges) of the edge capacity
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
@@ -261,6 +264,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
   e->drop_graphs();
   e->w2tp_ready = false;
   e->wchain_ready = false;
+  e->h0_pocket_valid = false;
   e->has_weights = true;
   return DSBDD_OK;
 }
@@ -317,6 +321,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->wchain_ready = false;
   e->frame = false;               // a pocket frame lives in the workspace
   e->ghost_dirty = true;
+  e->h0_pocket_valid = false;
   e->w2tp_ready = false;
   return DSBDD_OK;
 }
@@ -360,6 +365,7 @@ int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->drop_graphs();
   e->frame = false;
+  e->h0_pocket_valid = false;
   const int n3 = (int)n_frame, b3 = (int)batch_frame, N = (int)(n_lig + n_pocket);
   HIP_TRY(hipMemcpyAsync(e->xframe, x_frame, (size_t)n3 * 12, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(e->frame_rows, frame_rows, (size_t)n3 * 4, hipMemcpyDeviceToDevice, s));
@@ -392,6 +398,7 @@ int dsbdd_engine_clear_pocket_frame(dsbdd_engine* e) {
   if (!e) return fail(DSBDD_ERR_ARG, "null argument");
   if (e->frame) e->drop_graphs();
   e->frame = false;
+  e->h0_pocket_valid = false;
   return DSBDD_OK;
 }
 
@@ -660,7 +667,9 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         {xh_pocket + 3, dp, r, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0], 2 * r,
          W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1], J, e->h0 + (size_t)n_lig * JP, JP, (int)n_pocket}};
     if (mlp2_fits(enc[0]) && mlp2_fits(enc[1])) {
-      HIP_TRY(launch_mlp2(s, enc, 2));          // both node sets, both layers: one launch
+      // both node sets, both layers: one launch.  With a pocket frame the pocket's encoding is a constant of the chain:
+      // dsbdd_dynamics_forward computed it before this call (eagerly, so that replayed graphs find it too)
+      HIP_TRY(launch_mlp2(s, enc, (split0 && e->h0_pocket_valid) ? 1 : 2));
     } else {
       HIP_TRY(nl(s, xh_lig + 3, dl, a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0],
                  nullptr, 0, e->enc_tmp, LE, n_lig, 2 * a, 1));
@@ -1109,9 +1118,26 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
                         n_pocket == e->frame_npoc && batch == e->frame_batch;
     if (!framed) {
       e->ghost_dirty = true;
-    } else if (e->ghost_dirty) {
-      int rc = ghost_setup(e, s);
-      if (rc) return rc;
+      e->h0_pocket_valid = false;
+    } else {
+      if (e->ghost_dirty) {
+        int rc = ghost_setup(e, s);
+        if (rc) return rc;
+      }
+      if (!e->h0_pocket_valid) {
+        // the residue encoder on the chain's pocket features, once per chain (and again after a call the frame does not
+        // apply to overwrote the rows): dynamics.py:97
+        const dsbdd_config& c = e->cfg;
+        const int r = c.residue_nf, J = c.joint_nf, JP = pad4(J + 1);
+        const float* const* W = e->slots.data();
+        Mlp2Problem enc{xh_pocket + 3, 3 + r, r, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0], 2 * r,
+                        W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1], J, e->h0 + (size_t)n_lig * JP, JP,
+                        (int)n_pocket};
+        if (mlp2_fits(enc)) {
+          HIP_TRY(launch_mlp2(s, &enc, 1));
+          e->h0_pocket_valid = true;
+        }
+      }
     }
   }
 

@@ -149,6 +149,9 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* workspace, size_t bytes, 
  * The representatives are also the rows of the canonical (ligand-free) pocket network of the FORWARD CONE of the
  * ligand-output-only calls (eps_pocket == NULL, t_count == 1; see dsbdd_dynamics_forward): stage g then computes the
  * rows within min(g + 1, G - g) hops of a ligand atom only, the rest comes from the representative.
+ * A frame also fixes the pocket FEATURES of the calls it applies to (the feature columns of xh_pocket never change in
+ * pocket-conditioning mode): the residue encoder runs in the first such call only, later calls reuse its output.
+ * Set a new frame (or clear it) before calling with other pocket features.
  * The frame lives in the workspace; it is dropped by bind_workspace and by dsbdd_engine_clear_pocket_frame,
  * and only applies to calls with exactly (n_lig, n_pocket, batch).  edge_bound_frame = upper bound on the
  * frame's edge count (sum of squared pocket sizes of the frame samples + 32 per sample).  This function
