@@ -42,11 +42,14 @@ struct WaveLayout {
   static constexpr int B_BUF = BK * H;
   static constexpr int NV = (MODE == MODE_GCL) ? 1 : 2;
   static constexpr int VEC_PER = 7 * H;
-  static constexpr int VEC_OFF = 2 * B_BUF;
+  // the per-MLP vectors come first: every in-loop read of them is then `base register + 16-bit immediate`
+  // (behind the 64 KB of W2^T slices each read needed its own v_add)
+  static constexpr int VEC_OFF = 0;
   static constexpr int SCR_OFF = VEC_OFF + NV * VEC_PER;
   static constexpr int SCR_PER = 32 * 3;                   // per wave: trans[32][3]; phi[32] uses the same words earlier
   static constexpr int NEXT_OFF = SCR_OFF + 4 * SCR_PER;   // next tile index from the work queue
-  static constexpr int TOTAL = NEXT_OFF + 4;
+  static constexpr int B_OFF = (NEXT_OFF + 4 + 255) / 256 * 256;   // [2][BK][H], 1 KB aligned
+  static constexpr int TOTAL = B_OFF + 2 * B_BUF;
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -131,10 +134,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   static_assert(!BPERM || CT == 8 || CT == 4, "lane-grouped B reads need 4 or 8 column tiles");
   constexpr bool bperm = BPERM;
 
-  __shared__ float smem[L::TOTAL];
-  float* sB = smem;                         // [2][BK][H]
+  __shared__ __attribute__((aligned(1024))) float smem[L::TOTAL];
+  float* sB = smem + L::B_OFF;              // [2][BK][H]
   float* sV = smem + L::VEC_OFF;            // per MLP: wd, wd0, tab0..2, b2, w-out
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);     // wave index as a scalar: LDS-DMA bases stay in SGPRs
   const int half = lane >> 5, j = lane & 31;
   float* s_phi = smem + L::SCR_OFF + w * L::SCR_PER;   // [32]
   float* s_tr = s_phi;                                  // [32][3] (phi is consumed before trans is written)
@@ -213,13 +217,44 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #ifdef DSBDD_DIAG_NODMA
     return;   // DIAGNOSTIC ONLY: W2^T is never streamed
 #endif
-    const float* src = (bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H + t * 4;
+    // uniform slice base (SGPR pair) + this thread's 32-bit byte offset: the saddr form of global_load_lds, no
+    // per-lane 64-bit address arithmetic
+    const char* src = reinterpret_cast<const char*>((bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H);
+    const unsigned toff = (unsigned)t * 16u;
     float* dst = sB + buf * L::B_BUF + w * 256;          // wave-uniform
 #pragma unroll
     for (int i = 0; i < BI; ++i)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + kThreads * 4 * i),
+          (const __attribute__((address_space(1))) void*)(src + (size_t)(kThreads * 16 * i) + toff),
           (__attribute__((address_space(3))) void*)(dst + kThreads * 4 * i), 16, 0, 0);
+  };
+
+  // ---- the same stream through staging registers (default) ------------------------------------------------
+  // The compiler orders every LDS read behind ALL pending global_load_lds (it cannot tell the slice being filled
+  // from the slice being read), so a DMA burst costs each wave one exposed L2 round trip per K step.  Plain loads
+  // carry no such dependence: quarter g of the next slice is requested at the top of group g and written to LDS one
+  // group later (its latency sits behind the 32 MFMAs in between); nobody reads that buffer before the barrier.
+  constexpr int SG = (BI + 3) / 4;                         // staging registers (float4) per thread
+  f32x4 stg[SG];
+  auto stage_lo = [](int g) { return BI * g / 4; };
+  auto stage_load = [&](int q, int ks, int g) {
+#ifdef DSBDD_DIAG_NODMA
+    return;
+#endif
+    const char* src = reinterpret_cast<const char*>((bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H);
+    const unsigned toff = (unsigned)t * 16u;
+#pragma unroll
+    for (int i = stage_lo(g); i < stage_lo(g + 1); ++i)
+      stg[i - stage_lo(g)] = *reinterpret_cast<const f32x4*>(src + (size_t)(kThreads * 16 * i) + toff);
+  };
+  auto stage_store = [&](int buf, int g) {
+#ifdef DSBDD_DIAG_NODMA
+    return;
+#endif
+    float* dst = sB + buf * L::B_BUF + t * 4;
+#pragma unroll
+    for (int i = stage_lo(g); i < stage_lo(g + 1); ++i)
+      *reinterpret_cast<f32x4*>(dst + kThreads * 4 * i) = stg[i - stage_lo(g)];
   };
 
   // ---- this lane's edge (current unit) and the prefetched one (next tile) ----------------
@@ -229,16 +264,19 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   int my_prev = -1, nx_prev = -1;      // row of the edge just before this wave tile (wave-uniform)
   int my_wt = 0, nx_wt = 0;            // global wave-tile index
   float nx_d0 = 0.f, nxr[3] = {0.f, 0.f, 0.f}, nxc[3] = {0.f, 0.f, 0.f};
+  int vzero;                           // 0 in a vector register the compiler cannot see through
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  // fetch_idx only REQUESTS the next tile's indices; they are looked at one K step later (fetch_x: range check, then
+  // the coordinates), so that no wave waits for a global load at the top of a K step
   auto fetch_idx = [&](int tile) {
     const int e0 = tile * BMB + w * BMW, e = e0 + j;
     nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = p.wt_base + tile * 4 + w;
-    if (e < E) {
-      nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e];
-      if ((unsigned)nx_r >= (unsigned)p.n_nodes || (unsigned)nx_c >= (unsigned)p.n_nodes) { nx_r = -1; nx_c = 0; }
-    }
-    if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1];
+    if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
+    if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1 + vzero];   // (a per-lane load: nothing waits for it here)
   };
   auto fetch_x = [&]() {
+    // entries that do not name two rows of this call (stale workspace words after an overflowed build) are inactive
+    if ((unsigned)nx_r >= (unsigned)p.n_nodes || (unsigned)nx_c >= (unsigned)p.n_nodes) { nx_r = -1; nx_c = 0; }
     if (nx_r >= 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) { nxr[k] = p.x[3 * nx_r + k]; nxc[k] = p.x[3 * nx_c + k]; }
@@ -274,7 +312,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   };
 
   // prologue: first W2^T slice, first edge, first P/Q chunk
+#ifdef DSBDD_EDGE_DMA
   streamB(0, 0, 0);
+#else
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { stage_load(0, 0, g); stage_store(0, g); }
+#endif
   fetch_idx(cbase + kx);
   fetch_x();
   commit_edge();
@@ -284,7 +327,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 
   const float* Pp = p.mlp[qsel].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + 4 * half;
   const float* Qp = p.mlp[qsel].Q + (size_t)my_c * p.ldpq + 4 * half;
-  float4 pc = ld4(Pp), qc = ld4(Qp), pn = pc, qn4 = qc;
+  f32x4 pc = ldv4(Pp), qc = ldv4(Qp), pn = pc, qn4 = qc;
   float phi0 = 0.f, phi1 = 0.f;
 
   int li = kx, q = 0, next_li = 0, ticket = 0;
@@ -329,34 +372,44 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         if (st == 1 && has_next) fetch_x();
       }
       const bool last_unit_k = tile_ends && !has_next;     // final from st >= 2 (DYN) / st >= 0
-      if (more) streamB(q, kt + 1, (bslice + 1) & 1);
-      else if (!last_unit_k) streamB(qn, 0, (bslice + 1) & 1);   // continuous stream across units
+      (void)last_unit_k;
+      // the next W2^T slice: a continuous stream across units (the last K step of a workgroup re-reads slice 0 of
+      // its MLP: never used; unconditional, so that the compiler counts the loads in flight exactly)
+      const int sq = more ? q : qn, sks = more ? kt + 1 : 0;
+#ifdef DSBDD_EDGE_DMA
+      if (more || !last_unit_k) streamB(sq, sks, (bslice + 1) & 1);
+#endif
       const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
+      const float* vk = vq + kt * BK + 4 * half;           // this lane's k = kt*BK + 8g + 4*half + i
+      const float* vt = vk + (2 + my_ty) * H;
+      const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
+#ifndef DSBDD_EDGE_DMA
+        if (g > 0) stage_store((bslice + 1) & 1, g - 1);
+        stage_load(sq, sks, g);
+#endif
         if (g + 1 < BK / 8 || more) {                      // prefetch the next group's P/Q chunk
 #ifdef DSBDD_DIAG_NOGATHER
-          pn = make_float4(0.1f, 0.2f, 0.3f, 0.4f); qn4 = pn;   // DIAGNOSTIC ONLY
+          pn = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; qn4 = pn;   // DIAGNOSTIC ONLY
 #else
-          pn = ld4(Pp + kb + 8);
-          qn4 = ld4(Qp + kb + 8);
+          pn = ldv4(Pp + kb + 8);
+          qn4 = ldv4(Qp + kb + 8);
 #endif
         }
-        const float4 wd4 = *reinterpret_cast<const float4*>(vq + kb + 4 * half);
-        const float4 wz4 = *reinterpret_cast<const float4*>(vq + H + kb + 4 * half);
-        const float4 tb4 = *reinterpret_cast<const float4*>(vq + (2 + my_ty) * H + kb + 4 * half);
-        float a[4];
-#ifdef DSBDD_DIAG_NOSILU
-#define DSBDD_ACT(v) (v)   /* DIAGNOSTIC ONLY */
-#else
-#define DSBDD_ACT(v) silu(v)
+        // A operand: SiLU((P + Q) + d wd + d0 wd0 + tab), two values per instruction (explicit fma: the same
+        // arithmetic in every instantiation of the kernel)
+        const f32x4 wd4 = *reinterpret_cast<const f32x4*>(vk + 8 * g);
+        const f32x4 wz4 = *reinterpret_cast<const f32x4*>(vk + H + 8 * g);
+        const f32x4 tb4 = *reinterpret_cast<const f32x4*>(vt + 8 * g);
+        f32x2 alo = pk_fma(dz, wz4.xy, pk_fma(dd, wd4.xy, pc.xy + qc.xy)) + tb4.xy;
+        f32x2 ahi = pk_fma(dz, wz4.zw, pk_fma(dd, wd4.zw, pc.zw + qc.zw)) + tb4.zw;
+#ifndef DSBDD_DIAG_NOSILU
+        alo = silu2(alo);
+        ahi = silu2(ahi);
 #endif
-        a[0] = DSBDD_ACT(pc.x + qc.x + my_d * wd4.x + my_d0 * wz4.x + tb4.x);
-        a[1] = DSBDD_ACT(pc.y + qc.y + my_d * wd4.y + my_d0 * wz4.y + tb4.y);
-        a[2] = DSBDD_ACT(pc.z + qc.z + my_d * wd4.z + my_d0 * wz4.z + tb4.z);
-        a[3] = DSBDD_ACT(pc.w + qc.w + my_d * wd4.w + my_d0 * wz4.w + tb4.w);
-#undef DSBDD_ACT
+        const float a[4] = {alo.x, alo.y, ahi.x, ahi.y};
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -374,6 +427,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         pc = pn; qc = qn4;
       }
+#ifndef DSBDD_EDGE_DMA
+      stage_store((bslice + 1) & 1, BK / 8 - 1);
+#endif
       ++bslice;
 #ifdef DSBDD_DIAG_NOBARRIER
       __builtin_amdgcn_s_waitcnt(0x0f70);   // DIAGNOSTIC ONLY (racy): vmcnt(0) without the workgroup barrier
@@ -389,7 +445,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       const int r_n = tile_ends ? nx_r : my_r, c_n = tile_ends ? nx_c : my_c;
       Pp = p.mlp[qsel + qn].P + (size_t)(r_n < 0 ? 0 : r_n) * p.ldpq + 4 * half;
       Qp = p.mlp[qsel + qn].Q + (size_t)c_n * p.ldpq + 4 * half;
-      pc = ld4(Pp); qc = ld4(Qp);
+      pc = ldv4(Pp); qc = ldv4(Qp);
     }
 
     // ================= wave-private epilogue =================
@@ -404,21 +460,27 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     } else
 #endif
     if (MODE == MODE_GCL) {
-      // messages m = SiLU(acc)   (egnn_new.py:18-19; the bias is already in the accumulators)
+      // messages m = SiLU(acc)   (egnn_new.py:18-19; the bias is already in the accumulators), register pairs
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = silu(acc[c][r]);
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 m2 = silu2(f32x2{acc[c][r], acc[c][r + 1]});
+          acc[c][r] = m2.x; acc[c][r + 1] = m2.y;
+        }
       if (p.attention) {   // att = sigmoid(w_a . m + b_a); a half-wave holds complete rows
-        float part[16];
+        f32x2 part2[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] = 0.f;
+        for (int r = 0; r < 8; ++r) part2[r] = splat2(0.f);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const float aw = vq[6 * H + feat(c)];
+          const f32x2 aw = splat2(vq[6 * H + feat(c)]);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) part[r] += acc[c][r] * aw;
+          for (int r = 0; r < 8; ++r) part2[r] = pk_fma(f32x2{acc[c][2 * r], acc[c][2 * r + 1]}, aw, part2[r]);
         }
+        float part[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { part[2 * r] = part2[r].x; part[2 * r + 1] = part2[r].y; }
         // reduce-scatter over the half-wave: lane j ends with the dot product of accumulator register j >> 1,
         // takes ONE sigmoid, and the 16 gates of the half come back through 64 bytes of LDS (broadcast reads)
         const float gate = sigmoidf_fast(reduce16_half_wave(part, j) + att_b);
@@ -449,7 +511,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       for (int c = 0; c < CT; ++c) sum[c] = 0.f;
       int cur = -1;
       const int row0 = __builtin_amdgcn_readlane(my_r, 0);
-      bool to_head = row0 >= 0 && row0 == my_prev;
+      bool to_head = row0 >= 0 && row0 == __builtin_amdgcn_readfirstlane(my_prev);
       auto flush = [&]() {
         if (cur >= 0) {
           float* dst = to_head ? p.agg_head + (size_t)my_wt * H : p.agg + (size_t)cur * H;
@@ -482,15 +544,18 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       flush();
     } else {
       // scalar head: phi = w3 . SiLU(acc)   (egnn_new.py:80-92; the bias is already in the accumulators)
-      float part[16];
+      f32x2 part2[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[r] = 0.f;
+      for (int r = 0; r < 8; ++r) part2[r] = splat2(0.f);
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const float wv = vq[6 * H + feat(c)];
+        const f32x2 wv = splat2(vq[6 * H + feat(c)]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] += silu(acc[c][r]) * wv;
+        for (int r = 0; r < 8; ++r) part2[r] = pk_fma(silu2(f32x2{acc[c][2 * r], acc[c][2 * r + 1]}), wv, part2[r]);
       }
+      float part[16];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { part[2 * r] = part2[r].x; part[2 * r + 1] = part2[r].y; }
       // lane j of a half ends with the total of accumulator register j >> 1 = edge mfma_row(j >> 1, lane)
       s_phi[mfma_row(j >> 1, lane)] = reduce16_half_wave(part, j);
       wave_lds_fence();
@@ -532,7 +597,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           float* xa = p.xagg + pop * p.xagg_stride;
           float* xh = p.xagg_head + pop * p.xhead_stride;
           const int row0 = __builtin_amdgcn_readlane(my_r, 0);
-          bool to_head = row0 >= 0 && row0 == my_prev;
+          bool to_head = row0 >= 0 && row0 == __builtin_amdgcn_readfirstlane(my_prev);
           int cur = -1;
           float sum = 0.f;
           auto put = [&]() {
