@@ -89,6 +89,11 @@ struct EdgeArgs {
   // cross-product MLP of a tile (twice as many, half as long work items: better balance when
   // the masked edge prefix is only a few tiles per CU); the two terms of trans are linear
   int pass_split;
+  // MODE_GCL, optional second edge list of the same stage (e_count_b != nullptr): its 128-edge tiles follow the first
+  // list's in the launch's tile space, its messages go to agg_b / agg_head_b.  One launch instead of two when a stage
+  // walks two lists (block 0 of a framed call: ligand-endpoint edges + the frame's pocket-pocket edges).
+  const int* erow_b; const int* ecol_b; const float* ed0_b; const int* e_count_b; int e_cap_b; int wt_base_b;
+  float* agg_b; float* agg_head_b;
 };
 
 enum { MODE_GCL = 0, MODE_COORD = 1 };

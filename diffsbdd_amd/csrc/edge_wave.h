@@ -175,7 +175,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #endif
   DSBDD_TS();                                            // mark 0: kernel entry (after the vector loads were issued)
   const int E = min(*p.e_count, p.e_cap);
-  const int ntiles = (E + BMB - 1) / BMB;
+  const int nt_a = (E + BMB - 1) / BMB;
+  const int E_b = (MODE == MODE_GCL && p.e_count_b) ? min(*p.e_count_b, p.e_cap_b) : 0;   // second list of the stage
+  const int ntiles = nt_a + (E_b + BMB - 1) / BMB;
   const int xcd = blockIdx.x & 7;
   const int kx = split ? (blockIdx.x >> 4) : (blockIdx.x >> 3);
   const int gx = split ? (gridDim.x >> 4) : (gridDim.x >> 3);
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   };
   if (kx >= csize) { check_out(); return; }
 
+#ifdef DSBDD_EDGE_DMA   // (the round-1/2 stream, kept for A/B timing)
   // ---- W2^T slice streaming: direct global -> LDS DMA (global_load_lds, 16 B per lane,
   // LDS destination = wave-uniform base + lane*16), no staging registers.  The DMA is
   // tracked by vmcnt; the __syncthreads() that ends a K step drains it (vmcnt(0)) and
@@ -228,8 +231,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           (const __attribute__((address_space(1))) void*)(src + (size_t)(kThreads * 16 * i) + toff),
           (__attribute__((address_space(3))) void*)(dst + kThreads * 4 * i), 16, 0, 0);
   };
+#endif
 
-  // ---- the same stream through staging registers (default) ------------------------------------------------
+  // ---- W2^T slice stream through staging registers --------------------------------------------------------
   // The compiler orders every LDS read behind ALL pending global_load_lds (it cannot tell the slice being filled
   // from the slice being read), so a DMA burst costs each wave one exposed L2 round trip per K step.  Plain loads
   // carry no such dependence: quarter g of the next slice is requested at the top of group g and written to LDS one
@@ -263,16 +267,22 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   int nx_r = -1, nx_c = 0;
   int my_prev = -1, nx_prev = -1;      // row of the edge just before this wave tile (wave-uniform)
   int my_wt = 0, nx_wt = 0;            // global wave-tile index
+  bool my_lb = false, nx_lb = false;   // the tile belongs to the stage's second list
   float nx_d0 = 0.f, nxr[3] = {0.f, 0.f, 0.f}, nxc[3] = {0.f, 0.f, 0.f};
   int vzero;                           // 0 in a vector register the compiler cannot see through
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   // fetch_idx only REQUESTS the next tile's indices; they are looked at one K step later (fetch_x: range check, then
   // the coordinates), so that no wave waits for a global load at the top of a K step
   auto fetch_idx = [&](int tile) {
-    const int e0 = tile * BMB + w * BMW, e = e0 + j;
-    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = p.wt_base + tile * 4 + w;
-    if (e < E) { nx_r = p.erow[e]; nx_c = p.ecol[e]; nx_d0 = p.ed0[e]; }
-    if (e0 > 0 && e0 < E) nx_prev = p.erow[e0 - 1 + vzero];   // (a per-lane load: nothing waits for it here)
+    const bool lb = MODE == MODE_GCL && tile >= nt_a;     // a tile of the second list (wave-uniform)
+    const int tl = lb ? tile - nt_a : tile, El = lb ? E_b : E;
+    const int* er = lb ? p.erow_b : p.erow;
+    const int* ec = lb ? p.ecol_b : p.ecol;
+    const float* ed = lb ? p.ed0_b : p.ed0;
+    const int e0 = tl * BMB + w * BMW, e = e0 + j;
+    nx_r = -1; nx_c = 0; nx_d0 = 0.f; nx_prev = -1; nx_wt = (lb ? p.wt_base_b : p.wt_base) + tl * 4 + w; nx_lb = lb;
+    if (e < El) { nx_r = er[e]; nx_c = ec[e]; nx_d0 = ed[e]; }
+    if (e0 > 0 && e0 < El) nx_prev = er[e0 - 1 + vzero];   // (a per-lane load: nothing waits for it here)
   };
   auto fetch_x = [&]() {
     // entries that do not name two rows of this call (stale workspace words after an overflowed build) are inactive
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   };
   auto commit_edge = [&]() {
     my_r = nx_r; my_c = nx_c; my_d0 = nx_d0; my_d = 0.f; my_ty = 0;
-    my_prev = nx_prev; my_wt = nx_wt;
+    my_prev = nx_prev; my_wt = nx_wt; my_lb = nx_lb;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { xr[k] = nxr[k]; xc[k] = nxc[k]; }
     if (my_r >= 0) {
@@ -506,38 +516,53 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       // when its row continues from the previous wave tile, every other segment is the start of
       // its row and goes to agg[row]; plain stores, each address written by exactly one wave
       static_assert(CT % 2 == 0, "column tiles are exchanged in pairs");
-      float sum[CT];
+      // Even and odd rows of a half run in separate sums (the two words of a register pair) that meet at the flush:
+      // written as sum[c] += acc[c][r] the compiler pairs the adds ACROSS column tiles, whose accumulators are 16
+      // registers apart -- two v_mov per packed add.
+      f32x2 sum2[CT];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) sum[c] = 0.f;
+      for (int c = 0; c < CT; ++c) sum2[c] = splat2(0.f);
       int cur = -1;
       const int row0 = __builtin_amdgcn_readlane(my_r, 0);
       bool to_head = row0 >= 0 && row0 == __builtin_amdgcn_readfirstlane(my_prev);
       auto flush = [&]() {
         if (cur >= 0) {
-          float* dst = to_head ? p.agg_head + (size_t)my_wt * H : p.agg + (size_t)cur * H;
+          float* dst = to_head ? (my_lb ? p.agg_head_b : p.agg_head) + (size_t)my_wt * H
+                               : (my_lb ? p.agg_b : p.agg) + (size_t)cur * H;
 #pragma unroll
           for (int c = 0; c < CT / 2; ++c) {
-            const float tot = pair_sum_halves(sum[c], sum[c + CT / 2]);     // half 0: tile c, half 1: tile c + CT/2
+            // half 0: tile c, half 1: tile c + CT/2
+            const float tot = pair_sum_halves(sum2[c].x + sum2[c].y, sum2[c + CT / 2].x + sum2[c + CT / 2].y);
             dst[feat(c + half * (CT / 2))] = tot * inv_norm;
           }
           to_head = false;
         }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) sum2[c] = splat2(0.f);
       };
 #pragma unroll
       for (int gb = 0; gb < 8; ++gb) {
         const int hh = gb & 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rn = __builtin_amdgcn_readlane(my_r, 4 * gb + i);
-          if (rn != cur) {                                 // scalar compare / branch
+        for (int ip = 0; ip < 4; ip += 2) {
+          const int k = 4 * (gb >> 1) + ip;
+          const int rn0 = __builtin_amdgcn_readlane(my_r, 4 * gb + ip);
+          const int rn1 = __builtin_amdgcn_readlane(my_r, 4 * gb + ip + 1);
+          if (rn0 != cur) {                                // scalar compare / branch
             flush();
-            cur = rn;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) sum[c] = 0.f;
+            cur = rn0;
           }
           if (half == hh) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) sum[c] += acc[c][4 * (gb >> 1) + i];
+            for (int c = 0; c < CT; ++c) sum2[c].x += acc[c][k];
+          }
+          if (rn1 != rn0) {
+            flush();
+            cur = rn1;
+          }
+          if (half == hh) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) sum2[c].y += acc[c][k + 1];
           }
         }
       }

@@ -883,8 +883,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         EdgeArgs a3 = ea;
         a3.erow = e->erow3; a3.ecol = e->ecol3; a3.ed0 = e->ed03; a3.e_count = e->row_ptr3 + e->frame_n3;
         a3.agg = e->aggB; a3.agg_head = e->agg_headB; a3.e_cap = (int)e->cap_edges; a3.wt_base = 0;   // (x: the ghost rows of e->x)
-        HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound));
-        HIP_TRY(launch_edge(e, s, MODE_GCL, a3, e->frame_cap3));
+        // one launch: (B)'s few tiles ride behind (A)'s in the same persistent grid instead of paying a launch of
+        // single-occupancy tile latency of their own (45 us for 35 tiles)
+        a2.erow_b = a3.erow; a2.ecol_b = a3.ecol; a2.ed0_b = a3.ed0; a2.e_count_b = a3.e_count; a2.e_cap_b = a3.e_cap;
+        a2.wt_base_b = a3.wt_base; a2.agg_b = a3.agg; a2.agg_head_b = a3.agg_head;
+        HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound + ((e->frame_cap3 + 127) / 128) * 128));
         hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + n_ghost + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
                            (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,
