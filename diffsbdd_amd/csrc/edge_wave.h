@@ -617,6 +617,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         }
         if (half == 0) { s_tr[3 * j] = tx; s_tr[3 * j + 1] = ty; s_tr[3 * j + 2] = tz; }
         wave_lds_fence();
+        // all 32 values of this lane's component first (independent LDS reads, one wait), then the scalar walk over
+        // the rows: read inside the walk, every step sat out an LDS round trip
+        float trv[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) trv[e] = s_tr[3 * e + (lane < 3 ? lane : 0)];
         if (lane < 3) {
           const int pop = split ? qsel : 0;
           float* xa = p.xagg + pop * p.xagg_stride;
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
               cur = rn;
               sum = 0.f;
             }
-            sum += s_tr[3 * e + lane];
+            sum += trv[e];
           }
           put();
         }
