@@ -210,7 +210,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < N; ++i) perm[i] = i;
   std::shuffle(perm.begin() + n_lig, perm.end(), g);      // gathered row lists: ligand rows first, then pocket rows in level order
   int* d_rows = dev(perm);
-  std::vector<int> mcounts = {N, 11545, 3639, n_lig};
+  std::vector<int> mcounts = {N, 11545, 3639, n_lig, 16};
   int* d_mcounts = dev(mcounts);
   // packed weights of the row-owning chain kernel (node_chain.h)
   auto pack = [&](const float* WT, int ldw, int K, int Ncols) {
@@ -274,6 +274,13 @@ int main(int argc, char** argv) {
     printf("| **node_chain: MLP + 3 projections, one launch** | %d | %.1f | %.1f | %.3f | |\n", M, uc, (f1 + f2 + f3) / uc / 1e6, (f1 + f2 + f3) / uc / 1e6 / 157.3);
     printf("| node_chain: MLP only | %d | %.1f | %.1f | %.3f | |\n", M, um, (f1 + f2) / um / 1e6, (f1 + f2) / um / 1e6 / 157.3);
     printf("| node_chain: projections only (h from global) | %d | %.1f | %.1f | %.3f | |\n", M, up, f3 / up / 1e6, f3 / up / 1e6 / 157.3);
+    if (mi == 0) {   // the launch's fixed cost: 16 rows (one row tile on one workgroup, every other workgroup only computes the split)
+      NodeChainArgs ct = cm; ct.m_count = d_mcounts + 4;
+      const float ut = time_us([&] { (void)launch_node_chain(0, ct, H, n_cu); }, reps);
+      NodeChainArgs c3 = ca; c3.m_count = d_mcounts + 4;
+      const float ut3 = time_us([&] { (void)launch_node_chain(0, c3, H, n_cu); }, reps);
+      printf("| node_chain: 16 rows (fixed cost), MLP only / MLP + 3 projections | 16 | %.1f / %.1f | | | |\n", ut, ut3);
+    }
   }
 #endif
   return 0;
