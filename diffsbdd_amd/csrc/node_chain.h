@@ -91,21 +91,16 @@ __device__ __forceinline__ void chain_mfma_group(f32x4 (&acc)[RT][CT], const flo
 }
 
 // K loop with the row operand in LDS panels and the weights streamed from L2.
-//   * weights: a ring of four register sets, every group's 1-KiB pieces requested FOUR groups (4 x RT x CT x 4 MFMAs)
-//     ahead -- an L2 round trip under load is longer than one group of MFMAs, most of all when a workgroup holds few rows;
-//   * rows: two register sets, one group ahead (LDS latency);
-//   * no conditional loads (the last groups re-request the final group: valid addresses, unused values), so every
-//     s_waitcnt the compiler inserts sits one whole MFMA block behind the loads it waits for.
-// NG must be a multiple of 4.  CHUNKED (stage 1): the row operand of group g lives in chunk buffer (g / 4) & 1, which
-// another wave's LDS-DMA fills: `next_chunk(c)` issues the DMA of chunk c + 1 at the start of chunk c, and the chunk ends
-// with s_waitcnt vmcnt(4 * CT) -- the DMA is older than exactly the 4 * CT weight requests of this chunk, which stay in
-// flight -- and a workgroup barrier.
-// Two register sets alternate, the last pair of groups is peeled: no conditional load inside the loop, so every
-// s_waitcnt the compiler inserts sits one whole MFMA block behind the loads it waits for.  (A ring of four sets with the
-// weights requested four groups ahead measured 10 - 15 % SLOWER at every row count, profiles/r3_node_chain.md: the L2
-// round trip is not what the loop waits for.)  NG must be even.
+// Two register sets alternate, one group ahead (weights: an L2 round trip; rows: LDS latency), the last pair of groups is
+// peeled: no conditional load inside the loop, so every s_waitcnt the compiler inserts sits one whole MFMA block behind
+// the loads it waits for.  NG must be even.  Measured and not adopted (profiles/README.md): a ring of four sets with the
+// weights requested three or four groups ahead (10 - 15 % slower at every row count, also for one row tile -- the loop is
+// not waiting for the L2: a 16-row launch runs at the MFMA time of one row tile on one CU), the first group of a loop
+// requested before the preceding epilogue, the L2 warmed, a k-group-major weight layout, de-phased waves.
 // CHUNKED (stage 1): the row operand of group g lives in chunk buffer (g / 4) & 1, which the workgroup's LDS-DMA fills;
-// `next_chunk(c)` issues the DMA of chunk c + 1 at the start of chunk c and every chunk ends with a workgroup barrier.
+// `next_chunk(c)` issues the DMA of chunk c + 1 at the start of chunk c and every chunk ends with a workgroup barrier
+// (staging registers instead of the DMA, the remedy of the edge kernels, measured slower here: rows are 16-byte pieces of
+// 64 different cache lines per instruction).
 template <int RT, int CT, bool CHUNKED, class XOf, class Hook>
 __device__ __forceinline__ void chain_kloop(f32x4 (&acc)[RT][CT], XOf&& x_of, const float* wp, size_t wstride, int NG,
                                             Hook&& next_chunk) {
