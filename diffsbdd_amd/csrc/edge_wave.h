@@ -17,13 +17,20 @@
 //     k in {8g + 4h .. 8g + 4h + 3} of every group of 8 (any k pairing is legal as
 //     long as B uses the same one).  No LDS, no transpose, no barrier for A.
 //   * only W2^T goes through LDS (K slices of 32, double buffered, a continuous
-//     stream across tiles): one workgroup barrier per 128 MFMAs per wave.
-//   * the epilogue is wave-private: attention dot by lane shuffles inside each
-//     half-wave (a half-wave holds complete rows), accumulators scaled in place,
-//     segmented row sums walk the rows in edge order with the running sum passed
-//     as a baton between the two half-waves (rows alternate between them in groups
-//     of 4 in the MFMA accumulator layout); one plain store per (row segment,
-//     feature) following the aggregation protocol of edge_mlp.h (no atomics).
+//     stream across tiles): one workgroup barrier per 128 MFMAs per wave.  The slices
+//     travel global -> staging registers -> LDS, a quarter per MFMA group (an LDS-DMA
+//     stream makes the compiler drain it in front of every LDS read, see below).
+//   * the epilogue is wave-private: attention dot as a reduce-scatter over each
+//     half-wave (v_permlane16_swap + DPP; a half-wave holds complete rows), one
+//     sigmoid per row, accumulators scaled in place; segmented row sums: every half
+//     adds up its rows of the running segment (even / odd rows in the two words of a
+//     register pair), the halves meet through v_permlane32_swap when a segment ends;
+//     one plain store per (row segment, feature) following the aggregation protocol
+//     of edge_mlp.h (no atomics).
+//   * vector arithmetic is written on two-element vectors (v_pk_*_f32): beside an
+//     fp32 MFMA stream no vector instruction is free (tools/mfma_shadow.hip).
+//   * a stage that walks two edge lists (block 0 of a framed call) runs them in one
+//     launch: the second list's tiles follow the first's (EdgeArgs::*_b).
 //   * tiles are assigned round-robin inside each XCD's contiguous tile range (a per-XCD work
 //     queue exists behind -DDSBDD_DYNAMIC_TILES; it measured slower).
 //
