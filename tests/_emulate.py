@@ -408,3 +408,46 @@ def node_chain_ranges(M, grid, do_mlp, projs, H=256, rows_max=96):
                 nt -= take
             v += grid
     return out, (Mw, total, V)
+
+
+def edge_tile_walk(E_a, E_b, grid, split=False):
+    """Host model of edge_wave_kernel's static tile assignment (csrc/edge_wave.h): the launch's tile space is the first
+    list's 128-edge tiles followed by the second list's; every XCD (blockIdx & 7) owns a contiguous range, walked
+    round-robin by its workgroups.  Returns, per workgroup, the list of (list id, local tile, first edge, edges) it
+    processes (split: the coordinate stage's one-workgroup-per-(tile, MLP) form; then also the MLP index)."""
+    nt_a, nt_b = -(-E_a // 128), -(-E_b // 128)
+    ntiles = nt_a + nt_b
+    out = []
+    for b in range(grid):
+        xcd = b & 7
+        kx = (b >> 4) if split else (b >> 3)
+        gx = (grid >> 4) if split else (grid >> 3)
+        qsel = ((b >> 3) & 1) if split else 0
+        tq, tr = divmod(ntiles, 8)
+        csize = tq + (1 if xcd < tr else 0)
+        cbase = xcd * (tq + 1) if xcd < tr else tr * (tq + 1) + (xcd - tr) * tq
+        items = []
+        li = kx
+        while li < csize:
+            tile = cbase + li
+            lb = tile >= nt_a
+            tl = tile - nt_a if lb else tile
+            El = E_b if lb else E_a
+            e0 = tl * 128
+            items.append((int(lb), tl, e0, max(0, min(128, El - e0)), qsel))
+            li += gx
+        out.append(items)
+    return out
+
+
+def slice_stage_schedule(H, BK=32, threads=256):
+    """Host model of the W2^T slice stream of csrc/edge_wave.h: a slice is BK x H floats = BI float4 per thread; MFMA group
+    g of a K step requests the float4 indices [BI g / 4, BI (g + 1) / 4) and writes them to LDS one group later (the last
+    quarter in front of the barrier).  Returns [(g_load, g_store, float4 index)] for one thread."""
+    BI = BK * (H // 4) // threads
+    lo = lambda g: BI * g // 4
+    ops = []
+    for g in range(4):
+        for i in range(lo(g), lo(g + 1)):
+            ops.append((g, g + 1, i))        # stored at the top of group g + 1; g + 1 == 4: in front of the barrier
+    return BI, (BI + 3) // 4, ops

@@ -481,3 +481,46 @@ def test_node_chain_row_split_covers_every_tile_once_and_balances_cost():
     # the headline stage: one range per CU, 5 or 6 tiles each
     pieces, (_, _, V) = em.node_chain_ranges(19776, 256, True, [(512, 3639, 0), (512, 1472, 0), (512, None, 0)])
     assert V == 256 and all(len(p) == 1 for p in pieces) and {t for p in pieces for _, t in p} <= {1, 2, 3, 4, 5, 6}
+
+
+def test_edge_tile_walk_covers_both_lists_once_and_slice_staging_covers_a_slice_once():
+    """Host models of two schedules of csrc/edge_wave.h (tests/_emulate mirrors the device arithmetic).
+    (1) The static tile walk with a second edge list behind the first (block 0 of a framed call runs both lists in one
+    launch): every 128-edge tile of either list is processed by exactly one workgroup -- exactly one (tile, MLP) pair in
+    the coordinate stage's split form -- for any edge counts and any grid that is a multiple of 8 (16); the XCD ranges
+    differ by at most one tile.
+    (2) The W2^T slice stream through staging registers: over the four MFMA groups of a K step a thread requests every
+    float4 of its share of the slice exactly once, never holds more than ceil(BI / 4) at a time, and every request is
+    written one group later."""
+    rng = np.random.RandomState(1)
+    cases = [(61440, 4480, 512), (61441, 0, 512), (0, 4480, 512), (354071, 0, 512), (100, 50, 8), (0, 0, 512), (127, 129, 64)]
+    cases += [(int(rng.randint(0, 400000)), int(rng.choice([0, rng.randint(0, 20000)])), int(8 * rng.randint(1, 65))) for _ in range(30)]
+    for E_a, E_b, grid in cases:
+        walk = em.edge_tile_walk(E_a, E_b, grid)
+        nt = [-(-E_a // 128), -(-E_b // 128)]
+        seen = [np.zeros(nt[0], int), np.zeros(nt[1], int)]
+        edges = [0, 0]
+        per_xcd = np.zeros(8, int)
+        for b, items in enumerate(walk):
+            for lb, tl, e0, n, _ in items:
+                seen[lb][tl] += 1
+                edges[lb] += n
+                per_xcd[b & 7] += 1
+                assert e0 % 128 == 0 and 0 < n <= 128
+        assert (seen[0] == 1).all() and (seen[1] == 1).all(), (E_a, E_b, grid)
+        assert edges == [E_a, E_b]
+        assert per_xcd.max() - per_xcd.min() <= 1
+        if grid % 16 == 0:       # coordinate stage: one workgroup per (tile, MLP)
+            pairs = {}
+            for items in em.edge_tile_walk(E_a, 0, grid, split=True):
+                for lb, tl, e0, n, q in items:
+                    pairs[(tl, q)] = pairs.get((tl, q), 0) + 1
+            assert sorted(pairs) == [(t, q) for t in range(nt[0]) for q in (0, 1)] and set(pairs.values()) <= {1}
+    for H in (64, 128, 192, 256):
+        BI, SG, ops = em.slice_stage_schedule(H)
+        assert BI == 32 * (H // 4) // 256
+        assert sorted(i for _, _, i in ops) == list(range(BI))
+        for g in range(4):
+            held = [i for gl, gs, i in ops if gl <= g < gs]
+            assert len(held) <= SG
+        assert all(gs == gl + 1 for gl, gs, _ in ops)
