@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSBDD_LIB: load another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("DSBDD_LIB") or os.path.join(_HERE, "libdiffsbdd_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # error / status codes (include/diffsbdd_hip.h)
 OK, ERR_ARG, ERR_STATE, ERR_CAPACITY, ERR_LAUNCH = 0, -1, -2, -3, -4
@@ -43,6 +43,24 @@ class Config(C.Structure):
         "has_cutoff_interaction")] + [(n, C.c_float) for n in (
             "cutoff_ligand", "cutoff_pocket", "cutoff_interaction",
             "norm_constant", "normalization_factor", "coords_range")]
+
+
+class TrainGraph(C.Structure):
+    """struct dsbdd_train_graph"""
+    _fields_ = [(n, C.c_void_p) for n in ("erow", "ecol", "ed0", "row_ptr", "deg", "rev", "node_batch", "lig_off",
+                                          "poc_off")] + [(n, C.c_int64) for n in ("n_lig", "n_nodes", "n_edges", "batch")]
+
+
+class TrainMlp(C.Structure):
+    """struct dsbdd_train_mlp"""
+    _fields_ = [("P", C.c_void_p), ("Q", C.c_void_p), ("ldpq", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("wd", "wd0", "tab", "W2", "W2T", "b2", "head", "head_b")]
+
+
+class TrainMlpGrad(C.Structure):
+    """struct dsbdd_train_mlp_grad"""
+    _fields_ = [("dP", C.c_void_p), ("dQ", C.c_void_p), ("ldo", C.c_int32), ("d_vec", C.c_void_p), ("d_W2", C.c_void_p),
+                ("gd0", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -91,6 +109,20 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "dsbdd_bond_orders": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.c_float, C.c_float,
                                     C.c_float, _I32, _P]),
+    # training-step building blocks (struct arguments are passed by pointer: ctypes.byref / arrays)
+    "dsbdd_train_scratch_bytes": (C.c_size_t, [_I32, _I64, _I64]),
+    "dsbdd_train_wgrad_scratch_bytes": (C.c_size_t, [_I64, _I64, _I64]),
+    "dsbdd_train_edge_rev": (C.c_int, [_P, _P, _P]),
+    "dsbdd_train_sample_mean": (C.c_int, [_P, _P, _P, _P]),
+    "dsbdd_train_gcl_forward": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, C.c_size_t]),
+    "dsbdd_train_gcl_backward": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, _P, _P, C.c_size_t]),
+    "dsbdd_train_coord_forward": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _F, _F, _I32, _F, _P, _P,
+                                            C.c_size_t]),
+    "dsbdd_train_coord_backward": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _I64, _F, _F, _I32, _F, _P, _P, _P,
+                                             _P, _P, C.c_size_t]),
+    "dsbdd_train_radial_backward": (C.c_int, [_P, _P, _P, _P, _P]),
+    "dsbdd_train_wgrad": (C.c_int, [_P, _P, _I32, _P, _I32, _I64, _I32, _I32, _P, _P, C.c_size_t]),
+    "dsbdd_train_colsum": (C.c_int, [_P, _P, _I32, _I64, _I32, _P, _P, C.c_size_t]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 #include "molecule.h"
 #include "node_chain.h"
 #include "node_linear.h"
+#include "train.h"
 
 using namespace dsbdd;
 
@@ -1372,6 +1373,330 @@ int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig, con
   HIP_TRY(hipGetLastError());
   return build_edges_impl(s, x, (int)n_lig, N, B, *cfg, node_batch, lig_off, poc_off, deg, row_ptr, edge_row,
                           edge_col, edge_d0, edge_capacity, status);
+}
+
+}  // extern "C"
+
+// ---- training-step building blocks (csrc/train.h) ---------------------------------------------------------------
+static int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+static hipError_t launch_edge_plain(int H, hipStream_t s, int mode, const EdgeArgs& a, int64_t edge_bound) {
+  int64_t tiles = (edge_bound + 127) / 128;
+  int64_t g = tiles < 2LL * device_cus() ? tiles : 2LL * device_cus();
+  int grid = (int)((g + 7) / 8 * 8);
+  if (grid < 8) grid = 8;
+  switch (H) {
+    case 64: return launch_wave_t<64>(s, mode, a, grid);
+    case 128: return launch_wave_t<128>(s, mode, a, grid);
+    case 192: return launch_wave_t<192>(s, mode, a, grid);
+    case 256: return launch_wave_t<256>(s, mode, a, grid);
+  }
+  return hipErrorInvalidValue;
+}
+
+// out[i] = sum_p part[p * stride + i] in a fixed order (two levels above 64 parts); tmp: ceil(n_part / 32) * width floats
+static hipError_t reduce_parts(hipStream_t s, const float* part, int n_part, size_t stride, int width, float* out,
+                               float* tmp) {
+  const int bx = (width + 255) / 256;
+  if (n_part <= 64) {
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(bx, 1), dim3(256), 0, s, part, n_part, stride, width,
+                       n_part > 0 ? n_part : 1, out, (size_t)0);
+    return hipGetLastError();
+  }
+  const int groups = (n_part + 31) / 32;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(bx, groups), dim3(256), 0, s, part, n_part, stride, width, 32, tmp,
+                     (size_t)width);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(bx, 1), dim3(256), 0, s, (const float*)tmp, groups, (size_t)width,
+                     width, groups, out, (size_t)0);
+  return hipGetLastError();
+}
+
+struct WgradPlan { int chunks, kc; size_t floats; };
+static WgradPlan wgrad_plan(int64_t K, int64_t M, int64_t N) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int64_t chunks = (K + 255) / 256;
+  const int64_t cap = 768 / tiles > 1 ? 768 / tiles : 1;
+  if (chunks > cap) chunks = cap;
+  if (chunks < 1) chunks = 1;
+  int64_t kc = ((K + chunks - 1) / chunks + 15) / 16 * 16;
+  if (kc < 16) kc = 16;
+  chunks = (K + kc - 1) / kc;
+  if (chunks < 1) chunks = 1;
+  WgradPlan p{(int)chunks, (int)kc, 0};
+  p.floats = (size_t)chunks * M * N + (size_t)((chunks + 31) / 32) * M * N;
+  return p;
+}
+
+static int wgrad_impl(hipStream_t s, const float* A, int lda, const float* B, int ldb, int64_t K, int M, int N, float* C,
+                      float* scratch) {
+  const WgradPlan pl = wgrad_plan(K, M, N);
+  WgradArgs a{A, lda, B, ldb, (int)K, M, N, scratch, pl.kc};
+  hipLaunchKernelGGL(wgrad_kernel, dim3((M + 127) / 128, (N + 127) / 128, pl.chunks), dim3(kThreads), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(reduce_parts(s, scratch, pl.chunks, (size_t)M * N, M * N, C, scratch + (size_t)pl.chunks * M * N));
+  return DSBDD_OK;
+}
+
+struct TrainScratch {
+  float *dz2, *a1, *dz1, *partA, *partB, *rtmp, *wg, *gd, *gxr, *gxc, *gm, *agg_head, *xagg, *xagg_head, *vec;
+  size_t bytes;
+};
+static int train_grid(int64_t E) {
+  int64_t tiles = (E + 127) / 128;
+  int64_t g = tiles < device_cus() ? tiles : device_cus();
+  return g < 1 ? 1 : (int)g;
+}
+static TrainScratch carve_train(char* base, int H, int64_t N, int64_t E) {
+  TrainScratch t{};
+  size_t off = 0;
+  auto take = [&](size_t floats) { float* p = base ? reinterpret_cast<float*>(base + off) : nullptr; off += al256(floats * 4); return p; };
+  const size_t EH = (size_t)(E > 0 ? E : 1) * H;
+  const int slots = 256 * 8;
+  t.dz2 = take(EH); t.a1 = take(EH); t.dz1 = take(EH);
+  t.partA = take((size_t)slots * kPartA * H); t.partB = take((size_t)slots * kPartB * H);
+  t.rtmp = take((size_t)(slots / 32 + 1) * kPartB * H);
+  t.wg = take(wgrad_plan(E > N ? E : N, H, H).floats);
+  t.gd = take(E + 1); t.gxr = take(3 * (size_t)E + 4); t.gxc = take(3 * (size_t)E + 4); t.gm = take(3 * (size_t)E + 4);
+  t.agg_head = take((size_t)((E + 31) / 32 + 2) * H);
+  t.xagg = take(3 * (size_t)N + 4); t.xagg_head = take(4 * (size_t)((E + 31) / 32 + 2));
+  t.vec = take(8 * (size_t)H);
+  t.bytes = off;
+  return t;
+}
+
+template <int H>
+static hipError_t launch_bwd_a(hipStream_t s, int mode, const TrainEdgeArgs& a, int grid) {
+  if (mode == MODE_GCL) hipLaunchKernelGGL((edge_bwd_a_kernel<H, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((edge_bwd_a_kernel<H, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
+  return hipGetLastError();
+}
+static hipError_t launch_bwd_a(int H, hipStream_t s, int mode, const TrainEdgeArgs& a, int grid) {
+  switch (H) {
+    case 64: return launch_bwd_a<64>(s, mode, a, grid);
+    case 128: return launch_bwd_a<128>(s, mode, a, grid);
+    case 192: return launch_bwd_a<192>(s, mode, a, grid);
+    case 256: return launch_bwd_a<256>(s, mode, a, grid);
+  }
+  return hipErrorInvalidValue;
+}
+static hipError_t launch_bwd_b(int H, hipStream_t s, const TrainEdgeArgs& a, int grid) {
+  switch (H) {
+    case 64: hipLaunchKernelGGL((edge_bwd_b_kernel<64>), dim3(grid), dim3(kThreads), 0, s, a); break;
+    case 128: hipLaunchKernelGGL((edge_bwd_b_kernel<128>), dim3(grid), dim3(kThreads), 0, s, a); break;
+    case 192: hipLaunchKernelGGL((edge_bwd_b_kernel<192>), dim3(grid), dim3(kThreads), 0, s, a); break;
+    case 256: hipLaunchKernelGGL((edge_bwd_b_kernel<256>), dim3(grid), dim3(kThreads), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+static bool train_h_ok(int H) { return H == 64 || H == 128 || H == 192 || H == 256; }
+static bool graph_ok(const dsbdd_train_graph* g) {
+  return g && g->erow && g->ecol && g->ed0 && g->row_ptr && g->deg && g->node_batch && g->lig_off && g->poc_off &&
+         g->n_nodes > 0 && g->n_edges >= 0 && g->batch > 0 && g->n_lig >= 0 && g->n_lig <= g->n_nodes;
+}
+static bool mlp_ok(const dsbdd_train_mlp* m) {
+  return m && m->P && m->Q && m->wd && m->wd0 && m->tab && m->W2 && m->W2T && m->b2 && (m->ldpq & 3) == 0;
+}
+
+// the backward of ONE edge MLP: kernel A -> weight gradient -> kernel B -> node gathers; returns the per-edge gradient
+// w.r.t. the current squared distance in ts.gd
+static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+                        int64_t E, TrainEdgeArgs a, const dsbdd_train_mlp_grad* out, const TrainScratch& ts) {
+  const int grid = train_grid(E);
+  const int slots = grid * 8;
+  a.erow = g->erow; a.ecol = g->ecol; a.ed0 = g->ed0; a.E = (int)E; a.x = x; a.n_lig = (int)g->n_lig;
+  a.n_nodes = (int)g->n_nodes; a.P = m->P; a.Q = m->Q; a.ldpq = m->ldpq; a.wd = m->wd; a.wd0 = m->wd0; a.table = m->tab;
+  a.b2 = m->b2; a.head = m->head; a.head_b = m->head_b;
+  a.a1_out = ts.a1; a.gxr = ts.gxr; a.gxc = ts.gxc; a.gd = ts.gd; a.gd0 = out->gd0;
+  // A: dz2, a1, partial bias / head vectors
+  a.Bmat = m->W2T; a.dz_out = ts.dz2; a.part = ts.partA;
+  HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
+  HIP_TRY(reduce_parts(s, ts.partA, slots, (size_t)kPartA * H, kPartA * H, out->d_vec + 5 * (size_t)H, ts.rtmp));
+  // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
+  { const int rc = wgrad_impl(s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg); if (rc != DSBDD_OK) return rc; }
+  // B: dz1, partial first-layer vectors, per-edge distance gradients
+  a.Bmat = m->W2; a.dz_in = ts.dz2; a.dz_out = ts.dz1; a.part = ts.partB;
+  HIP_TRY(launch_bwd_b(H, s, a, grid));
+  HIP_TRY(reduce_parts(s, ts.partB, slots, (size_t)kPartB * H, kPartB * H, out->d_vec, ts.rtmp));
+  // dP / dQ
+  const int N = (int)g->n_nodes;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.dz1, H, g->row_ptr,
+                     g->deg, g->rev, (int)E, N, out->dP, out->dQ, out->ldo);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+extern "C" {
+
+size_t dsbdd_train_scratch_bytes(int32_t H, int64_t n_nodes, int64_t n_edges) {
+  if (!train_h_ok(H) || n_nodes < 1 || n_edges < 0) return 0;
+  return carve_train(nullptr, H, n_nodes, n_edges).bytes;
+}
+
+size_t dsbdd_train_wgrad_scratch_bytes(int64_t K, int64_t M, int64_t N) {
+  if (K < 1 || M < 1 || N < 1) return 0;
+  return wgrad_plan(K, M, N).floats * 4;
+}
+
+int dsbdd_train_edge_rev(void* stream, const dsbdd_train_graph* g, int32_t* rev) {
+  if (!graph_ok(g) || !rev) return fail(DSBDD_ERR_ARG, "bad argument");
+  if (g->n_edges == 0) return DSBDD_OK;
+  hipLaunchKernelGGL(edge_rev_kernel, dim3((unsigned)((g->n_edges + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g->erow, g->ecol, g->row_ptr, g->deg, (int)g->n_edges,
+                     (int)g->n_nodes, rev);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_train_sample_mean(void* stream, const float* x, const dsbdd_train_graph* g, float* mean) {
+  if (!graph_ok(g) || !x || !mean) return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(sample_mean_kernel, dim3((unsigned)g->batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x,
+                     g->lig_off, g->poc_off, (int)g->n_lig, mean);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+                            float norm_factor, float* agg, void* scratch, size_t scratch_bytes) {
+  if (!train_h_ok(H) || !graph_ok(g) || !mlp_ok(m) || !x || !agg || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
+  const TrainScratch ts = carve_train(static_cast<char*>(scratch), H, g->n_nodes, g->n_edges);
+  if (ts.bytes > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small (dsbdd_train_scratch_bytes)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = (int)g->n_nodes;
+  EdgeArgs ea{};
+  ea.erow = g->erow; ea.ecol = g->ecol; ea.ed0 = g->ed0; ea.e_count = g->row_ptr + N; ea.e_cap = (int)g->n_edges;
+  ea.x = x; ea.n_lig = (int)g->n_lig; ea.n_nodes = N; ea.ldpq = m->ldpq;
+  ea.mlp[0] = EdgeMlpW{m->P, m->Q, m->wd, m->wd0, m->tab, m->W2T, m->b2, nullptr};
+  ea.mlp[1] = ea.mlp[0];
+  ea.att_w = m->head; ea.att_b = m->head_b; ea.attention = m->head != nullptr;
+  ea.agg = agg; ea.agg_head = ts.agg_head; ea.norm_factor = norm_factor;
+  if (g->n_edges > 0) HIP_TRY(launch_edge_plain(H, s, MODE_GCL, ea, g->n_edges));
+  hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, agg, (const float*)ts.agg_head,
+                     g->row_ptr, g->deg, N, (int)H, (int)((g->n_edges + 31) / 32 + 1));
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+                             float norm_factor, const float* d_agg, const dsbdd_train_mlp_grad* out, float* d_x,
+                             void* scratch, size_t scratch_bytes) {
+  if (!train_h_ok(H) || !graph_ok(g) || !g->rev || !mlp_ok(m) || !x || !d_agg || !out || !out->dP || !out->dQ ||
+      !out->d_vec || !out->d_W2 || !out->gd0 || (out->ldo & 3) || !d_x || !scratch)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  const TrainScratch ts = carve_train(static_cast<char*>(scratch), H, g->n_nodes, g->n_edges);
+  if (ts.bytes > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small (dsbdd_train_scratch_bytes)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TrainEdgeArgs a{};
+  a.d_agg = d_agg; a.norm_factor = norm_factor;
+  { const int rc = mlp_backward(s, H, MODE_GCL, g, m, x, g->n_edges, a, out, ts); if (rc != DSBDD_OK) return rc; }
+  const int N = (int)g->n_nodes;
+  hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ts.gd,
+                     (const float*)nullptr, (const float*)nullptr, x, g->ecol, g->row_ptr, g->deg, g->rev,
+                     (int)g->n_edges, N, d_x, 0);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
+                              const float* x, const float* mean, int64_t n_upd, float norm_constant, float coords_range,
+                              int32_t use_tanh, float norm_factor, float* x_out, void* scratch, size_t scratch_bytes) {
+  if (!train_h_ok(H) || !graph_ok(g) || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) || (n_mlp == 2 && (!mlp_ok(m + 1) || !mean)) ||
+      !m->head || !x || !x_out || n_upd < 0 || n_upd > g->n_nodes || !scratch)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  const TrainScratch ts = carve_train(static_cast<char*>(scratch), H, g->n_nodes, g->n_edges);
+  if (ts.bytes > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small (dsbdd_train_scratch_bytes)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = (int)g->n_nodes;
+  HIP_TRY(hipMemcpyAsync(x_out, x, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
+  if (n_upd == 0 || g->n_edges == 0) return DSBDD_OK;
+  EdgeArgs ea{};
+  ea.erow = g->erow; ea.ecol = g->ecol; ea.ed0 = g->ed0; ea.e_count = g->row_ptr + n_upd; ea.e_cap = (int)g->n_edges;
+  ea.x = x; ea.n_lig = (int)g->n_lig; ea.n_nodes = N; ea.ldpq = m->ldpq;
+  for (int q = 0; q < 2; ++q) {
+    const dsbdd_train_mlp& mq = m[q < n_mlp ? q : 0];
+    ea.mlp[q] = EdgeMlpW{mq.P, mq.Q, mq.wd, mq.wd0, mq.tab, mq.W2T, mq.b2, nullptr};
+  }
+  ea.w3 = m->head; ea.node_batch = g->node_batch; ea.mean = mean; ea.norm_constant = norm_constant;
+  ea.coords_range = coords_range; ea.use_tanh = use_tanh; ea.n_mlp = n_mlp; ea.xagg = ts.xagg; ea.xagg_head = ts.xagg_head;
+  ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = 4 * (size_t)((g->n_edges + 31) / 32 + 2); ea.norm_factor = norm_factor;
+  HIP_TRY(launch_edge_plain(H, s, MODE_COORD, ea, g->n_edges));
+  hipLaunchKernelGGL(coord_update_kernel, dim3((unsigned)((3 * n_upd + 255) / 256)), dim3(256), 0, s, x_out,
+                     (const float*)ts.xagg, (const float*)ts.xagg_head, 1, ea.xagg_stride, ea.xhead_stride, g->row_ptr,
+                     g->deg, (int)(3 * n_upd), (int)((g->n_edges + 31) / 32 + 1));
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
+                               const float* x, const float* mean, int64_t n_upd, int64_t e_upd, float norm_constant,
+                               float coords_range, int32_t use_tanh, float norm_factor, const float* d_xout,
+                               const dsbdd_train_mlp_grad* out, float* d_x, float* d_mean, void* scratch,
+                               size_t scratch_bytes) {
+  if (!train_h_ok(H) || !graph_ok(g) || !g->rev || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) ||
+      (n_mlp == 2 && (!mlp_ok(m + 1) || !mean || !d_mean)) || !m->head || !x || !d_xout || !out || !d_x || n_upd < 0 ||
+      n_upd > g->n_nodes || e_upd < 0 || e_upd > g->n_edges || !scratch)
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  for (int q = 0; q < n_mlp; ++q)
+    if (!out[q].dP || !out[q].dQ || !out[q].d_vec || !out[q].d_W2 || !out[q].gd0 || (out[q].ldo & 3))
+      return fail(DSBDD_ERR_ARG, "bad gradient destination");
+  const TrainScratch ts = carve_train(static_cast<char*>(scratch), H, g->n_nodes, g->n_edges);
+  if (ts.bytes > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small (dsbdd_train_scratch_bytes)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = (int)g->n_nodes;
+  for (int q = 0; q < n_mlp; ++q) {
+    TrainEdgeArgs a{};
+    a.d_xagg = d_xout; a.node_batch = g->node_batch; a.mean = mean; a.norm_constant = norm_constant;
+    a.coords_range = coords_range; a.use_tanh = use_tanh; a.which = q; a.norm_factor = norm_factor;
+    a.gm = q == 1 ? ts.gm : nullptr;
+    dsbdd_train_mlp mq = m[q];
+    mq.head = m[0].head;                      // the output layer is shared by both MLPs (egnn_new.py:78,85,91)
+    { const int rc = mlp_backward(s, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, ts); if (rc != DSBDD_OK) return rc; }
+    hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ts.gd,
+                       (const float*)ts.gxr, (const float*)ts.gxc, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)e_upd, N,
+                       d_x, q);
+    HIP_TRY(hipGetLastError());
+    if (q == 1) {
+      hipLaunchKernelGGL(sample_edge_sum3_kernel, dim3((unsigned)g->batch), dim3(kThreads), 0, s, (const float*)ts.gm,
+                         g->row_ptr, g->lig_off, g->poc_off, (int)g->n_lig, (int)e_upd, d_mean);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  return DSBDD_OK;
+}
+
+int dsbdd_train_radial_backward(void* stream, const dsbdd_train_graph* g, const float* x, const float* gd, float* d_x) {
+  if (!graph_ok(g) || !g->rev || !x || !gd || !d_x) return fail(DSBDD_ERR_ARG, "bad argument");
+  const int N = (int)g->n_nodes;
+  hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gd,
+                     (const float*)nullptr, (const float*)nullptr, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)g->n_edges,
+                     N, d_x, 0);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_train_wgrad(void* stream, const float* A, int32_t lda, const float* B, int32_t ldb, int64_t K, int32_t M,
+                      int32_t N, float* C, void* scratch, size_t scratch_bytes) {
+  if (!A || !B || !C || K < 1 || M < 1 || N < 1 || lda < M || ldb < N || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
+  if (wgrad_plan(K, M, N).floats * 4 > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small");
+  return wgrad_impl(static_cast<hipStream_t>(stream), A, lda, B, ldb, K, M, N, C, static_cast<float*>(scratch));
+}
+
+int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int32_t N, float* out, void* scratch,
+                       size_t scratch_bytes) {
+  if (!A || !out || M < 1 || N < 1 || lda < N || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
+  if ((size_t)((M + 31) / 32) * N * 4 > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small");
+  HIP_TRY(reduce_parts(static_cast<hipStream_t>(stream), A, (int)M, (size_t)lda, N, out, static_cast<float*>(scratch)));
+  return DSBDD_OK;
 }
 
 }  // extern "C"

@@ -15,9 +15,10 @@ What is different: on the sampling path the modules below are *parameter
 containers*; nothing calls their `forward`.  The arithmetic is the factorised
 algorithm described in csrc/edge_mlp.h.  There is no CPU fallback: tensors must
 live on a GPU and the HIP library must be built, otherwise the call raises.
-Only the training step (training mode + autograd recording) evaluates the same
-function with differentiable GPU tensor operations on these modules
-(train_path.py); its radius graph still comes from the HIP builder.
+The training step (training mode + autograd recording) runs on hand-written
+forward / backward kernel pairs as well (train_hip.py over csrc/train.h); the
+eager torch evaluation of round 3 (train_path.py) is kept as an A/B switch
+(DSBDD_TRAIN=torch).
 """
 from __future__ import annotations
 
@@ -159,6 +160,7 @@ class EGNNDynamics(nn.Module):
         """The packed kernel weights are rebuilt lazily.  load_state_dict, .to() and in-place parameter updates
         (optimiser steps; detected through the tensors' version counters) trigger it automatically."""
         self._engine = None
+        self._plist = None        # load_state_dict(assign=True) replaces the Parameter objects (ADVICE r3)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -192,18 +194,18 @@ class EGNNDynamics(nn.Module):
         """dynamics.py:87-167.  Inputs are not modified.  Raises ValueError on NaN
         in the predicted velocity (eval-mode behaviour of the reference).
 
-        Training mode with autograd recording (the training step, lightning_modules.py:337-363): the differentiable
-        GPU evaluation of train_path.py; everything else -- sampling, validation, any call under no_grad -- the
-        fused HIP kernels."""
+        Training mode with autograd recording (the training step, lightning_modules.py:337-363): the HIP forward /
+        backward kernel pairs of train_hip.py; everything else -- sampling, validation, any call under no_grad -- the
+        fused HIP inference engine."""
         if self.training and torch.is_grad_enabled():
-            from .train_path import dynamics_forward_autograd
-            if not getattr(EGNNDynamics, "_warned_autograd", False):
-                EGNNDynamics._warned_autograd = True
-                import warnings
-                warnings.warn("EGNNDynamics.forward in training mode with autograd recording: the differentiable GPU "
-                              "path (train_path.py) is used; call .eval() or wrap the call in torch.no_grad() for the "
-                              "fused HIP kernels", stacklevel=2)
-            return dynamics_forward_autograd(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+            # the training step (SURVEY.md 8f-3): forward AND backward on the HIP kernels (train_hip.py: autograd
+            # Functions over csrc/train.h); DSBDD_TRAIN=torch selects round 3's eager torch path (train_path.py, A/B)
+            import os
+            if os.environ.get("DSBDD_TRAIN", "hip") == "torch":
+                from .train_path import dynamics_forward_autograd
+                return dynamics_forward_autograd(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+            from .train_hip import dynamics_forward_hip
+            return dynamics_forward_hip(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
         with torch.no_grad():
             return self._forward_hip(xh_atoms, xh_residues, t, mask_atoms, mask_residues)
 

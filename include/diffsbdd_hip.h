@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DSBDD_ABI_VERSION 5
+#define DSBDD_ABI_VERSION 6
 
 enum {
   DSBDD_OK = 0,
@@ -333,6 +333,81 @@ int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig,
                       const dsbdd_config* cfg, int32_t* node_batch, int32_t* lig_off,
                       int32_t* poc_off, int32_t* deg, int32_t* row_ptr, int32_t* edge_row,
                       int32_t* edge_col, float* edge_d0, int64_t edge_capacity, int32_t* status);
+
+/* ---- training step: backward of the fused edge stages -------------------------------------------
+ * The reference trains through `loss.backward()` over its eager op stream (lightning_modules.py:337-363 ->
+ * conditional_model.py:202-330 / en_diffusion.py:336-469 -> dynamics.py:87-167 -> egnn_new.py:31-58,96-122).  These entry
+ * points are the hand-written forward / backward pairs of the two fused edge stages and the weight-gradient GEMM; the
+ * Python side (diffsbdd_amd/train_hip.py) wraps them as torch.autograd.Function objects behind EGNNDynamics.forward.
+ * Nothing of size [n_edges][H] is kept from the forward pass: the backward recomputes the edge activations from the
+ * per-node projections.  All sums over edges are taken in a fixed order (bitwise reproducible gradients, no atomics).
+ *
+ * graph: the (row, col)-sorted list of dsbdd_build_edges plus rev (dsbdd_train_edge_rev: index of the edge (col, row)). */
+typedef struct dsbdd_train_graph {
+  const int32_t *erow, *ecol; const float* ed0;     /* [n_edges]                                    */
+  const int32_t *row_ptr, *deg;                     /* [n_nodes + 1], [n_nodes]                     */
+  const int32_t* rev;                               /* [n_edges] (backward only)                    */
+  const int32_t *node_batch, *lig_off, *poc_off;    /* [n_nodes], [batch + 1], [batch + 1]          */
+  int64_t n_lig, n_nodes, n_edges, batch;
+} dsbdd_train_graph;
+
+/* one edge MLP in its factorised form (csrc/edge_mlp.h): z1 = P[row] + Q[col] + d wd + d0 wd0 + tab[type] */
+typedef struct dsbdd_train_mlp {
+  const float *P, *Q; int32_t ldpq;   /* [n_nodes][ldpq] first-layer projections of the row / column node             */
+  const float *wd, *wd0, *tab;        /* [H], [H], [3][H]                                                             */
+  const float *W2, *W2T, *b2;         /* second layer: nn.Linear layout [out][in], its transpose [in][out], bias [H]  */
+  const float *head, *head_b;         /* GCL: att_mlp.0.weight [H] and bias [1] (head = NULL: no attention);
+                                         coordinate MLPs: the bias-free output layer [H] (egnn_new.py:78)             */
+} dsbdd_train_mlp;
+
+/* gradient destinations of one edge MLP */
+typedef struct dsbdd_train_mlp_grad {
+  float *dP, *dQ; int32_t ldo;        /* [n_nodes][ldo]: every row is written                                         */
+  float* d_vec;                       /* [8][H]: d_wd, d_wd0, d_tab[0..2], d_b2, d_head, d_head_b (element 0)         */
+  float* d_W2;                        /* [H][H] nn.Linear layout                                                      */
+  float* gd0;                         /* [n_edges] gradient w.r.t. ed0                                                */
+} dsbdd_train_mlp_grad;
+
+size_t dsbdd_train_scratch_bytes(int32_t H, int64_t n_nodes, int64_t n_edges);
+size_t dsbdd_train_wgrad_scratch_bytes(int64_t K, int64_t M, int64_t N);
+int dsbdd_train_edge_rev(void* stream, const dsbdd_train_graph* g, int32_t* rev);
+/* mean[b] = mean position of ALL nodes of sample b (coord2cross, egnn_new.py:307-310) */
+int dsbdd_train_sample_mean(void* stream, const float* x, const dsbdd_train_graph* g, float* mean);
+
+/* GCL.edge_model + aggregation (egnn_new.py:31-52): agg [n_nodes][H] = sum over the row's edges of m * att / nf */
+int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m,
+                            const float* x, float norm_factor, float* agg, void* scratch, size_t scratch_bytes);
+/* d_agg [n_nodes][H] -> gradients of the MLP's inputs and parameters; d_x [n_nodes][3] = gradient through |x_i - x_j|^2 */
+int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m,
+                             const float* x, float norm_factor, const float* d_agg,
+                             const dsbdd_train_mlp_grad* out, float* d_x, void* scratch, size_t scratch_bytes);
+
+/* EquivariantUpdate.coord_model (egnn_new.py:96-122): x_out = x + sum over the edges of rows < n_upd of
+ * (u T(phi) + cross T(phi_x)) / nf; m[0] = coord_mlp, m[1] = cross_product_mlp (n_mlp = 2), m[0].head = the shared
+ * output layer.  mean [batch][3] from dsbdd_train_sample_mean (n_mlp = 2 only). */
+int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m,
+                              int32_t n_mlp, const float* x, const float* mean, int64_t n_upd, float norm_constant,
+                              float coords_range, int32_t use_tanh, float norm_factor, float* x_out, void* scratch,
+                              size_t scratch_bytes);
+/* d_xout [n_nodes][3] -> out[0 .. n_mlp) and d_x [n_nodes][3] = the gradient through the geometry (u, cross,
+ * |x_i - x_j|^2; the identity path x -> x_out is NOT included), d_mean [batch][3].  e_upd = row_ptr[n_upd] (host value).
+ * out[1].d_vec row 6 (d_head) belongs to the shared output layer as well: the caller adds it to out[0]'s. */
+int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m,
+                               int32_t n_mlp, const float* x, const float* mean, int64_t n_upd, int64_t e_upd,
+                               float norm_constant, float coords_range, int32_t use_tanh, float norm_factor,
+                               const float* d_xout, const dsbdd_train_mlp_grad* out, float* d_x, float* d_mean,
+                               void* scratch, size_t scratch_bytes);
+
+/* gradient of the squared edge lengths d_e = |x_row - x_col|^2 (the edge list's ed0 when x is the call's input):
+ * d_x[i] = sum over row i's edges of 2 (gd[e] + gd[rev e]) (x_i - x_col) */
+int dsbdd_train_radial_backward(void* stream, const dsbdd_train_graph* g, const float* x, const float* gd, float* d_x);
+
+/* C[M][N] = sum_k A[k][m] B[k][n]  (A [K][lda], B [K][ldb]; the weight gradient dY^T X of a Linear layer), split-K with
+ * an ordered reduction.  out[n] = sum_m A[m][n] (bias gradient); scratch >= 4 * ceil(M / 32) * N bytes. */
+int dsbdd_train_wgrad(void* stream, const float* A, int32_t lda, const float* B, int32_t ldb, int64_t K, int32_t M,
+                      int32_t N, float* C, void* scratch, size_t scratch_bytes);
+int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int32_t N, float* out, void* scratch,
+                       size_t scratch_bytes);
 
 /* ---- post-processing of a finished batch ------------------*/
 /* Distance-based bond orders of a batch of molecules: replaces

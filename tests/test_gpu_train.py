@@ -1,0 +1,304 @@
+"""GPU tests of the training-step kernels (csrc/train.h through the C-ABI `dsbdd_train_*`).
+
+Layer 1: every autograd Function of diffsbdd_amd/train_hip.py against the same operation written with torch tensor
+operations in float64 (forward values and every input / parameter gradient).
+Layer 2: the whole denoiser under autograd (`EGNNDynamics.forward` in training mode) against the ORACLE differentiated by
+autograd on the CPU -- the literal reference graph -- on the small architectures and on crossdock_fullatom_cond at
+B = 8 (E > 40 k, H = 256), every parameter gradient at 1e-4 of that gradient's largest entry.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import egnn_oracle as eo
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def make_dynamics(cfg, sd):
+    from diffsbdd_amd.dynamics import EGNNDynamics
+    m = EGNNDynamics(**cfg, device=dev())
+    m.load_state_dict(sd)
+    return m
+
+
+def problem(cfg, n_lig, n_poc, seed, spread=3.0):
+    g = torch.Generator().manual_seed(seed)
+    B = len(n_lig)
+    ml = torch.repeat_interleave(torch.arange(B), torch.tensor(n_lig))
+    mp = torch.repeat_interleave(torch.arange(B), torch.tensor(n_poc))
+    a, r = cfg["atom_nf"], cfg["residue_nf"]
+    xl = torch.cat([torch.randn(len(ml), 3, generator=g) * spread * 0.5, torch.randn(len(ml), a, generator=g)], 1)
+    xp = torch.cat([torch.randn(len(mp), 3, generator=g) * spread, torch.randn(len(mp), r, generator=g)], 1)
+    t = torch.rand(B, 1, generator=g)
+    return xl, xp, t, ml, mp
+
+
+@pytest.mark.parametrize("K,M,N", [(1000, 256, 256), (37, 20, 10), (5000, 256, 512), (513, 129, 256), (2, 4, 4),
+                                     (70000, 256, 256)])
+def test_wgrad_and_colsum_vs_torch(K, M, N):
+    from diffsbdd_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(K + M + N)
+    A = torch.randn(K, M, generator=g).to(dev())
+    B = torch.randn(K, N, generator=g).to(dev())
+    C_ = torch.empty(M, N, device=dev())
+    nb = lib.dsbdd_train_wgrad_scratch_bytes(K, M, N)
+    scr = torch.empty(nb, dtype=torch.uint8, device=dev())
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.dsbdd_train_wgrad(s, A.data_ptr(), M, B.data_ptr(), N, K, M, N, C_.data_ptr(), scr.data_ptr(), nb))
+    ref = A.double().t() @ B.double()
+    assert rel_err(C_, ref) < 2e-6, rel_err(C_, ref)
+    C2 = torch.empty_like(C_)
+    _lib.check(lib.dsbdd_train_wgrad(s, A.data_ptr(), M, B.data_ptr(), N, K, M, N, C2.data_ptr(), scr.data_ptr(), nb))
+    assert torch.equal(C_, C2)                       # ordered reduction: bitwise reproducible
+    out = torch.empty(M, device=dev())
+    nb2 = 4 * ((K + 31) // 32) * M
+    scr2 = torch.empty(nb2, dtype=torch.uint8, device=dev())
+    _lib.check(lib.dsbdd_train_colsum(s, A.data_ptr(), M, K, M, out.data_ptr(), scr2.data_ptr(), nb2))
+    assert rel_err(out, A.double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(777, 256, 256, True), (300, 10, 20, True), (1500, 512, 256, True),
+                                         (64, 129, 256, True), (900, 256, 129, False), (500, 256, 1024, False)])
+def test_hip_linear_forward_backward(M, K, N, bias):
+    from diffsbdd_amd.train_hip import HipLinear
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev()).requires_grad_(True)
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev()).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev()).requires_grad_(True) if bias else None
+    gy = torch.randn(M, N, generator=g).to(dev())
+    y = HipLinear.apply(x, Wt, b)
+    y.backward(gy)
+    xd, Wd = x.detach().double().requires_grad_(True), Wt.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True) if bias else None
+    yr = F.linear(xd, Wd, bd)
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < 3e-6
+    assert rel_err(x.grad, xd.grad) < 3e-6
+    assert rel_err(Wt.grad, Wd.grad) < 3e-6
+    if bias:
+        assert rel_err(b.grad, bd.grad) < 3e-6
+
+
+def _graph_problem(arch, n_lig, n_poc, seed):
+    from diffsbdd_amd.train_hip import TrainGraph
+    cfg, _ = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, seed=3)
+    m = make_dynamics(cfg, sd)
+    xl, xp, t, ml, mp = problem(cfg, n_lig, n_poc, seed)
+    x = torch.cat((xl[:, :3], xp[:, :3]), 0).to(dev()).contiguous()
+    g = TrainGraph(m, ml.to(dev()), mp.to(dev()), x)
+    return cfg, m, g, x
+
+
+def _edge_ref(pq, x, ed0, row, col, n_lig, wd, wd0, tab, W2, b2, H):
+    """a2 = SiLU(SiLU(P[row] + Q[col] + d wd + d0 wd0 + tab[type]) W2^T + b2)   in the tensors' dtype"""
+    d = ((x[row] - x[col]) ** 2).sum(1)
+    rl, cl = row < n_lig, col < n_lig
+    ty = torch.zeros_like(row)
+    ty[rl & cl] = 1
+    ty[~rl & ~cl] = 2
+    z1 = pq[row, :H] + pq[col, H:2 * H] + d[:, None] * wd[None] + ed0[:, None] * wd0[None] + tab[ty]
+    return F.silu(F.silu(z1) @ W2.t() + b2), d
+
+
+@pytest.mark.parametrize("arch,n_lig,n_poc,attention", [
+    ("small_cond", [5, 7, 6], [40, 35, 38], True),
+    ("small_cond", [9, 0, 4], [30, 50, 0], False),
+    ("crossdock_ca_cond", [23, 20, 25, 11], [36, 40, 30, 33], True),
+    ("crossdock_fullatom_cond", [23, 18], [286, 250], True),
+])
+def test_edge_gcl_function_vs_torch_fp64(arch, n_lig, n_poc, attention):
+    """EdgeGCL: the aggregate and the gradients w.r.t. pq, x, ed0 and every parameter of the MLP (incl. the attention
+    head) against float64 torch autograd of the literal formula; the rows span several 32-edge wave tiles."""
+    from diffsbdd_amd.train_hip import EdgeGCL
+    cfg, m, g, x = _graph_problem(arch, n_lig, n_poc, seed=5)
+    H = cfg["hidden_nf"]
+    gen = torch.Generator().manual_seed(11)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(dev())
+    pq = rnd(g.N, 2 * H, sc=0.5)
+    wd, wd0, tab = rnd(H, sc=0.05), rnd(H, sc=0.05), rnd(3, H, sc=0.3)
+    W2, b2 = rnd(H, H, sc=1.0 / H ** 0.5), rnd(H, sc=0.1)
+    aw, ab = (rnd(1, H, sc=0.2), rnd(1, sc=0.1)) if attention else (None, None)
+    gagg = rnd(g.N, H)
+    ed0 = g.ed0[:g.E].clone()
+    leaves = [pq, x.clone(), ed0, wd, wd0, tab, W2, b2] + ([aw, ab] if attention else [])
+    for v in leaves:
+        v.requires_grad_(True)
+    args = leaves + ([None, None] if not attention else [])
+    agg = EdgeGCL.apply(*args, g, 100.0)
+    agg.backward(gagg)
+    # float64 reference
+    dl = [v.detach().double().requires_grad_(True) for v in leaves]
+    row, col = g.erow[:g.E].long(), g.ecol[:g.E].long()
+    a2, _ = _edge_ref(dl[0], dl[1], dl[2], row, col, g.n_lig, dl[3], dl[4], dl[5], dl[6], dl[7], H)
+    if attention:
+        a2 = a2 * torch.sigmoid(a2 @ dl[8].t() + dl[9])
+    ref = torch.zeros(g.N, H, dtype=torch.float64, device=dev()).index_add_(0, row, a2) / 100.0
+    ref.backward(gagg.double())
+    assert int((g.rev[:g.E] < 0).sum()) == 0                     # the radius graph is symmetric
+    assert rel_err(agg, ref) < 2e-5, rel_err(agg, ref)
+    names = ["pq", "x", "ed0", "wd", "wd0", "tab", "W2", "b2", "att_w", "att_b"]
+    for nme, a, b in zip(names, leaves, dl):
+        e = rel_err(a.grad, b.grad)
+        assert e < 1e-4, (nme, e)
+
+
+@pytest.mark.parametrize("arch,n_lig,n_poc", [
+    ("small_cond", [5, 7, 6], [40, 35, 38]),
+    ("small_joint", [6, 3], [30, 41]),
+    ("small_variant", [8, 5], [33, 29]),
+    ("crossdock_fullatom_cond", [23, 18], [286, 250]),
+])
+def test_edge_coord_function_vs_torch_fp64(arch, n_lig, n_poc):
+    """EdgeCoord: x_out and the gradients w.r.t. pq, x, the sample mean, ed0 and every parameter of the two coordinate
+    MLPs against float64 torch autograd of egnn_new.py:96-122 + coord2diff / coord2cross."""
+    from diffsbdd_amd.train_hip import EdgeCoord, SampleMean
+    cfg, m, g, x = _graph_problem(arch, n_lig, n_poc, seed=7)
+    hp = m._hp
+    H = cfg["hidden_nf"]
+    n_mlp = 1 if hp["reflection_equivariant"] else 2
+    gen = torch.Generator().manual_seed(13)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(dev())
+    pq = rnd(g.N, 2 * H * n_mlp, sc=0.5)
+    groups = []
+    for q in range(n_mlp):
+        groups += [rnd(H, sc=0.05), rnd(H, sc=0.05), rnd(3, H, sc=0.3), rnd(H, H, sc=1.0 / H ** 0.5), rnd(H, sc=0.1)]
+    w3 = rnd(1, H, sc=0.3)
+    xx = x.clone()
+    ed0 = g.ed0[:g.E].clone()
+    gx = rnd(g.N, 3)
+    leaves = [pq, xx, ed0] + groups + [w3]
+    for v in leaves:
+        v.requires_grad_(True)
+    mean = SampleMean.apply(xx, g) if n_mlp == 2 else None
+    gq = groups + [None] * (5 * (2 - n_mlp))
+    x_out = EdgeCoord.apply(pq, xx, mean, ed0, *gq, w3, g, hp)
+    x_out.backward(gx)
+    # float64 reference
+    dl = [v.detach().double().requires_grad_(True) for v in leaves]
+    pqd, xd, ed0d = dl[0], dl[1], dl[2]
+    w3d = dl[-1]
+    row, col = g.erow[:g.E].long(), g.ecol[:g.E].long()
+    nb = g.node_batch.long()
+    nc, rng = float(hp["norm_constant"]), float(hp["coords_range"])
+    diff = xd[row] - xd[col]
+    radial = (diff ** 2).sum(1, keepdim=True)
+    u = diff / (torch.sqrt(radial + 1e-8) + nc)
+    trans = 0
+    for q in range(n_mlp):
+        wd, wd0, tab, W2, b2 = dl[3 + 5 * q: 8 + 5 * q]
+        a2, _ = _edge_ref(pqd[:, 2 * H * q:], xd, ed0d, row, col, g.n_lig, wd, wd0, tab, W2, b2, H)
+        phi = a2 @ w3d.t()
+        if hp["tanh"]:
+            phi = torch.tanh(phi) * rng
+        if q == 0:
+            trans = u * phi
+        else:
+            cnt = torch.bincount(nb, minlength=g.batch).clamp(min=1).double()
+            mean_d = torch.zeros(g.batch, 3, dtype=torch.float64, device=dev()).index_add_(0, nb, xd) / cnt[:, None]
+            a, b = xd[row] - mean_d[nb[row]], xd[col] - mean_d[nb[col]]
+            cr = torch.cross(a, b, dim=1)
+            trans = trans + cr / (torch.linalg.norm(cr, dim=1, keepdim=True) + nc) * phi
+    aggx = torch.zeros(g.N, 3, dtype=torch.float64, device=dev()).index_add_(0, row, trans) / float(hp["normalization_factor"])
+    if not hp["update_pocket_coords"]:
+        aggx = aggx * (torch.arange(g.N, device=dev()) < g.n_lig)[:, None]
+    ref = xd + aggx
+    ref.backward(gx.double())
+    assert rel_err(x_out, ref) < 2e-5, rel_err(x_out, ref)
+    names = ["pq", "x", "ed0"] + [f"{n}_{q}" for q in range(n_mlp) for n in ("wd", "wd0", "tab", "W2", "b2")] + ["w3"]
+    for nme, a, b in zip(names, leaves, dl):
+        e = rel_err(a.grad, b.grad)
+        assert e < 1e-4, (nme, e)
+
+
+def _grads_vs_oracle(arch, n_lig, n_poc, seed, tol=1e-4, coord_scale=None):
+    cfg, _ = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, seed=1)
+    m = make_dynamics(cfg, sd)
+    m.train(True)
+    xl, xp, t, ml, mp = problem(cfg, n_lig, n_poc, seed)
+    gen = torch.Generator().manual_seed(99)
+    wl, wp = torch.randn(xl.shape, generator=gen), torch.randn(xp.shape, generator=gen)
+    out_l, out_p = m(xl.to(dev()), xp.to(dev()), t.to(dev()), ml.to(dev()), mp.to(dev()))
+    assert out_l.requires_grad
+    loss = (out_l * wl.to(dev())).sum() + (out_p * wp.to(dev())).sum()
+    loss.backward()
+    # oracle under autograd on the CPU, on the edge list the HIP builder produced (teacher-forced graph)
+    from diffsbdd_amd.train_hip import TrainGraph
+    x = torch.cat((xl[:, :3], xp[:, :3]), 0).to(dev()).contiguous()
+    edges = TrainGraph(m, ml.to(dev()), mp.to(dev()), x).edges().cpu()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_l, ref_p, _ = eo.dynamics_forward(sdr, cfg, xl, xp, t, ml, mp, edges=edges)
+    ref_loss = (ref_l * wl).sum() + (ref_p * wp).sum()
+    ref_loss.backward()
+    assert (out_l.detach().cpu() - ref_l.detach()).abs().max().item() < 1e-4
+    worst = {}
+    for pname, p in m.named_parameters():
+        g_ref = sdr[pname].grad
+        if pname.endswith("coord_mlp.4.weight"):
+            twin = pname.replace("coord_mlp", "cross_product_mlp")
+            if twin in sdr and sdr[twin].grad is not None:
+                g_ref = g_ref + sdr[twin].grad
+        assert p.grad is not None and g_ref is not None, pname
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        worst[pname] = (p.grad.cpu() - g_ref).abs().max().item() / scale
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    return max(worst.values()), edges.shape[1]
+
+
+@pytest.mark.parametrize("arch", ["small_cond", "small_joint", "small_variant"])
+def test_dynamics_training_gradients_vs_oracle_small(arch):
+    worst, _ = _grads_vs_oracle(arch, [5, 7, 6], [40, 35, 38], seed=21)
+    print(arch, "worst relative gradient error", worst)
+
+
+def test_dynamics_training_gradients_vs_oracle_full_width():
+    """crossdock_fullatom_cond (H = 256, 6 blocks) at B = 8: E > 40 k edges, rows spanning many wave tiles, the
+    persistent multi-tile loops of the backward kernels; every parameter gradient vs the oracle's autograd at 1e-4."""
+    B = 8
+    worst, E = _grads_vs_oracle("crossdock_fullatom_cond", [23] * B, [286] * B, seed=22)
+    assert E > 40_000, E
+    print("full width: E =", E, "worst relative gradient error", worst)
+
+
+def test_training_gradients_bitwise_reproducible_and_match_torch_path():
+    """The backward kernels sum in a fixed order: two runs give identical gradients; and the A/B path of round 3
+    (train_path.py, eager torch ops) agrees to rounding."""
+    cfg, _ = W.arch_cfg("crossdock_ca_cond")
+    sd = W.random_state_dict(cfg, seed=1)
+    m = make_dynamics(cfg, sd)
+    m.train(True)
+    xl, xp, t, ml, mp = problem(cfg, [23, 20, 25, 11], [36, 40, 30, 33], seed=4)
+    args = [v.to(dev()) for v in (xl, xp, t, ml, mp)]
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        o, _ = m(*args)
+        (o ** 2).sum().backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    a, b = run(), run()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    os.environ["DSBDD_TRAIN"] = "torch"
+    try:
+        c = run()
+    finally:
+        os.environ.pop("DSBDD_TRAIN")
+    assert set(a) == set(c)
+    for k in a:
+        assert rel_err(a[k], c[k]) < 1e-4, (k, rel_err(a[k], c[k]))

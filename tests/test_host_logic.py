@@ -196,7 +196,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()                      # loads without a GPU; no compute calls here
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dsbdd_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.dsbdd_abi_version() == _lib.ABI_VERSION == 6
     # enum sizes the binding mirrors
     assert len(_lib.G_NAMES) == 20 and len(_lib.GCL_NAMES) == 12 and len(_lib.EQ_NAMES) == 12
     for names, prefix in ((_lib.G_NAMES, "DSBDD_G_"), (_lib.GCL_NAMES, "DSBDD_GCL_"), (_lib.EQ_NAMES, "DSBDD_EQ_")):
