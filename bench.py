@@ -165,19 +165,32 @@ def call_flops(cfg, lv, plan, N, E, joint):
     return 2.0 * mac
 
 
-def self_launch(n):
+def self_launch(n, attempts=3):
     """Re-exec this script under torch.distributed.run with n ranks on this node
-    (rendezvous on 127.0.0.1 and a free port); returns the job's exit code."""
+    (rendezvous on 127.0.0.1 and a free port); returns the job's exit code.  The port is probed and released before
+    the launcher binds it, so another process may take it in between: a rendezvous that fails with EADDRINUSE is
+    retried on a fresh port."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
-        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    import tempfile
+    rc = 1
+    for _ in range(attempts):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+            "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        with tempfile.TemporaryFile(mode="w+") as err:
+            rc = subprocess.run(cmd, env=env, stderr=err).returncode
+            err.seek(0)
+            text = err.read()
+        sys.stderr.write(text)
+        low = text.lower()
+        if rc == 0 or not ("address already in use" in low or "eaddrinuse" in low):
+            break
+    return rc
 
 
 def main():

@@ -157,6 +157,11 @@ class GammaNetwork(nn.Module):
                 self._table = (key, self.forward(t.view(-1, 1)).view(-1).contiguous())
         return self._table[1]
 
+    def table_key(self):
+        """Changes whenever a parameter changed (consumers that cache values derived from `.gamma`)."""
+        _ = self.gamma
+        return self._table[0]
+
 
 class DistributionNodes:
     """Joint categorical over (n_ligand_nodes, n_pocket_nodes) from a 2-D
@@ -273,7 +278,8 @@ class EnVariationalDiffusion(nn.Module):
         self.register_buffer('buffer', torch.zeros(1))
         self.size_distribution = DistributionNodes(size_histogram)
         self.vnode_idx = virtual_node_idx
-        self.check_issues_norm_values()
+        if noise_schedule != 'learned':       # en_diffusion.py:65: the check reads the table of a FIXED schedule only
+            self.check_issues_norm_values()
         # noise: None -> sharding-invariant keyed Philox on the GPU; a callable
         # (shape) -> tensor injects external noise (parity tests)
         self.noise_source = None
@@ -404,7 +410,10 @@ class EnVariationalDiffusion(nn.Module):
         return (input_size - 1) * self.n_dims
 
     def _coefs(self, timesteps) -> StepCoefficients:
-        key = (timesteps, self.gamma.gamma.data_ptr(), self.gamma.gamma._version)
+        # a learned schedule rebuilds its table after every parameter update -- possibly at the same address with
+        # version 0 -- so the key carries the generation of the table (GammaNetwork.table_key), not only its pointer
+        gen = self.gamma.table_key() if hasattr(self.gamma, "table_key") else None
+        key = (timesteps, self.gamma.gamma.data_ptr(), self.gamma.gamma._version, gen)
         if key not in self._coef_cache:
             self._coef_cache = {key: StepCoefficients(self.gamma.gamma, self.T, timesteps)}
         return self._coef_cache[key]

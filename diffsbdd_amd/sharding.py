@@ -31,14 +31,15 @@ def shard_range(n_total: int, world: int, rank: int):
     return lo, hi
 
 
-def init_distributed(backend=None, one_gpu_per_rank=True):
+def init_distributed(backend=None, one_gpu_per_rank=True, force=False):
     """Initialise torch.distributed from the torchrun environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns
-    (rank, local_rank, world).  A single process (no env) is world 1."""
+    (rank, local_rank, world).  A single process (no env) is world 1 and needs no process group; `force` creates one
+    anyway (a one-rank RCCL communicator: the de-risking test of the multi-GPU path on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -51,14 +52,15 @@ def init_distributed(backend=None, one_gpu_per_rank=True):
     return rank, local_rank, world
 
 
-def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int, group=None):
+def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int, group=None, force_collective=False):
     """Gather the finished ligands of every rank.
 
     out_lig  [n_rows, D] this rank's ligand atoms (x | one-hot), lig_mask [n_rows]
     LOCAL sample ids; sample_lo = global index of this rank's first sample.
     Returns (all_lig [sum rows, D], all_mask with GLOBAL sample ids) on every
-    rank (all_gather; the payload is ~1 KB per molecule)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    rank (all_gather; the payload is ~1 KB per molecule).  force_collective: run the all_gather exchange at world
+    size 1 as well (tests)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return out_lig, lig_mask + sample_lo
     world = dist.get_world_size(group)
     # RCCL ("nccl") moves device tensors; gloo (CPU tests, or several ranks sharing one GPU)
@@ -85,7 +87,7 @@ def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int
     return rows[:, :D].to(out_lig.dtype), rows[:, D].round().to(torch.int64)
 
 
-def sample_sharded(sample_fn, n_total: int, group=None):
+def sample_sharded(sample_fn, n_total: int, group=None, force_collective=False):
     """Run `sample_fn(lo, hi) -> (out_lig, lig_mask_local)` on this rank's
     shard and gather.  `sample_fn` must key its randomness by the global sample
     index (e.g. model.seed(seed, sample_offset=lo))."""
@@ -101,4 +103,4 @@ def sample_sharded(sample_fn, n_total: int, group=None):
             dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
         out_lig = torch.zeros((0, 0), device=probe_dev)
         mask = torch.zeros((0,), dtype=torch.int64, device=probe_dev)
-    return gather_ligands(out_lig, mask, lo, group)
+    return gather_ligands(out_lig, mask, lo, group, force_collective=force_collective)

@@ -36,6 +36,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import sys
 import time
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
@@ -121,8 +122,16 @@ class IterationLimit(RuntimeError):
 
 
 def default_is_valid(m):
-    """Molecules (molecules.Molecule) go through the valence / connectivity filter of molecules.is_valid_molecule;
-    anything else (a caller's own result objects) only has to exist."""
+    """The reference's default run (test.py:99-135 with sanitize=False, relax=False) accepts every molecule
+    `process_molecule` returns: it only returns None when sanitisation or relaxation fails
+    (analysis/molecule_builder.py:162-214).  So by default every built molecule counts."""
+    return m is not None
+
+
+def valence_filter(m):
+    """`--sanitize` without RDKit: the valence / connectivity filter of molecules.is_valid_molecule on the molecule built
+    from the GPU bond-order matrix (allowed valences: constants.py:19-22).  It APPROXIMATES what RDKit's sanitisation
+    rejects for distance-table bonds (over-valent atoms); it does not kekulise or check aromaticity."""
     from .molecules import Molecule, is_valid_molecule
     return is_valid_molecule(m) if isinstance(m, Molecule) else m is not None
 
@@ -255,7 +264,9 @@ def jobs_from_test_dir(gen, test_dir, n_samples, test_list=None, fix_n_nodes=Fal
 
 def main(argv=None):
     """`python -m diffsbdd_amd.testset <checkpoint> --test_dir ... --outdir ...` -- the options of the
-    reference's test.py (:18-36) that apply without RDKit (`--sanitize` / `--relax` are refused)."""
+    reference's test.py (:18-36).  Without `--sanitize` every built molecule is accepted, as in the reference's default
+    run; `--sanitize` applies `valence_filter` (an approximation of RDKit's sanitisation, which is absent here) and the
+    driver refills the rejected slots; `--relax` (UFF, RDKit) is refused."""
     import torch
 
     from . import sharding
@@ -280,8 +291,11 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--trusted-checkpoint", action="store_true")
     a = ap.parse_args(argv)
-    if a.sanitize or a.relax:
-        raise SystemExit("--sanitize / --relax are RDKit operations (see generate.py)")
+    if a.relax:
+        raise SystemExit("--relax (UFF relaxation) is an RDKit operation (see generate.py)")
+    if a.sanitize:
+        print("[testset] --sanitize: RDKit is absent; using the valence / connectivity filter on the distance-table "
+              "bonds (testset.valence_filter), which approximates RDKit's sanitisation", file=sys.stderr)
     rank, local_rank, world = sharding.init_distributed()
     torch.cuda.set_device(local_rank)
     gen = LigandGenerator.from_checkpoint(a.checkpoint, device=f"cuda:{local_rank}", trusted=a.trusted_checkpoint)
@@ -294,7 +308,7 @@ def main(argv=None):
     extra = dict(resamplings=a.resamplings, jump_length=a.jump_length) if gen.mode == "joint" else {}
     driver = TestSetDriver(make_hip_sampler(gen, a.timesteps, a.seed, largest_frag=not a.all_frags,
                                             n_nodes_bias=a.n_nodes_bias, n_nodes_min=a.n_nodes_min, **extra),
-                           a.batch_size)
+                           a.batch_size, is_valid=valence_filter if a.sanitize else None)
     failed = None
     try:
         driver.run(mine)

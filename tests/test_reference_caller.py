@@ -166,3 +166,17 @@ def test_learned_noise_schedule_matches_the_reference_network():
     m = EnVariationalDiffusion(dynamics=dyn, atom_nf=10, residue_nf=10, n_dims=3, size_histogram=np.ones((4, 4)),
                                timesteps=40, noise_schedule="learned", loss_type="vlb", norm_values=(1.0, 1.0))
     assert "gamma.l2.weight" in m.state_dict() and m._coefs(40) is not None
+    # norm_values (1, 4) -- every full-atom / moad config -- with a FRESH learned schedule: gamma_0 = -5 gives
+    # sigma_0 * 8 = 0.65 > 1 / 4; the reference skips check_issues_norm_values for learned schedules
+    # (en_diffusion.py:65), so construction must not raise
+    m4 = EnVariationalDiffusion(dynamics=dyn, atom_nf=10, residue_nf=10, n_dims=3, size_histogram=np.ones((4, 4)),
+                                timesteps=40, noise_schedule="learned", loss_type="vlb", norm_values=(1.0, 4.0))
+    # the step coefficients follow the parameters: an in-place update (optimiser step) must not be served from the cache
+    c0 = m4._coefs(40)
+    with torch.no_grad():
+        m4.gamma.gamma_1.add_(1.0)
+    c1 = m4._coefs(40)
+    assert c1 is not c0
+    with torch.no_grad():
+        m4.gamma.gamma_1.sub_(1.0)
+    assert m4._coefs(40) is not c1

@@ -75,16 +75,19 @@ def test_budget_counts_samples_and_oversampling_follows_the_pass_rate():
     assert exc.value.jobs[0].n_generated >= 24 and len(exc.value.jobs[0].raw) == exc.value.jobs[0].n_generated
 
 
-def test_default_filter_rejects_overvalent_molecules():
-    """is_valid defaults to the valence / connectivity filter on molecules built from the bond-order matrix
+def test_default_accepts_every_molecule_and_sanitize_filter_rejects_overvalent_ones():
+    """The default acceptance is the reference's (test.py:99-135 with sanitize=False: every molecule process_molecule
+    returns); `--sanitize` maps to the valence / connectivity filter on molecules built from the bond-order matrix
     (molecules.is_valid_molecule; allowed valences = the reference's constants.py:19-22)."""
     from diffsbdd_amd.molecules import Molecule, is_valid_molecule
     pos = np.zeros((5, 3), dtype=np.float32)
     ok = Molecule(pos, ["C", "O", "N", "C", "F"], [(1, 0, 2), (2, 0, 1), (3, 2, 1), (4, 3, 1)])
-    assert ok.valences() == [3, 2, 2, 2, 1] and not ok.valence_violations() and ts.default_is_valid(ok)
+    assert ok.valences() == [3, 2, 2, 2, 1] and not ok.valence_violations() and ts.valence_filter(ok)
     bad = Molecule(pos, ["C", "O", "N", "C", "F"], [(1, 0, 2), (2, 0, 1), (3, 1, 1), (4, 3, 1)])   # O with 3 bonds
-    assert bad.valence_violations() == [1] and not ts.default_is_valid(bad)
+    assert bad.valence_violations() == [1] and not ts.valence_filter(bad) and ts.default_is_valid(bad)
     assert not ts.default_is_valid(None) and ts.default_is_valid("anything else that exists")
+    assert not ts.valence_filter(None) and ts.valence_filter("anything else that exists")
+    assert ts.TestSetDriver(lambda plan, b: [], 4).is_valid is ts.default_is_valid
     two = Molecule(pos, ["C", "C", "C", "C", "C"], [(1, 0, 1), (2, 1, 1), (4, 3, 1)])
     frag = two.largest_fragment()
     assert frag.num_atoms == 3 and frag.n_generated_atoms == 5
@@ -207,3 +210,89 @@ def test_packed_sampling_full_atom_pockets_is_independent_of_the_packing():
         for x, y, z_ in zip(a[name], b[name], c[name]):
             assert x.symbols == y.symbols == z_.symbols
             assert np.array_equal(x.positions, y.positions) and np.array_equal(x.positions, z_.positions)
+
+
+class _KeyedNoise:
+    """The oracle's noise source for a chain whose HIP counterpart draws keyed noise (dsbdd_randn_keyed): draw i of the
+    chain for the ligand rows of the samples with the given GLOBAL ids -- the same values whatever batch they sit in."""
+
+    def __init__(self, seed, sample_ids, lig_mask, dev):
+        import torch
+        self.seed, self.i, self.dev = int(seed), 0, dev
+        self.ids = torch.as_tensor(sample_ids, dtype=torch.int64, device=dev).contiguous()
+        self.mask = lig_mask.to(device=dev, dtype=torch.int64).contiguous()
+
+    def __call__(self, shape):
+        import ctypes as C
+        import torch
+        from diffsbdd_amd import _lib
+        n, cols = shape
+        assert n == self.mask.numel()
+        out = torch.empty((n, cols), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.load().dsbdd_randn_keyed(torch.cuda.current_stream(self.dev).cuda_stream, out.data_ptr(),
+                                                 self.mask.data_ptr(), n, cols, self.ids.numel(), 0, self.ids.data_ptr(),
+                                                 C.c_uint64(self.seed), C.c_uint64(self.i), 0), "dsbdd_randn_keyed")
+        self.i += 1
+        return out.cpu()
+
+
+@pytest.mark.gpu
+def test_driver_molecules_vs_oracle_chains():
+    """SURVEY.md 8f-4 against the ORACLE (not packing against packing): the test-set driver (two C-alpha pockets, 3
+    molecules each, 4 slots per batch -> the pockets share batches and one pocket is split over two, keyed noise, T = 4)
+    must return, per pocket, the molecules of `oracle.ddpm_oracle.cond_sample_given_pocket` run on that pocket alone
+    with the noise of the same global sample ids: coordinates (moved back into the pocket's frame like
+    lightning_modules.py:843-852) to 1e-3 free-running over the chain, identical atom types.  The reference's driver
+    (test.py:99-135) is this chain per pocket + process_molecule."""
+    import torch
+    from oracle import ddpm_oracle as do
+    from oracle import egnn_oracle as eo
+    from oracle import weights as W
+    from diffsbdd_amd import pocket as pk
+    from diffsbdd_amd.generate import LigandGenerator
+    from tests._golden import GOLDEN_DIR
+    cfg, dd = W.arch_cfg("crossdock_ca_cond")
+    egnn = dict(joint_nf=cfg["joint_nf"], hidden_nf=cfg["hidden_nf"], n_layers=cfg["n_layers"], attention=True,
+                tanh=True, norm_constant=1, inv_sublayers=1, sin_embedding=False, normalization_factor=100,
+                aggregation_method="sum", edge_cutoff_ligand=None, edge_cutoff_pocket=5.0,
+                edge_cutoff_interaction=5.0, reflection_equivariant=False, edge_embedding_dim=None)
+    diff = dict(diffusion_steps=500, diffusion_noise_schedule="polynomial_2", diffusion_noise_precision=5e-4,
+                diffusion_loss_type="l2", normalize_factors=[1, 1])
+    gen = LigandGenerator("crossdock", egnn, diff, "pocket_conditioning", np.ones((40, 400)), "CA", device="cuda:0")
+    sd = W.random_state_dict(cfg, 0)
+    gen.ddpm.dynamics.load_state_dict(sd)
+    inv = {v: k for k, v in pk.AA_ENCODER.items()}
+    one_to_three = {v: k for k, v in pk.AA3_TO_1.items()}
+    residues = {}
+    for name in ("3rfm", "5ndu"):
+        z = np.load(os.path.join(GOLDEN_DIR, f"pocket_{name}.npz"))
+        residues[name] = [dict(chain="A", resseq=i, icode=" ", resname=one_to_three[inv[int(t)]],
+                               atoms=[("CA", "C", tuple(map(float, xyz)))], hetero=False)
+                          for i, (xyz, t) in enumerate(zip(z["ca_x"], z["ca_types"]))]
+    n_lig, n_samples, T, seed = 9, 3, 4, 5
+    jobs = ts.number_jobs([ts.PocketJob(n, residues[n], len(residues[n]), n_samples, num_nodes_lig=n_lig)
+                           for n in ("3rfm", "5ndu")])
+    drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=T, seed=seed, largest_frag=False), batch_size=4)
+    done = drv.run(jobs)
+    assert len(drv.batches) >= 2 and any(len(plan) == 2 for _, plan in drv.batches)     # shared and split batches
+    om = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
+                        dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
+    dec = gen.dataset_info["atom_decoder"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    for job in done:
+        assert len(job.valid) == n_samples
+        pocket = {k: v.cpu().clone() for k, v in gen.prepare_pocket(job.residues, repeats=n_samples).items()}
+        sizes = torch.full((n_samples,), n_lig, dtype=torch.int64)
+        lig_mask = torch.repeat_interleave(torch.arange(n_samples), sizes)
+        ids = job.index * (1 << 20) + torch.arange(n_samples)
+        com0 = eo.segment_mean(pocket["x"].float(), pocket["mask"], n_samples)
+        noise = _KeyedNoise(seed, ids, lig_mask, torch.device("cuda:0"))
+        o_l, o_p, _, p_mask = do.cond_sample_given_pocket(om, pocket, sizes, noise, timesteps=T)
+        shift = com0 - eo.segment_mean(o_p[:, :3], p_mask, n_samples)                  # lightning_modules.py:843-852
+        x_ref = (o_l[:, :3] + shift[lig_mask]).numpy()
+        t_ref = o_l[:, 3:].argmax(1).numpy()
+        for k, mol in enumerate(job.valid):
+            sl = slice(k * n_lig, (k + 1) * n_lig)
+            assert mol.symbols == [dec[int(t)] for t in t_ref[sl]], (job.name, k)
+            err = np.abs(mol.positions - x_ref[sl]).max()
+            assert err < 1e-3, (job.name, k, err)

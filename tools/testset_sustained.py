@@ -4,11 +4,15 @@ test.py:59-176 with its per-pocket times, :152-176).
 
 8 different full-atom pockets (the 3rfm and 5ndu example pockets under 4 rigid rotations each -- to the engine a
 rotated pocket is a different pocket), N_SAMPLES accepted molecules per pocket, batch of 64 slots, T = 500,
-crossdock_fullatom_cond architecture with the seeded random weights of bench.py.  Acceptance = the driver's default
-filter (molecules.is_valid_molecule: valence + connectivity on the GPU bond-order matrix, largest fragment kept).
-Prints a markdown report: batches, per-pocket time (the reference's pocket_times), sustained ligands/s.
+crossdock_fullatom_cond architecture with the seeded random weights of bench.py.  Acceptance: `valence` = the
+`--sanitize` filter (molecules.is_valid_molecule: valence + connectivity on the GPU bond-order matrix, largest fragment
+kept; random weights give 1-atom fragments, which always pass) or `keyed:P` = the valence filter AND a synthetic
+rejection that keeps a molecule with probability P, decided by a hash of its coordinates (deterministic per molecule,
+independent of the packing) -- so that deficits, refills and the pass-rate-scaled request of the driver execute on
+hardware as they do with a trained model whose molecules fail sanitisation.
+Prints a markdown report: batches, per-pocket time (the reference's pocket_times), generated / s and accepted / s.
 
-    python tools/testset_sustained.py [n_samples] [timesteps] > gpurun_out/<tag>_testset_sustained.md
+    python tools/testset_sustained.py [n_samples] [timesteps] [valence|keyed:0.6] > gpurun_out/<tag>_testset_sustained.md
 """
 import os
 import sys
@@ -24,6 +28,20 @@ from diffsbdd_amd.generate import LigandGenerator  # noqa: E402
 
 n_samples = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+FILTER = sys.argv[3] if len(sys.argv) > 3 else "keyed:0.6"
+
+
+def make_filter(spec):
+    if spec == "valence":
+        return ts.valence_filter
+    p = float(spec.split(":")[1])
+
+    def keyed(m):
+        if not ts.valence_filter(m):
+            return False
+        h = int(np.abs(np.asarray(m.positions, dtype=np.float64)).sum() * 1e4) * 2654435761 % (1 << 32)
+        return (h / float(1 << 32)) < p
+    return keyed
 cfg, dd = synthetic.arch_cfg("crossdock_fullatom_cond")
 egnn = dict(joint_nf=cfg["joint_nf"], hidden_nf=cfg["hidden_nf"], n_layers=cfg["n_layers"], attention=True, tanh=True,
             norm_constant=1, inv_sublayers=1, sin_embedding=False, normalization_factor=100, aggregation_method="sum",
@@ -50,7 +68,8 @@ for rot in range(4):
                          hetero=False) for i, (xyz, t) in enumerate(zip(xr, z["fa_types"]))]
         jobs.append(ts.PocketJob(f"{name}_r{rot}", residues, len(residues), n_samples, num_nodes_lig=23))
 ts.number_jobs(jobs)
-drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=T, seed=0, largest_frag=True), batch_size=64)
+drv = ts.TestSetDriver(ts.make_hip_sampler(gen, timesteps=T, seed=0, largest_frag=True), batch_size=64,
+                       is_valid=make_filter(FILTER))
 # warm-up (kernels, graph capture, allocator): one short packed chain outside the clock
 gen.generate_for_pockets([(jobs[0].residues, 4, torch.full((4,), 23))], timesteps=4, largest_frag=True, seed=1,
                          sample_ids=torch.arange(4))
@@ -67,7 +86,7 @@ acc = sum(len(j.valid) for j in jobs)
 gen_n = sum(j.n_generated for j in jobs)
 print(f"# Test-set driver, sustained run ({status})\n")
 print(f"8 full-atom pockets (286 / 287 atoms), {n_samples} accepted molecules each, 64 slots per batch, T = {T}, "
-      f"23 ligand atoms, default acceptance filter, forward cone pinned on (cone_mode = 2).\n")
+      f"23 ligand atoms, acceptance filter `{FILTER}`, forward cone pinned on (cone_mode = 2).\n")
 print(f"| batches | wall s | molecules generated | accepted (kept) | generated / s | accepted / s | mean s per pocket (+- std) |")
 print("|---|---|---|---|---|---|---|")
 secs = [j.seconds for j in jobs]
