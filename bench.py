@@ -1,15 +1,22 @@
 #!/usr/bin/env python
 """Benchmark of the DDPM sampling hot path on MI355X (contract: see the task
-description / DESIGN.md §Measurement).
+description / DESIGN.md 6 Measurement).
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete sampling chain over one batch of synthetic pockets:
-`ConditionalDDPM.sample_given_pocket` on BASELINE.json configs[2]
-(crossdock_fullatom_cond, 64 pockets per GPU, 23 ligand atoms each, T = 500
-reverse steps + the final decode = 501 EGNN evaluations).  Inputs are resident
-in HBM before the timed region; weights are seeded random (no checkpoint is
-reachable), pockets are the 3rfm full-atom pocket fixture repeated.
+One "step" = one complete sampling chain over one batch of synthetic pockets on
+BASELINE.json configs[2] (crossdock_fullatom_cond, 64 pockets per GPU, 23 ligand
+atoms each, T = 500 reverse steps + the final decode = 501 EGNN evaluations).
+Inputs are resident in HBM before the timed region; weights are seeded random (no
+checkpoint is reachable), pockets are the 3rfm full-atom pocket fixture repeated.
+
+Which call is timed: `value` is `ConditionalDDPM.inpaint` with every ligand atom
+known ("anchored" states, `--states anchored`, the default): the same 501 EGNN calls
+and fused updates as sampling, on the state distribution a TRAINED model's chain
+has (ligand inside the pocket) -- a free-running chain on random weights drifts out
+of the pocket and its calls get cheaper.  The metric's literal call,
+`ConditionalDDPM.sample_given_pocket` free-running, is timed in the same run as
+`other_states`, with its own kernel timing and roofline block.
 
 For N > 1 either the driver launches one process per GPU with torch.distributed.run,
 or a plain `python bench.py --gpus N` starts the same job itself (self_launch);
@@ -18,12 +25,17 @@ the finished ligands are gathered once per chain over RCCL.  value = ligands of
 all ranks / max-over-ranks wall time.
 
 The JSON line also carries
-  roofline     : the dominant kernel (fused GCL edge stage, csrc/edge_mlp.h) timed
-                 live with HIP events on its own stream; algorithmic FLOPs
-                 (E*(H^2 + (A+2)H) MAC per launch) / duration vs
-                 the 157.3 TFLOP/s fp32 matrix peak
-  cpu_baseline : the CPU oracle (a port of the reference's PyTorch path) timed on
-                 this host's cores on a bounded sample of the same workload.
+  roofline        : the dominant kernel (fused GCL edge stage, edge_wave_kernel<H, MODE_GCL>,
+                    csrc/edge_wave.h) timed live with HIP events on its own stream;
+                    algorithmic FLOPs (E_r (H^2 + (A+2) H) MAC per launch, E_r =
+                    edges of the rows the launch evaluates) / duration vs the 157.3 TFLOP/s
+                    fp32 matrix peak; the same over the whole call
+  cpu_baseline    : the reference's own modules (kind "reference", oracle/_ref, when the build
+                    shipped them) or the CPU oracle (kind "port") timed on this host's cores on
+                    a bounded sample of the same workload
+  other_workloads : one chain each of configs[1] (C-alpha x 32), configs[4] on one GPU (joint
+                    RePaint x 64) and the heterogeneous-pocket batch, so that the driver's
+                    record holds them
 """
 import argparse
 import json
@@ -75,17 +87,9 @@ def build_model(arch, device):
     return cfg, dd, model
 
 
-def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
-    """The oracle (CPU port of the reference path) on this host's cores:
-    `steps` consecutive reverse steps after one warm-up at batch b_cpu,
-    extrapolated to a full chain (>= 98.6 % of a chain is the per-step dynamics
-    call, SURVEY.md §3.4)."""
+def _cpu_problem(arch, key, b_cpu, n_lig):
+    """The CPU legs' inputs: the pocket batch (normalised) and the ligand's z_T mean, as sample_given_pocket builds them."""
     from oracle import ddpm_oracle as do
-    # torch's intra-op pool stops scaling long before a 256-core host is full (measured on
-    # the GPU box: 256 threads -> 75 s/step at batch 16, i.e. 30x SLOWER than 8 threads on an
-    # 8-core machine); use at most `max_threads` and report the number actually used.
-    cores = min(os.cpu_count() or 1, max_threads)
-    torch.set_num_threads(cores)
     cfg, dd = synthetic.arch_cfg(arch)
     sd = synthetic.random_state_dict(cfg, seed=0)
     m = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
@@ -95,8 +99,23 @@ def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
     _, pocket = do.normalize(m, None, pocket)
     xh_pocket = torch.cat([pocket["x"], pocket["one_hot"]], 1)
     lig_mask = torch.repeat_interleave(torch.arange(b_cpu), n_lig)
-    tape = do.NoiseTape(1234)
     mu = torch.cat((do._seg_mean(pocket["x"], pocket["mask"], b_cpu), torch.zeros(b_cpu, cfg["atom_nf"])), 1)[lig_mask]
+    return cfg, dd, sd, m, pocket, xh_pocket, lig_mask, mu
+
+
+def cpu_port(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
+    """The oracle (CPU port of the reference path) on this host's cores:
+    `steps` consecutive reverse steps after one warm-up at batch b_cpu,
+    extrapolated to a full chain (>= 98.6 % of a chain is the per-step dynamics
+    call, SURVEY.md 3.4)."""
+    from oracle import ddpm_oracle as do
+    # torch's intra-op pool stops scaling long before a 256-core host is full (measured on
+    # the GPU box: 256 threads -> 75 s/step at batch 16, i.e. 30x SLOWER than 8 threads on an
+    # 8-core machine); use at most `max_threads` and report the number actually used.
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    cfg, dd, sd, m, pocket, xh_pocket, lig_mask, mu = _cpu_problem(arch, key, b_cpu, n_lig)
+    tape = do.NoiseTape(1234)
     z, xp = do.cond_sample_normal_zero_com(m, mu, xh_pocket, torch.ones(b_cpu, 1), lig_mask, pocket["mask"], tape, b_cpu)
     T = dd["timesteps"]
     times = []
@@ -114,6 +133,67 @@ def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
             "sample": f"{steps} reverse steps (EGNN call + posterior update) of {arch} at batch {b_cpu} after 1 "
                       f"warm-up step, {t_step:.3f} s/step, extrapolated to {n_calls} EGNN calls per chain",
             "torch_threads": torch.get_num_threads()}
+
+
+def cpu_reference(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
+    """THE REFERENCE ITSELF on this host's cores: its own `ConditionalDDPM.sample_p_zs_given_zt` -> `EGNNDynamics.forward`
+    (conditional_model.py:432-464, dynamics.py:87-167) imported from oracle/_ref/reference_path.zip (oracle/make_ref.py:
+    the unmodified modules, shipped with the push; third-party stubs from oracle/ref_shim.py), same weights, same
+    pocket batch, same protocol as cpu_port.  None when the archive was not shipped."""
+    from oracle import make_ref
+    if not make_ref.available():
+        return None
+    os.environ["DIFFSBDD_REFERENCE"] = make_ref.ARCHIVE
+    import contextlib
+    import io
+    from oracle import ref_shim
+    if ref_shim.REF_ROOT != make_ref.ARCHIVE:
+        ref_shim.REF_ROOT = make_ref.ARCHIVE
+    dyn_mod, en_mod, cond_mod, _ = ref_shim.import_reference()
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    cfg, dd, sd, _, pocket, xh_pocket, lig_mask, mu = _cpu_problem(arch, key, b_cpu, n_lig)
+    with contextlib.redirect_stdout(io.StringIO()):
+        d = dyn_mod.EGNNDynamics(**cfg).eval()
+        d.load_state_dict(sd)
+        model = cond_mod.ConditionalDDPM(dynamics=d, atom_nf=cfg["atom_nf"], residue_nf=cfg["residue_nf"], n_dims=3,
+                                         size_histogram=np.ones((40, 400)), timesteps=dd["timesteps"],
+                                         noise_schedule=dd["noise_schedule"], noise_precision=dd["noise_precision"],
+                                         loss_type="l2", norm_values=dd["norm_values"]).eval()
+    torch.manual_seed(1234)
+    T = dd["timesteps"]
+    times = []
+    with torch.no_grad():
+        z, xp = model.sample_normal_zero_com(mu, xh_pocket, torch.ones(b_cpu, 1), lig_mask, pocket["mask"])
+        for i, s in enumerate(range(T - 1, T - 2 - steps, -1)):
+            s_arr = torch.full((b_cpu, 1), float(s)) / T
+            t_arr = torch.full((b_cpu, 1), float(s + 1)) / T
+            t0 = time.perf_counter()
+            z, xp = model.sample_p_zs_given_zt(s_arr, t_arr, z, xp, lig_mask, pocket["mask"])
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
+    t_step = float(np.mean(times))
+    return {"value": b_cpu / (t_step * n_calls), "unit": "ligands/s", "cores": cores, "kind": "reference",
+            "sample": f"{steps} reverse steps of the reference's own ConditionalDDPM.sample_p_zs_given_zt (oracle/_ref: its "
+                      f"unmodified modules) of {arch} at batch {b_cpu} after 1 warm-up step, {t_step:.3f} s/step, "
+                      f"extrapolated to {n_calls} EGNN calls per chain",
+            "torch_threads": torch.get_num_threads()}
+
+
+def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
+    """kind "reference" when oracle/_ref was shipped with the push (then the port's figure rides along as `port`),
+    else the port."""
+    port = cpu_port(arch, key, b_cpu, n_lig, n_calls, steps=steps, max_threads=max_threads)
+    try:
+        ref = cpu_reference(arch, key, b_cpu, n_lig, n_calls, steps=steps, max_threads=max_threads)
+    except Exception as exc:      # a broken archive must not cost the benchmark line
+        ref = None
+        port["reference_error"] = repr(exc)[:200]
+    if ref is None:
+        return port
+    ref["port"] = {k: port[k] for k in ("value", "sample")}
+    return ref
 
 
 def cpu_config0(max_threads=32):
@@ -163,6 +243,62 @@ def call_flops(cfg, lv, plan, N, E, joint):
     mac += L * (e_upd * n_mlp * (H * H + (A + 1) * H) + (n_act + n_lig) * n_mlp * H * H)   # coordinate stages
     mac += 2 * N * (cfg["joint_nf"] + 1) * H                       # embedding in / out
     return 2.0 * mac
+
+
+def secondary_workloads(device, n_lig_atoms):
+    """One timed chain (after one warm-up chain) of the other single-GPU configurations, so that the driver's record of
+    the default run holds them: BASELINE.json configs[1] (crossdock_ca_cond x 32), configs[4] on ONE GPU
+    (moad_fullatom_joint x 64, RePaint resamplings = 2: 1000 EGNN calls) and the heterogeneous-pocket variant of
+    configs[2] (3rfm / 5ndu alternating, every sample under its own rotation)."""
+    out = []
+    for workload, pockets in (("crossdock_ca_cond", "same"), ("crossdock_fullatom_cond", "mixed"),
+                              ("moad_fullatom_joint", "same")):
+        arch, key, B = WORKLOADS[workload]
+        cfg, dd, model = build_model(arch, device)
+        T = dd["timesteps"]
+        joint = not dd["conditional"]
+        n_calls = (sum(model.get_repaint_schedule(2, 1, T)) + 1) if joint else T + 1
+        n_lig = torch.full((B,), n_lig_atoms, dtype=torch.int64)
+        if pockets == "mixed":
+            pocket0, anchor = synthetic.mixed_pockets(key, B, n_lig_atoms, cfg["atom_nf"], device)
+        else:
+            pocket0 = load_pocket(key, B, device)
+            anchor = None if joint else anchor_ligand(B, n_lig_atoms, cfg["atom_nf"], device)
+
+        def chain(seed):
+            model.seed(seed)
+            pocket = {k: v.clone() for k, v in pocket0.items()}
+            if joint:
+                lmask = torch.repeat_interleave(torch.arange(B, device=device), n_lig_atoms)
+                ligand = {"x": torch.zeros(B * n_lig_atoms, 3, device=device),
+                          "one_hot": torch.zeros(B * n_lig_atoms, cfg["atom_nf"], device=device),
+                          "size": n_lig.to(device), "mask": lmask}
+                return model.inpaint(ligand, pocket, torch.zeros(B * n_lig_atoms, device=device),
+                                     torch.ones(pocket["x"].shape[0], device=device), resamplings=2, jump_length=1,
+                                     timesteps=T)
+            ligand = {k: v.clone() for k, v in anchor.items()}
+            return model.inpaint(ligand, pocket, torch.ones(B * n_lig_atoms, device=device), resamplings=1, timesteps=T)
+
+        chain(100)
+        torch.cuda.synchronize(device)
+        eng = model.dynamics.engine()
+        lv0 = eng.level_stats(raw=True)
+        t0 = time.perf_counter()
+        out_l = chain(200)[0]
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(out_l).all()
+        N = B * n_lig_atoms + pocket0["x"].shape[0]
+        lv, plan = eng.level_stats(since=lv0), eng.last_plan()
+        call = call_flops(cfg, lv, plan, N, eng.edge_count(N), joint)
+        whole = call * n_calls / dt / 1e12 if call else None
+        out.append({"workload": workload, "pockets": pockets, "batch": B, "states": None if joint else "anchored",
+                    "egnn_calls_per_chain": n_calls, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3,
+                    "steps": 1, "warmup": 1, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
+                    "stage_radii": plan[0], "stage_ghost": plan[1]})
+        del model, eng
+        torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(n, attempts=3):
@@ -224,7 +360,10 @@ def main():
                          "of the pocket (fewer ligand-pocket contacts, cheaper calls).  The other one is reported "
                          "as a secondary figure.")
     ap.add_argument("--no-other-leg", action="store_true", help="skip the secondary figure (the other state model)")
-    ap.add_argument("--other-steps", type=int, default=3, help="timed chains of the secondary figure")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed chains of the secondary figure")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the one-chain legs of the other single-GPU configurations (configs[1], configs[4] on one "
+                         "GPU, heterogeneous pockets) that ride along with the default run")
     ap.add_argument("--no-config0", action="store_true",
                     help="skip the end-to-end CPU run of BASELINE configs[0] (C-alpha, 4 samples, 50 steps)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -298,10 +437,10 @@ def main():
     for w in range(args.warmup):
         chain(100 + w)
     sync()
+    per_call = cfg["n_layers"] * cfg["inv_sublayers"]
     if not args.no_kernel_timing:
         # the GCL launches of every 8th EGNN call are bracketed by HIP events (those calls run eagerly,
         # the other 7 replay the engine's captured graph, as in production)
-        per_call = cfg["n_layers"] * cfg["inv_sublayers"]
         eng.profile(args.time_every, max_launches=(args.steps * n_calls // args.time_every + 2) * per_call)
     lv0 = eng.level_stats(raw=True)
     t0 = time.perf_counter()
@@ -315,20 +454,30 @@ def main():
     e_main = eng.edge_count(B * args.n_lig + pocket0["x"].shape[0])
     timed_level = eng.last_plan()[2]
     plan_main = eng.last_plan()
-    # secondary figure: the other state model of the pocket-conditioned chain (one warm-up, --other-steps timed chains)
+    # secondary figure: the other state model of the pocket-conditioned chain -- with --states anchored (default) this is
+    # the metric's LITERAL call, sample_given_pocket free-running -- one warm-up, --other-steps timed chains, its own
+    # kernel timing, level statistics and roofline block
     other = None
     if not joint and world == 1 and not args.no_other_leg:
         o_states = "free" if args.states == "anchored" else "anchored"
         chain(300, o_states)
         sync()
+        if not args.no_kernel_timing:
+            eng.profile(args.time_every, max_launches=(args.other_steps * n_calls // args.time_every + 2) * per_call)
         lv1 = eng.level_stats(raw=True)
         t1 = time.perf_counter()
         for k in range(args.other_steps):
             chain(301 + k, o_states)
         sync()
-        dt = (time.perf_counter() - t1) / args.other_steps
-        other = {"states": o_states, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3,
-                 "steps": args.other_steps, "live_levels": eng.level_stats(since=lv1)}
+        el_o = time.perf_counter() - t1
+        k_ms, k_n = (eng.profile_read() if not args.no_kernel_timing else (0.0, 0))
+        eng.profile(False, 0)
+        other = {"states": o_states, "call": ("ConditionalDDPM.sample_given_pocket (conditional_model.py:478-555)"
+                                              if o_states == "free" else "ConditionalDDPM.inpaint, all atoms known"),
+                 "value": B * args.other_steps / el_o, "unit": "ligands/s", "ms_per_step": el_o / args.other_steps * 1e3,
+                 "steps": args.other_steps, "live_levels": eng.level_stats(since=lv1),
+                 "_raw": (k_ms, k_n, eng.level_stats(since=lv1), eng.last_plan(), el_o,
+                          eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]))}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -339,54 +488,68 @@ def main():
 
     if rank == 0:
         N = B * args.n_lig + pocket0["x"].shape[0]
-        E = E_timed = e_main              # edges of the main leg's last call
-        # the timed launches are those of the largest radius of the call's plan (csrc/engine.hip): the rows of
-        # level <= timed_level, a prefix of the edge list whose mean length the engine accumulated
-        if lv_main is not None and timed_level < 4:
-            E_timed = lv_main["edges"][timed_level]
+        E = e_main                        # edges of the main leg's last call
         H = cfg["hidden_nf"]
         A = 2 + (cfg.get("edge_embedding_dim") or 0)
-        flops_per_launch = 2.0 * E_timed * (H * H + (A + 2) * H)
-        avg_ms = kern_ms / max(kern_n, 1)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if kern_n else None
-        # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
-        bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E_timed + 3 * N + N * H)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-        if args.workload == "crossdock_fullatom_cond" and B == 64 and args.states == "anchored" and \
-                args.pockets == "same" and os.path.isfile(tpath):
-            # PMC counters cannot be read from inside this process; the figure is the one measured
-            # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
-            tj = json.load(open(tpath))
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc, gfx950-corrected)"
-        # algorithmic work of a WHOLE call from what the stages evaluated (mean over the timed chains): SURVEY.md 8d's
-        # F_min restricted to the rows / edges of every stage's radius
-        call = call_flops(cfg, lv_main, plan_main, N, E, joint)
-        whole = call * n_calls * args.steps / elapsed / 1e12 if call else None
-        roofline = {
-            "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
-            "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-            "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E_timed,
-            "algorithmic_flops_per_launch": flops_per_launch,
-            # timed = the message-stage launches that run over the WHOLE edge list (same work every launch).
-            # Pocket-conditioned chains: block 0 is split by the pocket frame and the last stages run on prefixes
-            # of the level-ordered list (csrc/graph.h), so fewer than n_layers launches per call qualify.
-            "timed_launch_kind": ("full edge list" if lv_main is None or timed_level >= 4
-                                  else f"rows of hop level <= {timed_level} (the call's largest message-stage launches)"),
-            # share of the timed region's wall time spent in the timed launches (timed on every k-th call only)
-            "kernel_share_of_wall": (kern_ms * args.time_every / (elapsed * 1e3)) if kern_n else None,
-            # the same roofline over the WHOLE call: algorithmic FLOP of everything a call evaluates / wall time
-            "whole_call_tflops": whole, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
-            "algorithmic_flops_per_call": call, "stage_radii": plan_main[0], "stage_ghost": plan_main[1],
-            # mean over the calls of the chain: nodes / edge-list slots with hop level <= r (r = 0: ligand rows,
-            # r = 4: everything); message stage g of G evaluates level <= G - g
-            "live_levels": lv_main,
-            "hbm_algorithmic_gbps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None,
-            "hbm_frac_of_8TBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_n else None,
-        }
+
+        def roofline_of(kern_ms, kern_n, lv, plan, elapsed_s, n_chains, e_last, with_traffic):
+            """The roofline block of one leg: the dominant kernel's timed launches and the whole call."""
+            t_level = plan[2]
+            # the timed launches are those of the largest radius of the call's plan (csrc/engine.hip): the rows of
+            # level <= t_level, a prefix of the edge list whose mean length the engine accumulated
+            E_timed = e_last
+            if lv is not None and t_level < 4:
+                E_timed = lv["edges"][t_level]
+            flops_per_launch = 2.0 * E_timed * (H * H + (A + 2) * H)
+            avg_ms = kern_ms / max(kern_n, 1)
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if kern_n else None
+            # algorithmic HBM bytes of the same launch: P|Q read once per node, W2^T, edge list, agg written
+            bytes_per_launch = 4.0 * (N * 2 * H + H * H + 3 * E_timed + 3 * N + N * H)
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+            if with_traffic and args.workload == "crossdock_fullatom_cond" and B == 64 and args.states == "anchored" and \
+                    args.pockets == "same" and os.path.isfile(tpath):
+                # PMC counters cannot be read from inside this process; the figure is the one measured
+                # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
+                tj = json.load(open(tpath))
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc, gfx950-corrected)"
+            # algorithmic work of a WHOLE call from what the stages evaluated (mean over the timed chains): SURVEY.md
+            # 8d's F_min restricted to the rows / edges of every stage's radius
+            call = call_flops(cfg, lv, plan, N, e_last, joint)
+            whole = call * n_calls * n_chains / elapsed_s / 1e12 if call else None
+            return {
+                "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
+                "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E_timed,
+                "algorithmic_flops_per_launch": flops_per_launch,
+                # timed = the message-stage launches that run over the WHOLE edge list (same work every launch).
+                # Pocket-conditioned chains: block 0 is split by the pocket frame and the last stages run on prefixes
+                # of the level-ordered list (csrc/graph.h), so fewer than n_layers launches per call qualify.
+                "timed_launch_kind": ("full edge list" if lv is None or t_level >= 4
+                                      else f"rows of hop level <= {t_level} (the call's largest message-stage launches)"),
+                # share of the leg's wall time spent in the timed launches (timed on every k-th call only)
+                "kernel_share_of_wall": (kern_ms * args.time_every / (elapsed_s * 1e3)) if kern_n else None,
+                # the same roofline over the WHOLE call: algorithmic FLOP of everything a call evaluates / wall time
+                "whole_call_tflops": whole, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
+                "algorithmic_flops_per_call": call, "stage_radii": plan[0], "stage_ghost": plan[1],
+                # mean over the calls of the chain: nodes / edge-list slots with hop level <= r (r = 0: ligand rows,
+                # r = 4: everything); message stage g of G evaluates level <= G - g
+                "live_levels": lv,
+                "hbm_algorithmic_gbps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None,
+                "hbm_frac_of_8TBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_n else None,
+            }
+
+        roofline = roofline_of(kern_ms, kern_n, lv_main, plan_main, elapsed, args.steps, e_main, True)
+        if other is not None:
+            k_ms, k_n, lv_o, plan_o, el_o, e_o = other.pop("_raw")
+            other["roofline"] = roofline_of(k_ms, k_n, lv_o, plan_o, el_o, args.other_steps, e_o, False)
+        other_workloads = None
+        if world == 1 and not args.no_other_workloads and args.workload == "crossdock_fullatom_cond" and \
+                args.pockets == "same" and args.timesteps is None and args.batch is None:
+            other_workloads = secondary_workloads(device, args.n_lig)
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not joint:
             cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, steps=args.cpu_steps,
@@ -410,7 +573,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
-            "roofline": roofline, "cpu_baseline": cpu, "other_states": other,
+            "roofline": roofline, "cpu_baseline": cpu, "other_states": other, "other_workloads": other_workloads,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
             "hipgraph": dict(zip(("replays", "captures", "eager_calls"), eng.graph_stats())),
             "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,

@@ -22,6 +22,8 @@ import math
 from typing import Dict
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -587,11 +589,20 @@ class EnVariationalDiffusion(nn.Module):
             raise ValueError("NaN detected in EGNN output")
 
     share_identical_pockets = True   # evaluate block 0's pocket-pocket messages once for a batch of identical pockets
-    # forward cone of the engine (csrc/engine.hip): 1 = when the engine's cost model says it pays (few distinct pockets
-    # in the batch), 2 = always, 0 = never.  Cone on / off differ in rounding (the canonical pocket is evaluated on the
-    # raw pocket coordinates), so a driver that wants bit-identical molecules for ANY packing of pockets into batches
-    # pins the mode (testset.TestSetDriver uses 2); None leaves the engine's setting (DSBDD_CONE) alone.
+    # forward cone of the engine (csrc/engine.hip): 2 = on, 0 = off (1 = the engine's own cost model, for direct C-API
+    # callers).  Cone on / off differ in rounding (the canonical pocket is evaluated on the raw pocket coordinates), so the
+    # mode is decided HERE, once per chain and from the pocket groups alone (`_cone_for_groups`: on while the distinct
+    # pockets are at most 0.4 of the batch -- one pocket repeated, the reference's generate_ligands / test.py case: on;
+    # every pocket different: off), never by an engine heuristic in the middle of a chain.  A driver that wants
+    # bit-identical molecules for ANY packing of pockets into batches pins the mode (testset.make_hip_sampler: 2 for
+    # the duration of a batch); the environment variable DSBDD_CONE overrides both.
     cone_mode = None
+
+    @staticmethod
+    def _cone_for_groups(rep, batch):
+        """2 (on) / 0 (off) from representative[b] (None: every sample its own pocket)."""
+        n_groups = batch if rep is None else int(torch.unique(rep).numel())
+        return 2 if 5 * n_groups <= 2 * batch else 0
     frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
                                      # extra launches of the split cost more than their few pocket-pocket edges
 
@@ -622,8 +633,9 @@ class EnVariationalDiffusion(nn.Module):
             if self.share_identical_pockets:
                 rep = self._pocket_groups(x, pocket['one_hot'].to(dev), sizes, batch)
             self.dynamics.engine().set_pocket_frame(x, pm, sizes, lm.numel(), batch, cap, representative=rep)
-            if self.cone_mode is not None:
-                self.dynamics.engine().set_option(_lib.OPT_CONE, int(self.cone_mode))
+            mode = self.cone_mode if self.cone_mode is not None else self._cone_for_groups(rep, batch)
+            env = os.environ.get("DSBDD_CONE")
+            self.dynamics.engine().set_option(_lib.OPT_CONE, int(env) if env not in (None, "") else int(mode))
             self._framed = True
         return lm, pm
 

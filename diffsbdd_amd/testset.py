@@ -214,8 +214,6 @@ def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bia
     the GPU (LigandGenerator.generate_for_pockets).  Global sample id of slot k of a job's r-th round =
     index * 2^20 + (samples generated for the job so far) + k: independent of the packing."""
     import torch
-    gen.ddpm.cone_mode = 2     # bit-identical molecules for any packing: the engine's forward cone must not switch
-                               # with the number of distinct pockets in a batch (en_diffusion.cone_mode)
 
     def ligand_sizes(job, ids):
         """Ligand sizes of the slots `ids` of one job: fixed, or drawn from p(n_lig | n_pocket)
@@ -233,9 +231,17 @@ def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bia
     def sample_batch(plan, batch_no):
         ids = [job.index * (1 << 20) + job.n_generated + torch.arange(n) for job, n in plan]
         jobs = [(job.residues, n, ligand_sizes(job, i)) for (job, n), i in zip(plan, ids)]
-        return gen.generate_for_pockets(jobs, timesteps=timesteps, largest_frag=largest_frag,
-                                        n_nodes_bias=n_nodes_bias, n_nodes_min=n_nodes_min, seed=seed,
-                                        sample_ids=torch.cat(ids), **kwargs)
+        # bit-identical molecules for any packing: the engine's forward cone must not switch with the number of
+        # distinct pockets in a batch (en_diffusion.cone_mode) -- pinned on for this batch only, the generator's own
+        # setting is restored afterwards
+        saved = gen.ddpm.cone_mode
+        gen.ddpm.cone_mode = 2
+        try:
+            return gen.generate_for_pockets(jobs, timesteps=timesteps, largest_frag=largest_frag,
+                                            n_nodes_bias=n_nodes_bias, n_nodes_min=n_nodes_min, seed=seed,
+                                            sample_ids=torch.cat(ids), **kwargs)
+        finally:
+            gen.ddpm.cone_mode = saved
 
     return sample_batch
 

@@ -4,8 +4,11 @@
   * oracle/ (our CPU restatement) can be validated against the real thing, and
   * tests/golden/make_golden.py can generate the committed golden vectors.
 
-/root/reference does not exist on the GPU box, so nothing in `-m gpu` tests,
-smoke() or bench.py may import this module.  It copies no reference source; it
+/root/reference does not exist on the GPU box, so nothing in `-m gpu` tests or
+smoke() may import this module; bench.py's `cpu_baseline` leg uses it with
+DIFFSBDD_REFERENCE = oracle/_ref/reference_path.zip (oracle/make_ref.py: the
+reference's own modules of this path, shipped with the push) to time the
+reference itself on the GPU host.  It copies no reference source; it
 only provides stand-ins for third-party modules that are missing in this image
 (SURVEY.md §8c):
 
@@ -22,6 +25,13 @@ REF_ROOT = os.environ.get("DIFFSBDD_REFERENCE", "/root/reference")
 
 
 def reference_available() -> bool:
+    if REF_ROOT.endswith(".zip"):      # oracle/_ref/reference_path.zip (oracle/make_ref.py): imported through zipimport
+        import zipfile
+        try:
+            with zipfile.ZipFile(REF_ROOT) as z:
+                return "equivariant_diffusion/egnn_new.py" in z.namelist()
+        except (OSError, zipfile.BadZipFile):
+            return False
     return os.path.isfile(os.path.join(REF_ROOT, "equivariant_diffusion", "egnn_new.py"))
 
 

@@ -23,33 +23,52 @@ __global__ void step_kernel(float* buf, int n) {
   if (i < n) buf[i] += 1.f;
 }
 
-// ctr[0]: global arrivals, ctr[1 .. 8]: per-XCD arrivals, ctr[16]: error flag.  Generation-counting barrier: the
-// target of barrier number g is g * (number of arrivals per generation); counters only grow (zeroed by the host).
+// Counters (unsigned words, zeroed by the host; every word on its own 128-byte line): ctr[0] top-level arrivals,
+// ctr[32 * (1 + x)] arrivals of group x, ctr[32 * (9 + x)] generation word of group x, ctr[32 * 17] error flag.
+// Groups = blockIdx.x & 7: the observed workgroup -> XCD mapping (speed only; the counts are exact for ANY placement).
+// HIER = the XCD-hierarchical barrier of the guide (MI355X_MICROARCH.md "barrier-xcd"): every workgroup arrives on its
+// group's counter (lane-0 agent release first); the group's LAST arriver -- the leader -- arrives on the top counter,
+// polls it (relaxed loads, s_sleep), takes one agent acquire and publishes the group's generation word; every other
+// workgroup polls only ITS group's generation word and takes one agent acquire.  8 pollers on the top line, n_wg / 8
+// on each group line, instead of n_wg pollers on one line (what round 3's version did: 18 - 40 us per barrier).
+// Generation counting: counters only grow, the target of barrier number g is (g + 1) * arrivals per generation.
+constexpr int kLine = 32;
+__device__ __forceinline__ bool poll_ge(unsigned* w, unsigned target, unsigned* err) {
+  long spins = 0;
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > 400000) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+  }
+  return true;
+}
+
 template <bool HIER>
 __device__ __forceinline__ bool grid_barrier(unsigned* ctr, unsigned gen, unsigned n_wg) {
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
-    __threadfence();
+    unsigned* err = ctr + kLine * 17;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (HIER) {
-      const unsigned xcd = blockIdx.x & 7, per = n_wg >> 3;
-      if (atomicAdd(&ctr[1 + xcd], 1u) == gen * per + per - 1) atomicAdd(&ctr[0], 1u);
-      const unsigned target = (gen + 1) * 8;
-      long spins = 0;
-      while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(4);         // back off: the pollers share one L2 line with the arriving atomics
-        if (++spins > 400000) { ctr[16] = 1; ok = false; break; }
+      const unsigned x = blockIdx.x & 7, per = n_wg >> 3;
+      unsigned* grp = ctr + kLine * (1 + x);
+      unsigned* genw = ctr + kLine * (9 + x);
+      const unsigned ticket = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == gen * per + per - 1) {                       // the group's leader
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = poll_ge(ctr, (gen + 1) * 8, err);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(genw, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        ok = poll_ge(genw, gen + 1, err);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
     } else {
-      atomicAdd(&ctr[0], 1u);
-      const unsigned target = (gen + 1) * n_wg;
-      long spins = 0;
-      while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > 400000) { ctr[16] = 1; ok = false; break; }
-      }
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = poll_ge(ctr, (gen + 1) * n_wg, err);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __threadfence();
   }
   __syncthreads();
   return ok;
@@ -61,7 +80,7 @@ __global__ __launch_bounds__(256) void persistent_kernel(float* buf, int n, int 
   for (int s = 0; s < steps; ++s) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_wg * blockDim.x) buf[i] += 1.f;
     if (!grid_barrier<HIER>(ctr, (unsigned)s, n_wg)) return;
-    if (__hip_atomic_load(&ctr[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (__hip_atomic_load(&ctr[kLine * 17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   }
 }
 
@@ -71,7 +90,7 @@ int main() {
   unsigned* ctr;
   CK(hipMalloc(&buf, n * 4));
   CK(hipMemset(buf, 0, n * 4));
-  CK(hipMalloc(&ctr, 64 * 4));
+  CK(hipMalloc(&ctr, 32 * 18 * 4));
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t a, b;
@@ -108,7 +127,7 @@ int main() {
       const int cover = grid * 256;
       float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
-        CK(hipMemsetAsync(ctr, 0, 64 * 4, st));
+        CK(hipMemsetAsync(ctr, 0, 32 * 18 * 4, st));
         CK(hipEventRecord(a, st));
         if (hier) hipLaunchKernelGGL((persistent_kernel<true>), dim3(grid), dim3(256), 0, st, buf, cover, steps, ctr);
         else hipLaunchKernelGGL((persistent_kernel<false>), dim3(grid), dim3(256), 0, st, buf, cover, steps, ctr);
@@ -116,8 +135,8 @@ int main() {
         CK(hipEventSynchronize(b));
         CK(hipEventElapsedTime(&ms, a, b));
       }
-      unsigned h[17];
-      CK(hipMemcpy(h, ctr, 17 * 4, hipMemcpyDeviceToHost));
+      unsigned h[17] = {0};
+      CK(hipMemcpy(&h[16], ctr + 32 * 17, 4, hipMemcpyDeviceToHost));
       printf("| one kernel, %d steps, %s grid barrier%s | %d | %.2f |\n", steps, hier ? "XCD-hierarchical" : "flat",
              h[16] ? " (BARRIER TIMED OUT)" : "", grid, ms * 1e3 / steps);
     }
