@@ -56,6 +56,8 @@ struct EdgeMlpW {
   // W2TP[k][j * (H/32) + c] = W2T[k][c * 32 + j], so that lane j finds the B values of all its
   // column tiles in consecutive words (16-byte LDS reads in edge_wave.h); nullptr = not available
   const float* W2TP;
+  // optional: the lane-grouped copy of the 16-edge-granule kernel (edge_wave16.h), W2TP16[k][16 n + c] = W2T[k][16 c + n]
+  const float* W2TP16;
 };
 
 struct EdgeArgs {
@@ -101,14 +103,15 @@ enum { MODE_GCL = 0, MODE_COORD = 1 };
 // agg[row] <- agg[row] + agg_head[T0 + 1] + ... + agg_head[T1] (tile order); rows without edges
 // become 0.  One wave per row, 16-byte lanes; rows that live in a single tile (about half of them
 // at degree ~17) are left untouched.  Costs what the zero fill of the atomic version cost.
+// `shift`: log2 of the wave-tile size of the edge kernel that wrote the partial sums (5: edge_wave.h, 4: edge_wave16.h).
 __global__ __launch_bounds__(kThreads) void agg_complete_kernel(float* agg, const float* agg_head,
                                                                 const int* row_ptr, const int* deg,
-                                                                int n_rows, int H, int max_tile) {
+                                                                int n_rows, int H, int max_tile, int shift) {
   const int row = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= n_rows) return;
   const int d = deg[row], s = row_ptr[row];
   // (max_tile: last slot of agg_head -- after an edge-capacity overflow row_ptr describes edges that were never stored)
-  const int t0 = s >> 5, t1 = min((s + d - 1) >> 5, max_tile);
+  const int t0 = s >> shift, t1 = min((s + d - 1) >> shift, max_tile);
   if (d > 0 && t1 == t0) return;
   for (int k = 4 * lane; k < H; k += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

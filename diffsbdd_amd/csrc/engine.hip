@@ -14,6 +14,7 @@
 #include "ddpm.h"
 #include "edge_mlp.h"
 #include "edge_wave.h"
+#include "edge_wave16.h"
 #include "graph.h"
 #include "molecule.h"
 #include "node_chain.h"
@@ -76,6 +77,10 @@ struct dsbdd_engine {
                                         // pocket of a chain: coordinates up to translation AND features, which never change in
                                         // pocket-conditioning mode) -> framed calls after the first run the ligand encoder only
   int64_t cap_tiles = 0;                // wave tiles (32 edges) of the edge capacity
+  int64_t cap_tiles16 = 0;              // the same in 16-edge tiles (edge_wave16.h)
+  unsigned granule16 = 0;               // DSBDD_OPT_GRANULE16: bit g = message stage g, bit 16 + b = coordinate stage of block b
+                                        // run on the 16-edge-granule kernels (default: none; DSBDD_GRANULE16=<mask> in the environment)
+  bool w2tp16_ready = false;            // their lane-grouped W2^T copies are current
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   bool w2tp_ready = false;   // lane-grouped W2^T copies in the workspace are current
@@ -162,8 +167,8 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * JP * 4,                                                                           // 18 hout
       (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
       (size_t)NG * 2 * H * 4,                                                                       // 22 pqg (GCL P|Q)
-      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 4,                                      // 23 lane-grouped W2^T copies
-      (size_t)T * H * 4, (size_t)T * 2 * 16,                                                        // 24 agg_head, 25 xagg_head[2][T][4]
+      (size_t)2 * c.n_layers * (c.inv_sublayers + 2) * H * H * 4,                                  // 23 lane-grouped W2^T copies (32- and 16-edge kernels)
+      (size_t)2 * T * H * 4, (size_t)2 * T * 2 * 16,                                                // 24 agg_head, 25 xagg_head[2][T][4] (16-edge tiles: 2 T slots)
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4,                       // 26 scan_tmp 27 seg_base 28 tile_ctr
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 29-33 list 2: erow ecol ed0 row_ptr deg
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4,                                                 // 34 scan_tmp2 35 seg_base2
@@ -222,6 +227,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
+  if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
   const char* cn = getenv("DSBDD_CONE");
   if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
   const char* nch = getenv("DSBDD_NODE_CHAIN");
@@ -264,6 +270,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
   }
   e->drop_graphs();
   e->w2tp_ready = false;
+  e->w2tp16_ready = false;
   e->wchain_ready = false;
   e->h0_pocket_valid = false;
   e->has_weights = true;
@@ -301,6 +308,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->scan_tmp = (int*)(b + L.off[26]); e->seg_base = (int*)(b + L.off[27]); e->tile_ctr = (int*)(b + L.off[28]);
   e->cap_edgesL = 2 * E + 32 * kLevels * B;
   e->cap_tiles = e->cap_edgesL / 32 + 2;
+  e->cap_tiles16 = e->cap_edgesL / 16 + 2;   // head slots of the 16-edge-granule kernels (edge_wave16.h); <= 2 * cap_tiles
   e->lvl = (int*)(b + L.off[50]); e->seg_rows = (int*)(b + L.off[51]); e->seg_edges = (int*)(b + L.off[52]);
   e->node_base = (int*)(b + L.off[53]); e->edge_base = (int*)(b + L.off[54]);
   e->lvl_cnt = (int*)(b + L.off[55]); e->lvl_end = (int*)(b + L.off[56]);
@@ -324,6 +332,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->ghost_dirty = true;
   e->h0_pocket_valid = false;
   e->w2tp_ready = false;
+  e->w2tp16_ready = false;
   return DSBDD_OK;
 }
 
@@ -418,6 +427,7 @@ int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value) {
   switch (which) {
     case DSBDD_OPT_PRUNE: e->prune = value ? 1 : 0; break;
     case DSBDD_OPT_CONE: e->cone = value <= 0 ? 0 : (value >= 2 ? 2 : 1); break;   // 0 off, 1 by the cost model, 2 always
+    case DSBDD_OPT_GRANULE16: e->granule16 = (unsigned)value; break;               // bit g: message stage g, bit 16 + b: coordinate stage b
     default: return fail(DSBDD_ERR_ARG, "unknown option");
   }
   e->drop_graphs();
@@ -526,8 +536,33 @@ static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int 
   return hipGetLastError();
 }
 
+template <int H>
+static hipError_t launch_wave16_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
+  if (mode == MODE_GCL) hipLaunchKernelGGL((edge_wave16_kernel<H, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((edge_wave16_kernel<H, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
+  return hipGetLastError();
+}
+
+// 16-edge-granule variant (edge_wave16.h): 64-edge workgroup items, one per (tile, MLP), persistent over 2 workgroups per CU
+static hipError_t launch_edge16(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a, int64_t edge_bound) {
+  const int H = e->cfg.hidden_nf;
+  int64_t items = (edge_bound + 63) / 64 * (mode == MODE_COORD ? a.n_mlp : 1);
+  int64_t resident = 2LL * e->n_cu;
+  if (e->edge_max_wg > 0 && e->edge_max_wg < resident) resident = e->edge_max_wg;
+  int grid = (int)(items < resident ? items : resident);
+  if (grid < 1) grid = 1;
+  switch (H) {
+    case 64: return launch_wave16_t<64>(s, mode, a, grid);
+    case 128: return launch_wave16_t<128>(s, mode, a, grid);
+    case 192: return launch_wave16_t<192>(s, mode, a, grid);
+    case 256: return launch_wave16_t<256>(s, mode, a, grid);
+  }
+  return hipErrorInvalidValue;
+}
+
 static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
-                              int64_t edge_bound) {
+                              int64_t edge_bound, bool g16 = false) {
+  if (g16) return launch_edge16(e, s, mode, a, edge_bound);
   const int H = e->cfg.hidden_nf;
   // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU, persistent over tiles
   int64_t tiles = (edge_bound + 127) / 128;
@@ -779,6 +814,22 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   auto w2tp_of = [&](int blk, int which) -> const float* {   // which: 0 .. inv_sublayers-1 GCL, then coord, cross
     return bperm ? e->w2tp + ((size_t)blk * (c.inv_sublayers + 2) + which) * H * H : nullptr;
   };
+  const size_t n_w2 = (size_t)c.n_layers * (c.inv_sublayers + 2);
+  auto w2tp16_of = [&](int blk, int which) -> const float* {
+    return e->granule16 ? e->w2tp + (n_w2 + (size_t)blk * (c.inv_sublayers + 2) + which) * H * H : nullptr;
+  };
+  if (e->granule16 && !e->w2tp16_ready) {
+    for (int blk = 0; blk < c.n_layers; ++blk)
+      for (int which = 0; which < c.inv_sublayers + 2; ++which) {
+        const float* src = which < c.inv_sublayers ? W[gcl_slot(c, blk, which, DSBDD_GCL_E2_WT)]
+                         : W[eq_slot(c, blk, which == c.inv_sublayers ? DSBDD_EQ_C_W2T : DSBDD_EQ_X_W2T)];
+        if (!src) continue;
+        hipLaunchKernelGGL(pack16_w2t_kernel, dim3((H * H + 255) / 256), dim3(256), 0, s, src,
+                           const_cast<float*>(w2tp16_of(blk, which)), H);
+        HIP_TRY(hipGetLastError());
+      }
+    e->w2tp16_ready = true;
+  }
   if (bperm && !e->w2tp_ready) {
     for (int blk = 0; blk < c.n_layers; ++blk)
       for (int which = 0; which < c.inv_sublayers + 2; ++which) {
@@ -868,8 +919,10 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.e_cap = L_cap - (int)begin; ea.wt_base = (int)(begin / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
-                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub)};
+                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub), w2tp16_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
+      // 16-edge-granule variant of this stage (engine option; never for block 0's two-list launch of a framed call)
+      const bool g16 = ((e->granule16 >> (g & 15)) & 1u) && !(split0 && blk == 0 && sub == 0);
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
       ea.agg = e->agg; ea.agg_head = e->agg_head; ea.tile_ctr = e->tile_ctr;
       ea.norm_factor = c.normalization_factor;
@@ -898,7 +951,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // (timed: the launches over the whole list only, so that every timed launch is the same work)
         const bool timed = e->time_now && (all_rows || radius == e->plan_timed_level) && e->ev_used + 2 <= e->ev.size();
         if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
-        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, L_bound));
+        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, L_bound, g16));
         if (timed) {
           HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
           e->ev_used += 2;
@@ -906,7 +959,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // complete the rows whose edges span several wave tiles (ordered head partial sums, edge_mlp.h)
         const int n_rows = N + (ghost ? n_ghost : 0);
         hipLaunchKernelGGL(agg_complete_kernel, dim3((n_rows + 3) / 4), dim3(kThreads), 0, s, e->agg,
-                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, n_rows, H, (int)e->cap_tiles - 1);
+                           (const float*)e->agg_head, L_ptr, (const int*)e->deg, n_rows, H,
+                           (int)(g16 ? e->cap_tiles16 : e->cap_tiles) - 1, g16 ? 4 : 5);
         HIP_TRY(hipGetLastError());
       }
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
@@ -1020,23 +1074,26 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.e_cap = L_cap - (int)ghost_slots; ea.wt_base = (int)(ghost_slots / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
-                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers)};
+                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers), w2tp16_of(blk, c.inv_sublayers)};
       if (n_mlp == 2)
         ea.mlp[1] = EdgeMlpW{e->pq + QW + H, e->pq + H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
-                             Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2), w2tp_of(blk, c.inv_sublayers + 1)};
+                             Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2), w2tp_of(blk, c.inv_sublayers + 1),
+                             w2tp16_of(blk, c.inv_sublayers + 1)};
       else
         ea.mlp[1] = ea.mlp[0];
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
       ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
       ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.xagg_head = e->xagg_head;
-      ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = (size_t)e->cap_tiles * 4;
+      const bool c16 = (e->granule16 >> (16 + (blk & 15))) & 1u;          // 16-edge-granule variant of this stage
+      ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = (size_t)(c16 ? e->cap_tiles16 : e->cap_tiles) * 4;
       ea.tile_ctr = e->tile_ctr; ea.norm_factor = c.normalization_factor;
-      ea.pass_split = e->coord_split;
+      ea.pass_split = c16 ? 1 : e->coord_split;
       if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
      
-      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, L_bound));
+      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, L_bound, c16));
       {
-        const int n_q = (e->coord_split && n_mlp == 2) ? 2 : 1;
+        const int n_q = ((e->coord_split || c16) && n_mlp == 2) ? 2 : 1;   // (the 16-edge kernel keeps one sum per MLP)
+        const int c_shift = c16 ? 4 : 5, c_max = (int)(c16 ? e->cap_tiles16 : e->cap_tiles) - 1;
         // few updated rows (the ligand's): one workgroup per sample updates them and reduces the next block's mean;
         // all rows updated (joint model): the wide per-component kernel, the mean stays a launch of its own
         const bool next_mean = subset && n_mlp == 2 && blk + 1 < c.n_layers;
@@ -1044,14 +1101,14 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
           if (n_upd > 0) {
             hipLaunchKernelGGL(coord_update_kernel, dim3((3 * n_upd + 255) / 256), dim3(256), 0, s, e->x,
                                (const float*)e->xagg, (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride,
-                               L_ptr, (const int*)e->deg, 3 * n_upd, (int)e->cap_tiles - 1);
+                               L_ptr, (const int*)e->deg, 3 * n_upd, c_max, c_shift);
             HIP_TRY(hipGetLastError());
           }
         } else if (n_upd > 0 || next_mean) {
           hipLaunchKernelGGL(coord_update_mean_kernel, dim3(B), dim3(kThreads), 0, s, e->x, (const float*)e->xagg,
                              (const float*)e->xagg_head, n_q, ea.xagg_stride, ea.xhead_stride, L_ptr,
                              (const int*)e->deg, n_upd, (const int*)e->lig_off, (const int*)e->poc_off, nlig,
-                             next_mean ? e->mean : (float*)nullptr, (int)e->cap_tiles - 1);
+                             next_mean ? e->mean : (float*)nullptr, c_max, c_shift);
           HIP_TRY(hipGetLastError());
         }
       }
@@ -1582,7 +1639,7 @@ int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g,
   ea.agg = agg; ea.agg_head = ts.agg_head; ea.norm_factor = norm_factor;
   if (g->n_edges > 0) HIP_TRY(launch_edge_plain(H, s, MODE_GCL, ea, g->n_edges));
   hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, agg, (const float*)ts.agg_head,
-                     g->row_ptr, g->deg, N, (int)H, (int)((g->n_edges + 31) / 32 + 1));
+                     g->row_ptr, g->deg, N, (int)H, (int)((g->n_edges + 31) / 32 + 1), 5);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }
@@ -1632,7 +1689,7 @@ int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* 
   HIP_TRY(launch_edge_plain(H, s, MODE_COORD, ea, g->n_edges));
   hipLaunchKernelGGL(coord_update_kernel, dim3((unsigned)((3 * n_upd + 255) / 256)), dim3(256), 0, s, x_out,
                      (const float*)ts.xagg, (const float*)ts.xagg_head, 1, ea.xagg_stride, ea.xhead_stride, g->row_ptr,
-                     g->deg, (int)(3 * n_upd), (int)((g->n_edges + 31) / 32 + 1));
+                     g->deg, (int)(3 * n_upd), (int)((g->n_edges + 31) / 32 + 1), 5);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
 }

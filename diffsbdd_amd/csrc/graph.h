@@ -628,13 +628,13 @@ __global__ __launch_bounds__(kThreads) void sample_mean_kernel(const float* x, c
 // they are added here in tile order (fixed summation order, no atomics).
 __global__ void coord_update_kernel(float* x, const float* xagg, const float* xhead, int n_q,
                                     size_t xagg_stride, size_t xhead_stride, const int* row_ptr,
-                                    const int* deg, int n_upd3, int max_tile) {
+                                    const int* deg, int n_upd3, int max_tile, int shift) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_upd3) return;
   const int i = idx / 3, c = idx - 3 * i;
   const int d = deg[i];
   if (d == 0) return;
-  const int s = row_ptr[i], t0 = s >> 5, t1 = min((s + d - 1) >> 5, max_tile);   // (max_tile: see agg_complete_kernel)
+  const int s = row_ptr[i], t0 = s >> shift, t1 = min((s + d - 1) >> shift, max_tile);   // (max_tile, shift: see agg_complete_kernel)
   float tot = 0.f;
   for (int q = 0; q < n_q; ++q) {
     float a = xagg[q * xagg_stride + idx];
@@ -650,7 +650,7 @@ __global__ void coord_update_kernel(float* x, const float* xagg, const float* xh
 __global__ __launch_bounds__(kThreads) void coord_update_mean_kernel(
     float* x, const float* xagg, const float* xhead, int n_q, size_t xagg_stride, size_t xhead_stride,
     const int* row_ptr, const int* deg, int n_upd, const int* lig_off, const int* poc_off, int n_lig, float* mean,
-    int max_tile) {
+    int max_tile, int shift) {
   __shared__ float red[3][kThreads];
   const int b = blockIdx.x, t = threadIdx.x;
   const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void coord_update_mean_kernel(
       const int i = k / 3, c = k - 3 * i;
       const int d = deg[i];
       if (d == 0) continue;
-      const int s = row_ptr[i], t0 = s >> 5, t1 = min((s + d - 1) >> 5, max_tile);
+      const int s = row_ptr[i], t0 = s >> shift, t1 = min((s + d - 1) >> shift, max_tile);
       float tot = 0.f;
       for (int q = 0; q < n_q; ++q) {
         float v = xagg[q * xagg_stride + k];

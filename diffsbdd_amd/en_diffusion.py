@@ -603,6 +603,10 @@ class EnVariationalDiffusion(nn.Module):
         """2 (on) / 0 (off) from representative[b] (None: every sample its own pocket)."""
         n_groups = batch if rep is None else int(torch.unique(rep).numel())
         return 2 if 5 * n_groups <= 2 * batch else 0
+    # 16-edge-granule edge kernels (csrc/edge_wave16.h, include/diffsbdd_hip.h DSBDD_OPT_GRANULE16): bit mask of the stages
+    # that use them; None leaves the engine's setting (default 0, environment DSBDD_GRANULE16) alone.  The variants agree to
+    # rounding, so the mask is part of a chain's definition like `cone_mode`: set once, never changed by the engine.
+    edge_granule16 = None
     frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
                                      # extra launches of the split cost more than their few pocket-pocket edges
 
@@ -623,6 +627,9 @@ class EnVariationalDiffusion(nn.Module):
         cap = edge_capacity(lm, pm, batch)
         self._chain = (cap,)
         self._framed = False
+        if self.edge_granule16 is not None:
+            g16 = int(self.edge_granule16) & 0xFFFFFFFF
+            self.dynamics.engine().set_option(_lib.OPT_GRANULE16, g16 - (1 << 32) if g16 >= (1 << 31) else g16)
         if pocket is not None and not self.dynamics.update_pocket_coords and pm.numel() > 0 and \
                 int(pocket['size'].min()) >= self.frame_min_pocket_nodes:
             # (the size rule looks at every sample's pocket: in practice a property of the model's pocket

@@ -213,8 +213,14 @@ int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghos
 
 /* Switches of the dead-row elimination (environment: DSBDD_PRUNE, DSBDD_CONE).  DSBDD_OPT_PRUNE: 0 / 1.
  * DSBDD_OPT_CONE: 0 = never, 1 = when the engine's cost model says the canonical-pocket network pays (default: the
- * frame's representatives hold at most 0.4 of the batch's pocket rows), 2 = always.  Cone on / off agree to rounding. */
-enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1 };
+ * frame's representatives hold at most 0.4 of the batch's pocket rows), 2 = always.  Cone on / off agree to rounding.
+ * DSBDD_OPT_GRANULE16: bit mask of the stages that run on the 16-edge-granule variant of the fused edge kernels
+ * (csrc/edge_wave16.h: a wave owns 16 edges on v_mfma_f32_16x16x4_f32 instead of 32 on 32x32x2; half the work unit, for
+ * launches too small to fill the SIMDs a whole number of times): bit g (g < 16) = message stage g (block * inv_sublayers +
+ * sublayer), bit 16 + b = the coordinate stage of block b.  Default 0 (environment: DSBDD_GRANULE16=<mask>).  The two
+ * variants agree to rounding (< 1e-6 relative measured); each is bitwise reproducible; the mask is never changed by the
+ * engine itself. */
+enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1, DSBDD_OPT_GRANULE16 = 2 };
 int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value);
 
 /* Introspection of the last forward (device pointers into the workspace). */

@@ -554,12 +554,14 @@ def test_frame_survives_unrelated_calls_on_the_same_engine():
     eng.clear_pocket_frame()
 
 
-@pytest.mark.parametrize("B,n_lig,mode,n_steps", [
-    (64, 23, "inpaint", 3),      # bench.py's headline plan at its size
-    (64, 23, "sample", 2),       # the secondary (free-running) leg's step at the same size
-    (3, 14, "inpaint2", 4),      # small batch, resamplings = 2: the q(z_t | z_s) jump inside the fused kernel
+@pytest.mark.parametrize("B,n_lig,mode,n_steps,granule", [
+    (64, 23, "inpaint", 3, "32"),      # bench.py's headline plan at its size
+    (64, 23, "sample", 2, "32"),       # the secondary (free-running) leg's step at the same size
+    (3, 14, "inpaint2", 4, "32"),      # small batch, resamplings = 2: the q(z_t | z_s) jump inside the fused kernel
+    (64, 23, "inpaint", 2, "16"),      # the headline plan with every eligible stage on the 16-edge-granule kernels
+    (3, 14, "inpaint2", 4, "16"),
 ])
-def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps):
+def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps, granule, monkeypatch):
     """The EXACT engine plan bench.py times, against the oracle at the size it is timed at: B identical 3rfm
     full-atom pockets (prepare_pocket(repeats=B) -> one representative: shared pocket frame + forward cone),
     the anchored ligand pose, ligand output only, one t for the batch -- message-stage radii [1,2,3,3,2,1] with the
@@ -570,6 +572,8 @@ def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps):
     captures the hipGraph and the later ones replay it), the same injected noise, the device-built radius graph
     handed to the oracle; z_lig and the moved pocket within 1e-4 per step."""
     from diffsbdd_amd import synthetic
+    if granule == "16":
+        monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")     # (block 0's two-list launch of a framed call stays on 32)
     arch = "crossdock_fullatom_cond"
     cfg, dd = W.arch_cfg(arch)
     sd = W.random_state_dict(cfg, 0)
@@ -643,21 +647,26 @@ def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps):
         model._end_chain()
 
 
-@pytest.mark.parametrize("arch,B,frame", [
-    ("small_cond", 6, "shared"),               # H = 64: the chain kernel does not apply (three-launch path on both sides)
-    ("small_variant", 6, False),               # H = 128, two sublayers (the next sublayer's P|Q rides the chain), E(3)
-    ("crossdock_fullatom_cond", 8, "shared"),  # H = 256: ghost rows in front of the level list, cone radii 1,2,3,3,2,1
-    ("crossdock_fullatom_cond", 8, False),     # backward cone only
-    ("crossdock_ca_cond", 8, False),
+@pytest.mark.parametrize("arch,B,frame,granule", [
+    ("small_cond", 6, "shared", "32"),               # H = 64: the chain kernel does not apply (three-launch path on both sides)
+    ("small_variant", 6, False, "32"),               # H = 128, two sublayers (the next sublayer's P|Q rides the chain), E(3)
+    ("crossdock_fullatom_cond", 8, "shared", "32"),  # H = 256: ghost rows in front of the level list, cone radii 1,2,3,3,2,1
+    ("crossdock_fullatom_cond", 8, False, "32"),     # backward cone only
+    ("crossdock_ca_cond", 8, False, "32"),
+    ("small_variant", 6, False, "16"),               # the same calls with the edge stages on the 16-edge-granule kernels
+    ("crossdock_fullatom_cond", 8, "shared", "16"),
+    ("crossdock_ca_cond", 8, False, "16"),
 ])
 @pytest.mark.parametrize("want_pocket", [False, True])
-def test_node_chain_kernel_vs_three_launches_and_oracle(arch, B, frame, want_pocket, monkeypatch):
+def test_node_chain_kernel_vs_three_launches_and_oracle(arch, B, frame, granule, want_pocket, monkeypatch):
     """The row-owning node-phase kernel (csrc/node_chain.h: node MLP + the projections of the new h in one launch,
     16-row tiles dealt out by cost) against the three-launch node phase (csrc/node_linear.h) on the same call --
     different MFMA shapes, i.e. a different summation order inside every 16-k group: 2e-5 -- and against the oracle
     (1e-4).  DSBDD_NODE_CHAIN_MIN_ROWS=0 forces the kernel onto problems far below its default row threshold, so that
     every row-tile count (1 .. 6), ragged ends, ghost-row offsets and the projection-only launches are exercised."""
     from diffsbdd_amd.engine import edge_capacity
+    if granule == "16":
+        monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")
     cfg, dd, xl, xp, t, ml, mp = bench_problem(arch, B)
     sd = W.random_state_dict(cfg, 0)
     d = dev()

@@ -513,12 +513,16 @@ def _random_problem(cfg, n_lig, n_poc, seed, lig_shift=None, spread=3.0):
     return torch.cat([xl, hl], 1), torch.cat([xp, hp], 1), t, ml, mp
 
 
+@pytest.mark.parametrize("granule", ["32", "16"])
 @pytest.mark.parametrize("arch,max_wg", [("small_cond", 0), ("small_variant", 0), ("small_joint", 0),
                                          ("small_cond", 8), ("small_variant", 8), ("small_joint", 8)])
-def test_rows_spanning_many_tiles(arch, max_wg):
+def test_rows_spanning_many_tiles(arch, max_wg, granule, monkeypatch):
     """A 150-atom ligand: fully connected ligand rows have degree > 150, so one
-    row's edge segment spans 5+ wave tiles / 2+ workgroup tiles."""
+    row's edge segment spans 5+ wave tiles / 2+ workgroup tiles.  granule "16": every stage on the 16-edge-granule
+    kernels (csrc/edge_wave16.h: a row then spans 10+ wave tiles; head slots per 16-edge tile)."""
     import os
+    if granule == "16":
+        monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")
     cfg, _ = W.arch_cfg(arch)
     sd = W.random_state_dict(cfg, 3)
     xl, xp, t, ml, mp = _random_problem(cfg, [150, 3, 40], [40, 30, 5], seed=11,
@@ -528,6 +532,8 @@ def test_rows_spanning_many_tiles(arch, max_wg):
     try:
         m = make_dynamics(cfg, sd)
         e_l, e_p, st = m.forward_async(xl, xp, t, ml, mp, edges=edges)
+        e_l2, e_p2, _ = m.forward_async(xl, xp, t, ml, mp, edges=edges)
+        assert torch.equal(e_l, e_l2) and torch.equal(e_p, e_p2)                            # each variant bitwise reproducible
         f_l, f_p = m(xl.to(dev()), xp.to(dev()), t.to(dev()), ml.to(dev()), mp.to(dev()))   # device-built edges
     finally:
         del os.environ["DSBDD_EDGE_MAX_WG"]
@@ -536,6 +542,32 @@ def test_rows_spanning_many_tiles(arch, max_wg):
     er, ec = m.engine().last_edges(len(ml) + len(mp))
     if er.numel() == edges.shape[1] and torch.equal(er, edges[0]) and torch.equal(ec, edges[1]):
         assert excess(f_l, o_l) <= 0 and excess(f_p, o_p) <= 0
+
+
+@pytest.mark.parametrize("arch", ["small_cond", "small_joint", "crossdock_ca_cond"])
+def test_edge_granule_variants_agree(arch, monkeypatch):
+    """The 16-edge-granule kernels (csrc/edge_wave16.h) against the 32-edge ones on the same call: another k grouping
+    inside the fp32 MFMA chains and another summation tree of the row sums -- rounding only (2e-5 stated, ~1e-6
+    measured); the ligand-output-only call (level-ordered list, head slots at list offsets) included."""
+    cfg, _ = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, 2)
+    xl, xp, t, ml, mp = _random_problem(cfg, [23, 9, 40, 1], [36, 50, 20, 44], seed=17,
+                                        spread=0.5 if arch == "small_joint" else 3.0)
+    out = {}
+    for granule in ("32", "16"):
+        if granule == "16":
+            monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")
+        else:
+            monkeypatch.delenv("DSBDD_GRANULE16", raising=False)
+        m = make_dynamics(cfg, sd)
+        a = m.forward_async(xl, xp, t, ml, mp)
+        b = m.forward_async(xl, xp, t[:1], ml, mp, want_pocket=False) if not cfg["update_pocket_coords"] else a
+        torch.cuda.synchronize()
+        assert int(a[2].item()) == 0 and int(b[2].item()) == 0
+        out[granule] = (a[0].clone(), a[1].clone(), b[0].clone())
+    for u, v in zip(out["32"], out["16"]):
+        assert (u - v).abs().max().item() < 2e-5 * max(1.0, v.abs().max().item())
+    assert not torch.equal(out["32"][0], out["16"][0]) or arch == "small_joint"     # (the variant really switched)
 
 
 def test_ligand_without_pocket_neighbours_and_batch_of_one():
