@@ -255,6 +255,7 @@ def secondary_workloads(device, n_lig_atoms):
                               ("moad_fullatom_joint", "same")):
         arch, key, B = WORKLOADS[workload]
         cfg, dd, model = build_model(arch, device)
+        model.edge_granule16 = "auto"     # opt-in: coordinate stages on the 16-edge kernels where a round is saved (C-alpha)
         T = dd["timesteps"]
         joint = not dd["conditional"]
         n_calls = (sum(model.get_repaint_schedule(2, 1, T)) + 1) if joint else T + 1
@@ -295,7 +296,9 @@ def secondary_workloads(device, n_lig_atoms):
         out.append({"workload": workload, "pockets": pockets, "batch": B, "states": None if joint else "anchored",
                     "egnn_calls_per_chain": n_calls, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3,
                     "steps": 1, "warmup": 1, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
-                    "stage_radii": plan[0], "stage_ghost": plan[1]})
+                    "stage_radii": plan[0], "stage_ghost": plan[1],
+                    "edge_granule16": "auto (EnVariationalDiffusion.granule16_auto): mask 0x%08x" %
+                                      (eng._options.get(2, 0) & 0xFFFFFFFF)})
         del model, eng
         torch.cuda.empty_cache()
     return out
@@ -366,6 +369,8 @@ def main():
                          "GPU, heterogeneous pockets) that ride along with the default run")
     ap.add_argument("--no-config0", action="store_true",
                     help="skip the end-to-end CPU run of BASELINE configs[0] (C-alpha, 4 samples, 50 steps)")
+    ap.add_argument("--granule16", default=None,
+                    help="16-edge-granule edge kernels: 'auto' or a stage bit mask (DSBDD_OPT_GRANULE16); default: off")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -387,6 +392,8 @@ def main():
     arch, key, default_batch = WORKLOADS[args.workload]
     B = args.batch or default_batch
     cfg, dd, model = build_model(arch, device)
+    if args.granule16 is not None:
+        model.edge_granule16 = "auto" if args.granule16 == "auto" else int(args.granule16, 0)
     T = args.timesteps or dd["timesteps"]
     joint = not dd["conditional"]
     n_calls = (sum(model.get_repaint_schedule(2, 1, T)) + 1) if joint else T + 1

@@ -607,6 +607,22 @@ class EnVariationalDiffusion(nn.Module):
     # that use them; None leaves the engine's setting (default 0, environment DSBDD_GRANULE16) alone.  The variants agree to
     # rounding, so the mask is part of a chain's definition like `cone_mode`: set once, never changed by the engine.
     edge_granule16 = None
+
+    @staticmethod
+    def granule16_auto(lig_mask, batch, n_blocks, n_mlp=2, n_cu=256):
+        """`edge_granule16 = "auto"`: the coordinate stages go to the 16-edge kernels when halving the work unit saves a
+        round of workgroups -- items of 128 edges (32-edge kernel: one per (tile, MLP), <= one co-resident pair per CU
+        round) against items of 64 edges at half the time each, 5 % in hand for the 16-edge kernel's shorter K loops:
+        ceil(items64 / n_cu) * 0.525 < ceil(items128 / n_cu).  The ligand-row edge count is estimated from the ligand
+        sizes alone (the complete ligand graph, which dominates it; one host sync per chain).  Measured
+        (profiles/r4c_*): crossdock_ca_cond x 32 (274 -> 548 items) 52.1 -> 54.7 ligands/s; the full-atom headline
+        (748 items) keeps the 32-edge kernels.  Message stages are left alone: their edge counts are device-side."""
+        nl = torch.bincount(lig_mask, minlength=batch).to(torch.int64)
+        e_u = int((nl * nl).sum().item())
+        items128 = n_mlp * ((e_u + 127) // 128)
+        items64 = n_mlp * ((e_u + 63) // 64)
+        use = -(-items64 // n_cu) * 0.525 < -(-items128 // n_cu)
+        return (((1 << n_blocks) - 1) << 16) if use else 0
     frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
                                      # extra launches of the split cost more than their few pocket-pocket edges
 
@@ -628,7 +644,12 @@ class EnVariationalDiffusion(nn.Module):
         self._chain = (cap,)
         self._framed = False
         if self.edge_granule16 is not None:
-            g16 = int(self.edge_granule16) & 0xFFFFFFFF
+            if self.edge_granule16 == "auto":
+                hp = self.dynamics._hp
+                g16 = self.granule16_auto(lm, batch, hp["n_layers"], 1 if hp["reflection_equivariant"] else 2) \
+                    if not self.dynamics.update_pocket_coords else 0
+            else:
+                g16 = int(self.edge_granule16) & 0xFFFFFFFF
             self.dynamics.engine().set_option(_lib.OPT_GRANULE16, g16 - (1 << 32) if g16 >= (1 << 31) else g16)
         if pocket is not None and not self.dynamics.update_pocket_coords and pm.numel() > 0 and \
                 int(pocket['size'].min()) >= self.frame_min_pocket_nodes:

@@ -234,14 +234,16 @@ def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bia
         # bit-identical molecules for any packing: the engine's forward cone must not switch with the number of
         # distinct pockets in a batch (en_diffusion.cone_mode) -- pinned on for this batch only, the generator's own
         # setting is restored afterwards
-        saved = gen.ddpm.cone_mode
+        saved, saved_g = gen.ddpm.cone_mode, gen.ddpm.edge_granule16
         gen.ddpm.cone_mode = 2
+        if saved_g == "auto":
+            gen.ddpm.edge_granule16 = 0        # (the automatic choice looks at the batch: pinned for the same reason)
         try:
             return gen.generate_for_pockets(jobs, timesteps=timesteps, largest_frag=largest_frag,
                                             n_nodes_bias=n_nodes_bias, n_nodes_min=n_nodes_min, seed=seed,
                                             sample_ids=torch.cat(ids), **kwargs)
         finally:
-            gen.ddpm.cone_mode = saved
+            gen.ddpm.cone_mode, gen.ddpm.edge_granule16 = saved, saved_g
 
     return sample_batch
 
