@@ -16,6 +16,7 @@
 #include "edge_wave.h"
 #include "edge_wave16.h"
 #include "graph.h"
+#include "lig_head.h"
 #include "molecule.h"
 #include "node_chain.h"
 #include "node_linear.h"
@@ -89,6 +90,7 @@ struct dsbdd_engine {
   bool wchain_ready = false;
   int chain = 1;             // DSBDD_NODE_CHAIN=0: the three-launch node phase (node_linear.h) everywhere
   int64_t chain_min_rows = 0;      // (test hook; the choice of kernel must not depend on the batch size: bitwise batch invariance)
+  int lig_head = 1;    // DSBDD_LIG_HEAD=0: embedding_out / decoder / finalize as three launches also for ligand-only calls
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
   int profile = 0;        // 0 off, k: the GCL launches of every k-th forward call are timed with HIP events
@@ -227,6 +229,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (ngp && atoi(ngp) == 0) e->node_group = 0;
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
+  if (const char* lh = getenv("DSBDD_LIG_HEAD")) e->lig_head = atoi(lh) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
   const char* cn = getenv("DSBDD_CONE");
   if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
@@ -1119,6 +1122,16 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       HIP_TRY(hipMemcpyAsync(e->trace_x + (size_t)blk * N * 3, e->x, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
   }
   // ---- embedding_out, decoders (egnn_new.py:241, dynamics.py:147-153) --------
+  // ligand output only, pocket-conditioning mode: embedding_out + atom decoder + velocity + NaN flag in ONE launch
+  // (csrc/lig_head.h; DSBDD_LIG_HEAD=0: the three launches below)
+  LigHeadArgs lh{e->h, H, W[DSBDD_G_EMBOUT_WT], JP, W[DSBDD_G_EMBOUT_B], J,
+                 W[DSBDD_G_ATOM_DEC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_DEC_B0], 2 * a,
+                 W[DSBDD_G_ATOM_DEC_W1T], pad4(a), W[DSBDD_G_ATOM_DEC_B1], a,
+                 e->x, e->x_in, nlig, N, eps_lig, dl, status};
+  if (e->lig_head && !eps_pocket && !c.update_pocket_coords && lig_head_fits(lh)) {
+    HIP_TRY(launch_lig_head(s, lh));
+    return DSBDD_OK;
+  }
   HIP_TRY(nl(s, e->h, H, H, nullptr, 0, 0, W[DSBDD_G_EMBOUT_WT], JP, W[DSBDD_G_EMBOUT_B], nullptr, 0, e->hout, JP,
              eps_pocket ? N : n_lig, JP, 0));
   {
@@ -1464,7 +1477,7 @@ static hipError_t launch_edge_plain(int H, hipStream_t s, int mode, const EdgeAr
 static hipError_t reduce_parts(hipStream_t s, const float* part, int n_part, size_t stride, int width, float* out,
                                float* tmp) {
   const int bx = (width + 255) / 256;
-  if (n_part <= 64) {
+  if (n_part <= 96) {
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(bx, 1), dim3(256), 0, s, part, n_part, stride, width,
                        n_part > 0 ? n_part : 1, out, (size_t)0);
     return hipGetLastError();
@@ -1479,13 +1492,15 @@ static hipError_t reduce_parts(hipStream_t s, const float* part, int n_part, siz
 
 struct WgradPlan { int chunks, kc; size_t floats; };
 static WgradPlan wgrad_plan(int64_t K, int64_t M, int64_t N) {
+  // short chunks for the node-level gradients (K = a few thousand rows: the launch is a latency chain), at most
+  // 768 / tiles chunks for the edge-level ones (the reduction reads every partial once)
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int64_t chunks = (K + 255) / 256;
+  int64_t chunks = (K + 63) / 64;
   const int64_t cap = 768 / tiles > 1 ? 768 / tiles : 1;
   if (chunks > cap) chunks = cap;
   if (chunks < 1) chunks = 1;
-  int64_t kc = ((K + chunks - 1) / chunks + 15) / 16 * 16;
-  if (kc < 16) kc = 16;
+  int64_t kc = ((K + chunks - 1) / chunks + 31) / 32 * 32;
+  if (kc < 32) kc = 32;
   chunks = (K + kc - 1) / kc;
   if (chunks < 1) chunks = 1;
   WgradPlan p{(int)chunks, (int)kc, 0};
@@ -1570,7 +1585,7 @@ static bool mlp_ok(const dsbdd_train_mlp* m) {
 static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                         int64_t E, TrainEdgeArgs a, const dsbdd_train_mlp_grad* out, const TrainScratch& ts) {
   const int grid = train_grid(E);
-  const int slots = grid * 8;
+  const int slots = grid;                  // one partial-vector slot per workgroup
   a.erow = g->erow; a.ecol = g->ecol; a.ed0 = g->ed0; a.E = (int)E; a.x = x; a.n_lig = (int)g->n_lig;
   a.n_nodes = (int)g->n_nodes; a.P = m->P; a.Q = m->Q; a.ldpq = m->ldpq; a.wd = m->wd; a.wd0 = m->wd0; a.table = m->tab;
   a.b2 = m->b2; a.head = m->head; a.head_b = m->head_b;
@@ -1657,7 +1672,7 @@ int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g
   a.d_agg = d_agg; a.norm_factor = norm_factor;
   { const int rc = mlp_backward(s, H, MODE_GCL, g, m, x, g->n_edges, a, out, ts); if (rc != DSBDD_OK) return rc; }
   const int N = (int)g->n_nodes;
-  hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ts.gd,
+  hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.gd,
                      (const float*)nullptr, (const float*)nullptr, x, g->ecol, g->row_ptr, g->deg, g->rev,
                      (int)g->n_edges, N, d_x, 0);
   HIP_TRY(hipGetLastError());
@@ -1718,7 +1733,7 @@ int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph*
     dsbdd_train_mlp mq = m[q];
     mq.head = m[0].head;                      // the output layer is shared by both MLPs (egnn_new.py:78,85,91)
     { const int rc = mlp_backward(s, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, ts); if (rc != DSBDD_OK) return rc; }
-    hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ts.gd,
+    hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.gd,
                        (const float*)ts.gxr, (const float*)ts.gxc, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)e_upd, N,
                        d_x, q);
     HIP_TRY(hipGetLastError());
@@ -1734,7 +1749,7 @@ int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph*
 int dsbdd_train_radial_backward(void* stream, const dsbdd_train_graph* g, const float* x, const float* gd, float* d_x) {
   if (!graph_ok(g) || !g->rev || !x || !gd || !d_x) return fail(DSBDD_ERR_ARG, "bad argument");
   const int N = (int)g->n_nodes;
-  hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gd,
+  hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, static_cast<hipStream_t>(stream), gd,
                      (const float*)nullptr, (const float*)nullptr, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)g->n_edges,
                      N, d_x, 0);
   HIP_TRY(hipGetLastError());

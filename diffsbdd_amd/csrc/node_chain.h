@@ -96,7 +96,9 @@ __device__ __forceinline__ void chain_mfma_group(f32x4 (&acc)[RT][CT], const flo
 // the loads it waits for.  NG must be even.  Measured and not adopted (profiles/README.md): a ring of four sets with the
 // weights requested three or four groups ahead (10 - 15 % slower at every row count, also for one row tile -- the loop is
 // not waiting for the L2: a 16-row launch runs at the MFMA time of one row tile on one CU), the first group of a loop
-// requested before the preceding epilogue, the L2 warmed, a k-group-major weight layout, de-phased waves.
+// requested before the preceding epilogue, the L2 warmed, a k-group-major weight layout, de-phased waves; round 4: the
+// next chunk's first two weight groups requested BEFORE the chunk barrier of stage 1 (172.3 -> 174.3 us at 19.8 k rows,
+// profiles/r4d_node_chain_xbar.md).
 // CHUNKED (stage 1): the row operand of group g lives in chunk buffer (g / 4) & 1, which the workgroup's LDS-DMA fills;
 // `next_chunk(c)` issues the DMA of chunk c + 1 at the start of chunk c and every chunk ends with a workgroup barrier
 // (staging registers instead of the DMA, the remedy of the edge kernels, measured slower here: rows are 16-byte pieces of

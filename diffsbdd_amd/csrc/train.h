@@ -46,7 +46,7 @@ struct TrainEdgeArgs {
   float* a1_out;         // kernel A: [E][H]
   const float* dz_in;    // kernel B: dz2 [E][H]
   float* dz_out;         // kernel A: dz2 [E][H]; kernel B: dz1 [E][H]
-  float* part;           // [gridDim.x * 8][NPV][H] partial vectors, one slot per (workgroup, wave, half)
+  float* part;           // [gridDim.x][NPV][H] partial vectors, one slot per workgroup (its 8 (wave, half) sums added in order)
   float* gxr; float* gxc; float* gm;   // COORD kernel A: [E][3] gradient pieces for x[row], x[col], the sample mean
   float* gd; float* gd0; // kernel B: [E] gradient w.r.t. the current and the input squared distance
 };
@@ -343,13 +343,21 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
     }
     wave_lds_fence();
   }
-  // partial vectors of this (workgroup, wave, half)
-  float* pp = p.part + ((size_t)(blockIdx.x * 4 + w) * 2 + half) * kPartA * H;
+  // partial vectors: the 8 (wave, half) sums of this workgroup meet in LDS (the slice buffers are free now), slot order
+  __syncthreads();
+  float* sp = sB + (size_t)((w * 2 + half) * kPartA) * H;
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    pp[32 * c + j] = pb2[c];
-    pp[H + 32 * c + j] = pv1[c];
-    pp[2 * H + 32 * c + j] = (c == 0 && j == 0) ? ps : 0.f;
+    sp[32 * c + j] = pb2[c];
+    sp[H + 32 * c + j] = pv1[c];
+    sp[2 * H + 32 * c + j] = (c == 0 && j == 0) ? ps : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < kPartA * H; i += kThreads) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += sB[(size_t)q * kPartA * H + i];
+    p.part[(size_t)blockIdx.x * kPartA * H + i] = v;
   }
 }
 
@@ -490,14 +498,22 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_b_kernel(TrainEdgeArgs p
     }
     wave_lds_fence();
   }
-  float* pp = p.part + ((size_t)(blockIdx.x * 4 + w) * 2 + half) * kPartB * H;
+  __syncthreads();
+  float* sp = sB + (size_t)((w * 2 + half) * kPartB) * H;
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    pp[32 * c + j] = pwd[c];
-    pp[H + 32 * c + j] = pwd0[c];
-    pp[2 * H + 32 * c + j] = pt0[c];
-    pp[3 * H + 32 * c + j] = pt1[c];
-    pp[4 * H + 32 * c + j] = pt2[c];
+    sp[32 * c + j] = pwd[c];
+    sp[H + 32 * c + j] = pwd0[c];
+    sp[2 * H + 32 * c + j] = pt0[c];
+    sp[3 * H + 32 * c + j] = pt1[c];
+    sp[4 * H + 32 * c + j] = pt2[c];
+  }
+  __syncthreads();
+  for (int i = t; i < kPartB * H; i += kThreads) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += sB[(size_t)q * kPartB * H + i];
+    p.part[(size_t)blockIdx.x * kPartB * H + i] = v;
   }
 }
 
@@ -548,15 +564,17 @@ __global__ __launch_bounds__(kThreads) void rows_gather_kernel(const float* dz, 
 // d_x[i] (+)= sum over row i's edges e = (i, j) of  [gxr[e] + 2 gd[e] (x_i - x_j)]  (e < e_lim)
 //                                               + [gxc[re] + 2 gd[re] (x_i - x_j)]  (re = rev(e) < e_lim)
 // (|x_i - x_j|^2 depends on both endpoints; an edge's column-node gradient reaches x_i through its reverse edge)
-__global__ void edge_to_node3_kernel(const float* gd, const float* gxr, const float* gxc, const float* x, const int* ecol,
-                                     const int* row_ptr, const int* deg, const int* rev, int e_lim, int n_rows,
-                                     float* dx, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kThreads) void edge_to_node3_kernel(const float* gd, const float* gxr, const float* gxc,
+                                                                 const float* x, const int* ecol, const int* row_ptr,
+                                                                 const int* deg, const int* rev, int e_lim, int n_rows,
+                                                                 float* dx, int accumulate) {
+  // one wave per node: lane l takes the row's edges l, l + 64, ...; the 64 partial sums meet in a fixed butterfly
+  const int i = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (i >= n_rows) return;
   const int s = row_ptr[i], dg = deg[i];
   const float xi0 = x[3 * i], xi1 = x[3 * i + 1], xi2 = x[3 * i + 2];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int e = s; e < s + dg; ++e) {
+  for (int e = s + lane; e < s + dg; e += 64) {
     const int jn = ecol[e];
     const float f0 = xi0 - x[3 * jn], f1 = xi1 - x[3 * jn + 1], f2 = xi2 - x[3 * jn + 2];
     if (e < e_lim) {
@@ -571,8 +589,14 @@ __global__ void edge_to_node3_kernel(const float* gd, const float* gxr, const fl
       if (gxc) { a0 += gxc[3 * (size_t)re]; a1 += gxc[3 * (size_t)re + 1]; a2 += gxc[3 * (size_t)re + 2]; }
     }
   }
-  if (accumulate) { dx[3 * i] += a0; dx[3 * i + 1] += a1; dx[3 * i + 2] += a2; }
-  else { dx[3 * i] = a0; dx[3 * i + 1] = a1; dx[3 * i + 2] = a2; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+  }
+  if (lane == 0) {
+    if (accumulate) { dx[3 * i] += a0; dx[3 * i + 1] += a1; dx[3 * i + 2] += a2; }
+    else { dx[3 * i] = a0; dx[3 * i + 1] = a1; dx[3 * i + 2] = a2; }
+  }
 }
 
 // out[b][0..2] = sum of v[e][0..2] over the edges (e < e_lim) whose row belongs to sample b; one workgroup per sample
@@ -638,25 +662,36 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
     const float* A1 = p.A + (mv1 ? m0 + 32 + j : 0);
     const float* B0 = p.B + (nv0 ? n0 + j : 0);
     const float* B1 = p.B + (nv1 ? n0 + 32 + j : 0);
-#pragma unroll 1
-    for (int k = k0; k < k1; k += 16) {
-      float a0[8], a1[8], b0[8], b1[8];
+    // two register sets: the loads of block k + 16 are in flight while block k multiplies (the loop is a latency chain
+    // for the short K of the node-level gradients)
+    float a0[2][8], a1[2][8], b0[2][8], b1[2][8];
+    auto load = [&](int k, int sel) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int kk = k + 2 * s + kh;
         const bool ok = kk < k1;
         const size_t row = ok ? kk : k0;
         const float va0 = A0[row * p.lda], va1 = A1[row * p.lda], vb0 = B0[row * p.ldb], vb1 = B1[row * p.ldb];
-        a0[s] = (ok && mv0) ? va0 : 0.f; a1[s] = (ok && mv1) ? va1 : 0.f;
-        b0[s] = (ok && nv0) ? vb0 : 0.f; b1[s] = (ok && nv1) ? vb1 : 0.f;
+        a0[sel][s] = (ok && mv0) ? va0 : 0.f; a1[sel][s] = (ok && mv1) ? va1 : 0.f;
+        b0[sel][s] = (ok && nv0) ? vb0 : 0.f; b1[sel][s] = (ok && nv1) ? vb1 : 0.f;
       }
+    };
+    auto mult = [&](int sel) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
-        acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
-        acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
-        acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+        acc[0][0] = mfma32(a0[sel][s], b0[sel][s], acc[0][0]);
+        acc[0][1] = mfma32(a0[sel][s], b1[sel][s], acc[0][1]);
+        acc[1][0] = mfma32(a1[sel][s], b0[sel][s], acc[1][0]);
+        acc[1][1] = mfma32(a1[sel][s], b1[sel][s], acc[1][1]);
       }
+    };
+    load(k0, 0);
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 32) {
+      load(k + 16, 1);            // (rows past k1 load row k0 and count as zero)
+      mult(0);
+      load(k + 32, 0);
+      mult(1);
     }
   }
   float* C = p.Cp + (size_t)blockIdx.z * p.M * p.N;

@@ -302,3 +302,34 @@ def test_training_gradients_bitwise_reproducible_and_match_torch_path():
     assert set(a) == set(c)
     for k in a:
         assert rel_err(a[k], c[k]) < 1e-4, (k, rel_err(a[k], c[k]))
+
+
+@pytest.mark.parametrize("arch", ["small_cond", "small_joint"])
+def test_input_gradients_match_the_torch_path(arch):
+    """Gradients w.r.t. the INPUTS (z_t depends on the schedule's parameters when the noise schedule is learned,
+    en_diffusion.py:65,378): d loss / d xh_atoms and d xh_residues through the HIP Functions -- the radius-graph
+    distances d0 as a differentiable input (EdgeRadial), the coordinate gradients of both edge stages, the encoders --
+    against the eager torch path (train_path.py) on the same call."""
+    cfg, _ = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, seed=1)
+    m = make_dynamics(cfg, sd)
+    m.train(True)
+    xl, xp, t, ml, mp = problem(cfg, [5, 7, 6], [40, 35, 38], seed=31, spread=0.6 if arch == "small_joint" else 3.0)
+    gen = torch.Generator().manual_seed(5)
+    wl, wp = torch.randn(xl.shape, generator=gen).to(dev()), torch.randn(xp.shape, generator=gen).to(dev())
+
+    def run():
+        a = xl.to(dev()).clone().requires_grad_(True)
+        b = xp.to(dev()).clone().requires_grad_(True)
+        o_l, o_p = m(a, b, t.to(dev()), ml.to(dev()), mp.to(dev()))
+        ((o_l * wl).sum() + (o_p * wp).sum()).backward()
+        return o_l.detach(), a.grad.clone(), b.grad.clone()
+    o_h, ga_h, gb_h = run()
+    os.environ["DSBDD_TRAIN"] = "torch"
+    try:
+        o_t, ga_t, gb_t = run()
+    finally:
+        os.environ.pop("DSBDD_TRAIN")
+    assert rel_err(o_h, o_t) < 1e-5
+    assert rel_err(ga_h, ga_t) < 1e-4, rel_err(ga_h, ga_t)
+    assert rel_err(gb_h, gb_t) < 1e-4, rel_err(gb_h, gb_t)
