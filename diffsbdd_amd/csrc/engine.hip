@@ -90,6 +90,7 @@ struct dsbdd_engine {
   bool wchain_ready = false;
   int chain = 1;             // DSBDD_NODE_CHAIN=0: the three-launch node phase (node_linear.h) everywhere
   int64_t chain_min_rows = 0;      // (test hook; the choice of kernel must not depend on the batch size: bitwise batch invariance)
+  int level_rows = 0;  // DSBDD_LEVEL_ROWS=1: all-row stages of a pruned call walk the level list (measured slower, see rows_of)
   int lig_head = 1;    // DSBDD_LIG_HEAD=0: embedding_out / decoder / finalize as three launches also for ligand-only calls
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
@@ -230,6 +231,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
   if (const char* lh = getenv("DSBDD_LIG_HEAD")) e->lig_head = atoi(lh) != 0;
+  if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
   const char* cn = getenv("DSBDD_CONE");
   if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
@@ -781,8 +783,13 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   const int L_cap = prune ? (int)e->cap_edgesL : (int)e->cap_edges;
   const int64_t L_bound = prune ? e->cap_edgesL : edge_bound;
   // rows of the nodes of level <= r (r >= kLevels - 1: everything), with or without the ghost rows in front
+  // (round 4 experiment, DSBDD_LEVEL_ROWS=1: the all-row stages of a pruned call walk the level list as well -- a
+  //  permutation of the rows -- so that the active nodes and the ligand rows are PREFIXES of every stage's row list and the
+  //  coordinate projections ride in the node-phase launch of every stage, not only of the radius-limited ones: 3 launches
+  //  fewer per call on the C-alpha and mixed-pocket plans [4,4,4,3,2,1].  Measured 0.5 % SLOWER on both
+  //  (profiles/r4f_ab.md: the grouped node GEMM launch beats the chain's projection passes); off by default)
   auto rows_of = [&](int r, bool ghost, NodeLinearArgs& a) {
-    if (!prune || (r >= LV && !ghost)) return;
+    if (!prune || (r >= LV && !ghost && !e->level_rows)) return;
     if (r > LV) r = LV;
     a.row_idx = ghost ? e->lvl_list : e->lvl_list + n_ghost;
     a.m_count = ghost ? e->lvl_cnt + r : e->lvl_cnt + kLevels + r;
