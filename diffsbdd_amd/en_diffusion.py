@@ -609,20 +609,29 @@ class EnVariationalDiffusion(nn.Module):
     edge_granule16 = None
 
     @staticmethod
-    def granule16_auto(lig_mask, batch, n_blocks, n_mlp=2, n_cu=256):
-        """`edge_granule16 = "auto"`: the coordinate stages go to the 16-edge kernels when halving the work unit saves a
-        round of workgroups -- items of 128 edges (32-edge kernel: one per (tile, MLP), <= one co-resident pair per CU
-        round) against items of 64 edges at half the time each, 5 % in hand for the 16-edge kernel's shorter K loops:
-        ceil(items64 / n_cu) * 0.525 < ceil(items128 / n_cu).  The ligand-row edge count is estimated from the ligand
-        sizes alone (the complete ligand graph, which dominates it; one host sync per chain).  Measured
-        (profiles/r4c_*): crossdock_ca_cond x 32 (274 -> 548 items) 52.1 -> 54.7 ligands/s; the full-atom headline
-        (748 items) keeps the 32-edge kernels.  Message stages are left alone: their edge counts are device-side."""
+    def granule16_auto(lig_mask, batch, n_blocks, n_mlp=2, n_cu=256, pocket_mask=None):
+        """`edge_granule16 = "auto"`: the coordinate stages go to the 16-edge kernels when halving the work unit saves at
+        least a fifth of the stage -- workgroup items of 128 edges (32-edge kernel, one per (tile, MLP)) against items
+        of 64 edges at half the time each: ceil(items64 / n_cu) / 2 <= 0.8 ceil(items128 / n_cu).  The ligand-row edge
+        count is only known on the device; the rule must hold for both ends of a host-side bracket -- the complete
+        ligand graph alone, and with n_pocket / 24 (at most 12) pocket neighbours per ligand atom on top: the 3rfm pockets
+        give 0.5 (C-alpha, 36 nodes) and 10 (full-atom, 286 nodes) per atom (one host sync per chain).
+        Measured (profiles/r4c_granule16_ab.md): crossdock_ca_cond x 32 (274 -> 548 items) 52.1 -> 54.7 ligands/s; the
+        full-atom headline (748 items: 3 rounds either way) is slower on them and keeps the 32-edge kernels.  Message
+        stages are left alone: their edge counts are device-side and the two kernels are within 1 % there."""
         nl = torch.bincount(lig_mask, minlength=batch).to(torch.int64)
-        e_u = int((nl * nl).sum().item())
-        items128 = n_mlp * ((e_u + 127) // 128)
-        items64 = n_mlp * ((e_u + 63) // 64)
-        use = -(-items64 // n_cu) * 0.525 < -(-items128 // n_cu)
-        return (((1 << n_blocks) - 1) << 16) if use else 0
+        lo = int((nl * nl).sum().item())
+        hi = lo
+        if pocket_mask is not None:
+            npk = torch.bincount(pocket_mask, minlength=batch).to(torch.int64)
+            hi = int((nl * (nl + torch.clamp((npk + 23) // 24, max=12))).sum().item())
+
+        def pays(e_u):
+            items128 = n_mlp * ((e_u + 127) // 128)
+            items64 = n_mlp * ((e_u + 63) // 64)
+            return -(-items64 // n_cu) * 0.5 <= 0.8 * -(-items128 // n_cu)
+        return (((1 << n_blocks) - 1) << 16) if (pays(lo) and pays(hi)) else 0
+
     frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
                                      # extra launches of the split cost more than their few pocket-pocket edges
 
@@ -646,7 +655,8 @@ class EnVariationalDiffusion(nn.Module):
         if self.edge_granule16 is not None:
             if self.edge_granule16 == "auto":
                 hp = self.dynamics._hp
-                g16 = self.granule16_auto(lm, batch, hp["n_layers"], 1 if hp["reflection_equivariant"] else 2) \
+                g16 = self.granule16_auto(lm, batch, hp["n_layers"], 1 if hp["reflection_equivariant"] else 2,
+                                          pocket_mask=pm) \
                     if not self.dynamics.update_pocket_coords else 0
             else:
                 g16 = int(self.edge_granule16) & 0xFFFFFFFF

@@ -524,3 +524,60 @@ def test_edge_tile_walk_covers_both_lists_once_and_slice_staging_covers_a_slice_
             held = [i for gl, gs, i in ops if gl <= g < gs]
             assert len(held) <= SG
         assert all(gs == gl + 1 for gl, gs, _ in ops)
+
+
+def test_per_chain_engine_choices_are_pure_functions_of_the_batch():
+    """Round 4: the forward cone and the 16-edge-granule choice are made in Python, once per chain, from the pocket groups /
+    ligand sizes alone (never by an engine heuristic in the middle of a chain)."""
+    from diffsbdd_amd.en_diffusion import EnVariationalDiffusion as D
+    assert D._cone_for_groups(torch.zeros(64, dtype=torch.int64), 64) == 2          # one pocket repeated
+    assert D._cone_for_groups(torch.arange(64), 64) == 0 and D._cone_for_groups(None, 64) == 0
+    two = torch.cat([torch.zeros(40, dtype=torch.int64), torch.full((24,), 40)])
+    assert D._cone_for_groups(two, 64) == 2                                         # 2 groups of 64: 10 <= 128
+    many = torch.cat([torch.zeros(40, dtype=torch.int64), torch.arange(40, 64)])
+    assert D._cone_for_groups(many, 64) == 2 and D._cone_for_groups(torch.arange(64) // 2, 64) == 0
+    # coordinate stages on the 16-edge kernels: C-alpha x 32 (274 -> 548 items: a round saved) yes, full-atom x 64 no
+    ca = torch.repeat_interleave(torch.arange(32), 23)
+    fa = torch.repeat_interleave(torch.arange(64), 23)
+    ca_p = torch.repeat_interleave(torch.arange(32), 36)
+    fa_p = torch.repeat_interleave(torch.arange(64), 286)
+    assert D.granule16_auto(ca, 32, 6, pocket_mask=ca_p) == 0x003F0000
+    assert D.granule16_auto(fa, 64, 6, pocket_mask=fa_p) == 0 and D.granule16_auto(fa, 64, 6) == 0
+    assert D.granule16_auto(ca[:23 * 8], 8, 6) == 0x003F0000                        # 8 x 23: 68 -> 134 items, half the time
+
+
+def test_training_c_abi_argument_errors_and_sizes():
+    """The dsbdd_train_* entry points reject misuse with DSBDD_ERR_ARG / _CAPACITY before anything is launched (no GPU)."""
+    lib = _lib.load()
+    assert lib.dsbdd_train_scratch_bytes(96, 100, 1000) == 0                        # unsupported hidden_nf
+    n = lib.dsbdd_train_scratch_bytes(256, 4944, 91152)
+    assert n > 3 * 91152 * 256 * 4                                                  # dz2, a1, dz1 + partials
+    assert lib.dsbdd_train_wgrad_scratch_bytes(0, 4, 4) == 0
+    w = lib.dsbdd_train_wgrad_scratch_bytes(91152, 256, 256)
+    assert 256 * 256 * 4 <= w <= 200 * 256 * 256 * 4
+    one = ctypes.c_void_p(4096)
+    assert lib.dsbdd_train_wgrad(None, None, 4, one, 4, 8, 4, 4, one, one, 1 << 20) == _lib.ERR_ARG
+    assert lib.dsbdd_train_wgrad(None, one, 4, one, 4, 8, 4, 4, one, one, 16) == _lib.ERR_CAPACITY
+    assert lib.dsbdd_train_colsum(None, one, 2, 8, 4, one, one, 1 << 20) == _lib.ERR_ARG      # lda < N
+    g = _lib.TrainGraph()                                                            # all-null graph
+    assert lib.dsbdd_train_edge_rev(None, ctypes.byref(g), one) == _lib.ERR_ARG
+    m = _lib.TrainMlp()
+    assert lib.dsbdd_train_gcl_forward(None, 256, ctypes.byref(g), ctypes.byref(m), one, 100.0, one, one, 1 << 20) == _lib.ERR_ARG
+    assert b"bad argument" in lib.dsbdd_last_error()
+
+
+def test_oracle_ref_archive_matches_the_reference_sources():
+    """oracle/_ref/reference_path.zip (oracle/make_ref.py; git-ignored, shipped with the push) holds the reference's own
+    modules of this path, unmodified: SHA-256 against /root/reference when that exists (build container), and the archive
+    imports through oracle/ref_shim.py."""
+    import hashlib
+    import zipfile
+    from oracle import make_ref
+    if not os.path.isfile(os.path.join(make_ref.SRC, make_ref.FILES[0])):
+        pytest.skip("reference sources not present on this machine")
+    assert make_ref.make(verbose=False) and make_ref.available()
+    with zipfile.ZipFile(make_ref.ARCHIVE) as z:
+        man = json.loads(z.read("MANIFEST.json"))
+        for f in make_ref.FILES:
+            assert hashlib.sha256(z.read(f)).hexdigest() == man["sha256"][f] == \
+                hashlib.sha256(open(os.path.join(make_ref.SRC, f), "rb").read()).hexdigest()
