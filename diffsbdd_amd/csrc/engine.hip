@@ -90,6 +90,9 @@ struct dsbdd_engine {
   bool wchain_ready = false;
   int chain = 1;             // DSBDD_NODE_CHAIN=0: the three-launch node phase (node_linear.h) everywhere
   int64_t chain_min_rows = 0;      // (test hook; the choice of kernel must not depend on the batch size: bitwise batch invariance)
+  int fork_front = 0;  // DSBDD_FORK=1: encoders / embedding on a side stream at the head of a call (measured slower, see forward_impl)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int level_rows = 0;  // DSBDD_LEVEL_ROWS=1: all-row stages of a pruned call walk the level list (measured slower, see rows_of)
   int lig_head = 1;    // DSBDD_LIG_HEAD=0: embedding_out / decoder / finalize as three launches also for ligand-only calls
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
@@ -133,6 +136,9 @@ struct dsbdd_engine {
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     drop_graphs();
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
   }
 };
 
@@ -232,6 +238,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (prn && atoi(prn) == 0) e->prune = 0;
   if (const char* lh = getenv("DSBDD_LIG_HEAD")) e->lig_head = atoi(lh) != 0;
   if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
+  if (const char* fk = getenv("DSBDD_FORK")) e->fork_front = atoi(fk) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
   const char* cn = getenv("DSBDD_CONE");
   if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
@@ -700,6 +707,23 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                        t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
     HIP_TRY(hipGetLastError());
   }
+  // ---- two independent chains at the head of a call: A = encoders -> embedding (-> ghost-row features), needs only the
+  // assembled inputs; B = radius graph -> scan -> fill -> hop levels -> level-ordered list, needs only the coordinates.
+  // Both are strings of short latency-bound kernels (A: 46 us, B: 78 us per call at the benchmark size).  Round 4
+  // experiment, DSBDD_FORK=1: A on an engine-owned side stream, forked and joined by events -- inside a captured graph the
+  // two become parallel branches.  Parity-green (146 GPU tests) and measured SLOWER: 37.56 vs 38.00 ligands/s (full-atom),
+  // 52.7 vs 55.0 (C-alpha), i.e. +40 us per call: a fork / join inside a replayed graph costs more than the 46 us of
+  // serial kernels it hides (profiles/r4g_fork_ab.md; the same finding as round 2's second-stream experiment).  Off.
+  const bool fork = e->fork_front && !ext;
+  hipStream_t sa = s;
+  if (fork) {
+    if (!e->side_stream) HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    if (!e->ev_fork) HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    if (!e->ev_join) HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+    sa = e->side_stream;
+  }
   // ---- encoders (dynamics.py:96-97) -> h0[:, 0:J] ----------------------------
   {
     Mlp2Problem enc[2] = {
@@ -710,19 +734,27 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     if (mlp2_fits(enc[0]) && mlp2_fits(enc[1])) {
       // both node sets, both layers: one launch.  With a pocket frame the pocket's encoding is a constant of the chain:
       // dsbdd_dynamics_forward computed it before this call (eagerly, so that replayed graphs find it too)
-      HIP_TRY(launch_mlp2(s, enc, (split0 && e->h0_pocket_valid) ? 1 : 2));
+      HIP_TRY(launch_mlp2(sa, enc, (split0 && e->h0_pocket_valid) ? 1 : 2));
     } else {
-      HIP_TRY(nl(s, xh_lig + 3, dl, a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0],
+      HIP_TRY(nl(sa, xh_lig + 3, dl, a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W0T], pad4(2 * a), W[DSBDD_G_ATOM_ENC_B0],
                  nullptr, 0, e->enc_tmp, LE, n_lig, 2 * a, 1));
-      HIP_TRY(nl(s, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W1T], pad4(J),
+      HIP_TRY(nl(sa, e->enc_tmp, LE, 2 * a, nullptr, 0, 0, W[DSBDD_G_ATOM_ENC_W1T], pad4(J),
                  W[DSBDD_G_ATOM_ENC_B1], nullptr, 0, e->h0, JP, n_lig, J, 0));
       float* tmp_p = e->enc_tmp + (size_t)n_lig * LE;
-      HIP_TRY(nl(s, xh_pocket + 3, dp, r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0],
+      HIP_TRY(nl(sa, xh_pocket + 3, dp, r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W0T], pad4(2 * r), W[DSBDD_G_RES_ENC_B0],
                  nullptr, 0, tmp_p, LE, n_pocket, 2 * r, 1));
-      HIP_TRY(nl(s, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1],
+      HIP_TRY(nl(sa, tmp_p, LE, 2 * r, nullptr, 0, 0, W[DSBDD_G_RES_ENC_W1T], pad4(J), W[DSBDD_G_RES_ENC_B1],
                  nullptr, 0, e->h0 + (size_t)n_lig * JP, JP, n_pocket, J, 0));
     }
   }
+  // ---- embedding (egnn_new.py:233) ---------------------------------------------
+  HIP_TRY(nl(sa, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
+  if (split0) {   // the ghost rows start from the embedded features of the pockets they stand for
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((e->frame_n3 + 3) / 4), dim3(kThreads), 0, sa, e->h + (size_t)N * H,
+                       (const float*)(e->h + (size_t)nlig * H), (const int*)e->frame_rows, (int)e->frame_n3, H);
+    HIP_TRY(hipGetLastError());
+  }
+  if (fork) HIP_TRY(hipEventRecord(e->ev_join, sa));
   // ---- edges (dynamics.py:114, 169-187) ---------------------------------------
   int64_t edge_bound = e->cap_edges;
   if (ext) {
@@ -807,13 +839,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                        (const int*)e->act_ptr, e->act_list, N);
     HIP_TRY(hipGetLastError());
   }
-  // ---- embedding (egnn_new.py:233) ---------------------------------------------
-  HIP_TRY(nl(s, e->h0, JP, JP, nullptr, 0, 0, W[DSBDD_G_EMB_WT], H, W[DSBDD_G_EMB_B], nullptr, 0, e->h, H, N, H, 0));
-  if (split0) {   // the ghost rows start from the embedded features of the pockets they stand for
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_frame_rows + 3) / 4), dim3(kThreads), 0, s, e->h + (size_t)N * H,
-                       (const float*)(e->h + (size_t)nlig * H), (const int*)e->frame_rows, n_frame_rows, H);
-    HIP_TRY(hipGetLastError());
-  }
+  // (the embedding and the ghost rows' features were enqueued with the encoders, on the side stream: join)
+  if (fork) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
 
   const int n_upd = c.update_pocket_coords ? N : nlig;   // update_coords_mask, dynamics.py:130-132
   const int* e_all = prune ? e->lvl_end + kLevels + LV : e->row_ptr + N;   // (counted from the end of the ghost segment)
