@@ -30,6 +30,23 @@ namespace dsbdd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DSBDD_CHAIN_TS
+// -DDSBDD_CHAIN_TS builds (tools/microbench.hip only): marks of wave 0 of every workgroup -- slots 0..7 shader clock
+// (s_memtime), 16..23 the constant 100 MHz clock, 8..10 the range (first row, rows, projection passes)
+__device__ unsigned long long* g_chain_ts = nullptr;
+__device__ __forceinline__ void chain_ts(int slot) {
+  if (g_chain_ts && threadIdx.x == 0 && slot < 16) {
+    g_chain_ts[blockIdx.x * 32 + slot] = __builtin_readcyclecounter();
+    g_chain_ts[blockIdx.x * 32 + 16 + slot] = wall_clock64();
+  }
+}
+#define CHAIN_TS(k) chain_ts(k)
+#define CHAIN_NOTE(slot, v) do { if (g_chain_ts && threadIdx.x == 0) g_chain_ts[blockIdx.x * 32 + (slot)] = (unsigned long long)(v); } while (0)
+#else
+#define CHAIN_TS(k) do { } while (0)
+#define CHAIN_NOTE(slot, v) do { } while (0)
+#endif
+
 constexpr int kChainThreads = 512;     // 8 waves: one workgroup per CU, two waves per SIMD
 constexpr int kChainRowsMax = 96;      // rows a workgroup holds in LDS at a time (6 row tiles)
 constexpr int kChainChunkK = 64;       // k per streamed input chunk of stage 1
@@ -198,6 +215,10 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) rowp[rt] = phys(r0 + 16 * rt + i);
 
+  CHAIN_TS(1);
+  CHAIN_NOTE(8, r0); CHAIN_NOTE(9, R16);
+  int n_pass = 0;
+  (void)n_pass;
   if (p.do_mlp) {
     {
       // ================= stage 1: t1 = SiLU([h | agg] W1 + b1) =================
@@ -239,6 +260,7 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
           }
         }
       }
+      CHAIN_TS(2);                                         // stage-1 K loop done
       // bias + SiLU -> LDS panels (float4 = four consecutive columns of one row)
 #pragma unroll
       for (int c = 0; c < (col_active ? CTW : 0); ++c) {
@@ -253,6 +275,7 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
         }
       }
       __syncthreads();
+      CHAIN_TS(3);                                         // epilogue 1 + barrier
       // ================= stage 2: h += t1 W2 + b2 =================
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -273,6 +296,7 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
       if (col_active)
         chain_kloop<RT, CTW, false>(acc, x_panel, p.W2p + ((size_t)(w * CTW) * NG * 64 + lane) * 4, (size_t)NG * 256, NG, no_hook);
       if (!PRE) load_res();
+      CHAIN_TS(4);                                         // stage-2 K loop done
 #pragma unroll
       for (int c = 0; c < (col_active ? CTW : 0); ++c) {
         const int col = 16 * (w * CTW + c) + 4 * kq;
@@ -302,6 +326,7 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
     __syncthreads();
   }
 
+  CHAIN_TS(5);                                             // epilogue 2 (+ h panels for the projections)
   // ================= projections from the rows' h in LDS =================
   for (int q = 0; q < p.n_proj; ++q) {
     const ChainProj& pj = p.proj[q];
@@ -309,6 +334,7 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
     if (r0 >= cnt || r0 + R16 <= lo) continue;             // uniform per workgroup
     const int rt_n = min(RT, (cnt - r0 + 15) >> 4);        // row tiles of this range the problem covers
     for (int ct0 = 2 * w; ct0 < pj.N / 16; ct0 += 16) {    // passes of 2 column tiles per wave
+      ++n_pass;
       f32x4 acc[RT][2];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) { acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = acc[rt][0]; }
@@ -329,12 +355,16 @@ __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0
       }
     }
   }
+  CHAIN_TS(6);                                             // projections done
+  CHAIN_NOTE(10, n_pass);
   __syncthreads();                                         // the panels are rewritten by the next range
+  CHAIN_TS(7);
 }
 
 template <int H>
 __global__ __launch_bounds__(kChainThreads, 2) void node_chain_kernel(NodeChainArgs p) {
   __shared__ float smem[kChainRowsMax * H + 2 * (kChainChunkK / 4) * kChainRowsMax * 4];
+  CHAIN_TS(0);
   const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
   if (M <= 0) return;
   // ---- cost-weighted split of the row list into ranges of 16-row tiles (identical arithmetic in every workgroup) ----

@@ -274,6 +274,53 @@ int main(int argc, char** argv) {
     printf("| **node_chain: MLP + 3 projections, one launch** | %d | %.1f | %.1f | %.3f | |\n", M, uc, (f1 + f2 + f3) / uc / 1e6, (f1 + f2 + f3) / uc / 1e6 / 157.3);
     printf("| node_chain: MLP only | %d | %.1f | %.1f | %.3f | |\n", M, um, (f1 + f2) / um / 1e6, (f1 + f2) / um / 1e6 / 157.3);
     printf("| node_chain: projections only (h from global) | %d | %.1f | %.1f | %.3f | |\n", M, up, f3 / up / 1e6, f3 / up / 1e6 / 157.3);
+#ifdef DSBDD_CHAIN_TS
+    {   // in-kernel timeline of wave 0 of every workgroup (shader clock), one launch
+      unsigned long long* d_ts = dev_zero<unsigned long long>((size_t)n_cu * 32);
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_ts), &d_ts, sizeof(d_ts)));
+      CK(launch_node_chain(0, ca, H, n_cu));
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> ts((size_t)n_cu * 32);
+      CK(hipMemcpy(ts.data(), d_ts, ts.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long* nul = nullptr;
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_ts), &nul, sizeof(nul)));
+      const char* nm[8] = {"entry", "split + panel DMA issue", "stage-1 K loop (chunked, 8 barriers)", "epilogue 1 (bias, SiLU -> LDS) + barrier",
+                           "stage-2 K loop", "epilogue 2 (residual, store, h -> LDS, 2 barriers)", "projections (all passes)", "final barrier"};
+      double sum[8] = {0}; int cnt = 0; double tot = 0;
+      for (int b = 0; b < n_cu; ++b) {
+        const unsigned long long* t = ts.data() + (size_t)b * 32;
+        if (!t[0] || !t[7]) continue;
+        for (int k = 1; k < 8; ++k) sum[k] += (double)(t[k] - t[k - 1]);
+        tot += (double)(t[7] - t[0]); ++cnt;
+      }
+      printf("| node_chain timeline (M = %d, wave 0, mean over %d workgroups, shader cycles; LAST range of each workgroup) | | | | | |\n", M, cnt);
+      for (int k = 1; k < 8; ++k) printf("| ... %s | | %.0f cycles | %.1f %% | | |\n", nm[k], sum[k] / cnt, 100.0 * sum[k] / tot);
+      double wall = 0;
+      for (int b = 0; b < n_cu; ++b) { const unsigned long long* t = ts.data() + (size_t)b * 32; if (t[0] && t[7]) wall += (double)(t[16 + 7] - t[16]); }
+      {
+        unsigned long long t0 = ~0ull, t1 = 0; double smin = 1e30, smax = 0, lat_max = 0; int bmax = -1, bmin = -1;
+        for (int b = 0; b < n_cu; ++b) { const unsigned long long* t = ts.data() + (size_t)b * 32; if (t[0] && t[7]) { t0 = std::min(t0, t[16]); t1 = std::max(t1, t[16 + 7]); } }
+        for (int b = 0; b < n_cu; ++b) {
+          const unsigned long long* t = ts.data() + (size_t)b * 32;
+          if (!t[0] || !t[7]) continue;
+          const double sp = (double)(t[16 + 7] - t[16]) / 100.0;
+          if (sp > smax) { smax = sp; bmax = b; }
+          if (sp < smin) { smin = sp; bmin = b; }
+          lat_max = std::max(lat_max, (double)(t[16] - t0) / 100.0);
+        }
+        printf("| ... first entry -> last end %.1f us; workgroup span min %.1f (wg %d) / max %.1f us (wg %d); latest entry +%.1f us | | | | | |\n",
+               (double)(t1 - t0) / 100.0, smin, bmin, smax, bmax, lat_max);
+        for (int b : {bmin, bmax, 0, 20, 40, 60, 80, 120, 200, 255}) {
+          const unsigned long long* t = ts.data() + (size_t)b * 32;
+          printf("| ... wg %d r0 %llu rows %llu passes %llu phases (us):", b, t[8], t[9], t[10]);
+          for (int k = 1; k < 8; ++k) printf(" %.1f", (double)(t[16 + k] - t[16 + k - 1]) / 100.0);
+          printf(" | | | | | |\n");
+        }
+      }
+      printf("| ... entry -> end | | %.0f cycles = %.1f us by the 100 MHz wall clock -> shader clock %.2f GHz | | | |\n", tot / cnt,
+             wall / cnt / 100.0, (tot / cnt) / (wall / cnt * 10.0));
+    }
+#endif
     if (mi == 0) {   // the launch's fixed cost: 16 rows (one row tile on one workgroup, every other workgroup only computes the split)
       NodeChainArgs ct = cm; ct.m_count = d_mcounts + 4;
       const float ut = time_us([&] { (void)launch_node_chain(0, ct, H, n_cu); }, reps);
