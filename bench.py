@@ -55,7 +55,7 @@ from diffsbdd_amd.pocket import prepare_pocket  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / fp32 vector peak
 HBM_PEAK_GBPS = 8000.0
-PMC_TRAFFIC_FILE = "r3z_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r4z_pmc_traffic.json"
 METRIC = "sampled ligands/sec (500-step DDPM, fullatom_cond) at 1/2/4/8 MI355X"
 
 WORKLOADS = {
