@@ -368,56 +368,98 @@ __global__ __launch_bounds__(kChainThreads, 2) void node_chain_kernel(NodeChainA
   const int M = p.m_count ? min(p.M, *p.m_count) : p.M;
   if (M <= 0) return;
   // ---- cost-weighted split of the row list into ranges of 16-row tiles (identical arithmetic in every workgroup) ----
-  // cost of a row, in units of H*H/16 MAC: 48 for the node MLP + N_p / H * 16 for every projection that covers it
+  // cost of a row, in units of H*H/16 MAC: 48 for the node MLP + N_p / H * 16 for every projection that covers it.
+  // All of it in 32-bit arithmetic on wave-uniform values (rows x 240 units < 2^31: launch_node_chain rejects more than 8 M
+  // rows): round 3's 64-bit version -- bisection of the cumulative cost, 64-bit divisions -- cost every workgroup 7 us
+  // before its first load (in-kernel timeline, profiles/r4h_node_chain_timeline.md).
   int cnt[kChainMaxProj], fst[kChainMaxProj];
-  long wgt[kChainMaxProj];
-  const long w_mlp = p.do_mlp ? 48 : 0;
+  unsigned wgt[kChainMaxProj];
+  const unsigned w_mlp = p.do_mlp ? 48u : 0u;
   int M_work = p.do_mlp ? M : 0;                           // rows behind the last problem's end have no work
+#pragma unroll
   for (int q = 0; q < kChainMaxProj; ++q) {
     cnt[q] = 0; wgt[q] = 0; fst[q] = 0;
     if (q < p.n_proj) {
       fst[q] = min(M, p.proj[q].first);
       cnt[q] = p.proj[q].count ? min(M - fst[q], *p.proj[q].count) : M - fst[q];
       if (cnt[q] < 0) cnt[q] = 0;
-      wgt[q] = (long)p.proj[q].N * 16 / H;
+      wgt[q] = (unsigned)(p.proj[q].N * 16 / H);
       M_work = max(M_work, fst[q] + cnt[q]);
     }
   }
-  // cumulative cost of the logical rows [0, r)
-  auto cost_to = [&](long r) {
-    long f = w_mlp * min(r, (long)M_work);
-    for (int q = 0; q < kChainMaxProj; ++q) f += wgt[q] * max(0L, min(r - fst[q], (long)cnt[q]));
-    return f;
-  };
   const int Mw = M_work;
   if (Mw <= 0) return;
-  const long total = cost_to(Mw);
-  if (total <= 0) return;
-  // the cheapest row of the list (the marginal cost only changes where a problem starts or ends)
-  long w_min = cost_to(1);
-  for (int q = 0; q < kChainMaxProj; ++q)
-    for (int e = 0; e < 2; ++e) {
-      const long r = e ? fst[q] + cnt[q] : fst[q];
-      if (q < p.n_proj && r < Mw) w_min = min(w_min, cost_to(r + 1) - cost_to(r));
+  CHAIN_NOTE(11, (unsigned long long)(Mw > 0 ? wall_clock64() : 0));     // row counts loaded
+  // cumulative cost of the logical rows [0, r)
+  auto cost_to = [&](int r) {
+    unsigned f = w_mlp * (unsigned)min(r, M_work);
+#pragma unroll
+    for (int q = 0; q < kChainMaxProj; ++q) f += wgt[q] * (unsigned)max(0, min(r - fst[q], cnt[q]));
+    return f;
+  };
+  // F is piecewise linear: its slope only changes where a problem starts or ends (<= 8 breakpoints, sorted here)
+  constexpr int NB = 2 * kChainMaxProj + 3;
+  int bpv[NB];
+  unsigned Fb[NB];
+  {
+    int nb = 0;
+    bpv[nb++] = 0;
+#pragma unroll
+    for (int q = 0; q < kChainMaxProj; ++q) {
+      bpv[nb++] = q < p.n_proj ? min(Mw, fst[q]) : Mw;
+      bpv[nb++] = q < p.n_proj ? min(Mw, fst[q] + cnt[q]) : Mw;
     }
-  if (w_min <= 0) w_min = 1;
+    bpv[nb++] = min(Mw, p.do_mlp ? M : Mw);
+    bpv[nb++] = Mw;
+#pragma unroll
+    for (int a2 = 1; a2 < NB; ++a2)                        // insertion sort, fully unrolled (the arrays stay in registers)
+#pragma unroll
+      for (int b2 = NB - 1; b2 > 0; --b2)
+        if (b2 <= a2 && bpv[b2] < bpv[b2 - 1]) { const int tmp = bpv[b2]; bpv[b2] = bpv[b2 - 1]; bpv[b2 - 1] = tmp; }
+#pragma unroll
+    for (int a2 = 0; a2 < NB; ++a2) Fb[a2] = cost_to(bpv[a2]);
+  }
+  const unsigned total = Fb[NB - 1];
+  if (total == 0) return;
+  // the cheapest row of the list = the smallest positive slope of a piece
+  unsigned w_min = ~0u;
+#pragma unroll
+  for (int a2 = 0; a2 < NB - 1; ++a2) {
+    const int len = bpv[a2 + 1] - bpv[a2];
+    if (len > 0 && Fb[a2 + 1] > Fb[a2]) w_min = min(w_min, (Fb[a2 + 1] - Fb[a2]) / (unsigned)len);
+  }
+  if (w_min == ~0u || w_min == 0) w_min = 1;
   // number of ranges: a multiple of the grid, large enough that a range of the cheapest rows fits kChainRowsMax (the
   // boundaries are rounded UP to tiles, so a range has floor or ceil of (rows per range / 16) tiles, never more)
-  const long per_max = (long)kChainRowsMax * w_min;
-  long V = (total + per_max - 1) / per_max;
+  const unsigned per_max = (unsigned)kChainRowsMax * w_min;
+  unsigned V = (total + per_max - 1) / per_max;
   V = (V + gridDim.x - 1) / gridDim.x * gridDim.x;
-  // first row (multiple of 16) whose cumulative cost reaches y: F(r) = w_mlp r + sum_q wgt_q min(r, cnt_q)
-  auto row_at = [&](long y) {
-    long lo = 0, hi = (Mw + 15) / 16;                      // in 16-row tiles
-    while (lo < hi) {
-      const long mid = (lo + hi) >> 1;
-      if (cost_to(mid * 16) < y) lo = mid + 1; else hi = mid;
+  const unsigned tq = total / V, trem = total % V;         // ceil(total v / V) = tq v + ceil(trem v / V): no 64-bit division
+  // first row (multiple of 16) whose cumulative cost reaches y: F inverted piece by piece, one 32-bit division
+  auto row_at = [&](unsigned y) {
+    if (y == 0) return 0;
+    if (y > total) return (Mw + 15) / 16 * 16;
+    // the piece [b[a], b[a + 1]) with F(b[a]) < y <= F(b[a + 1]): the first a whose end reaches y (F is non-decreasing,
+    // F(b[0]) = 0 < y); pieces of zero length or zero slope can never be it
+    int base = bpv[NB - 2], bnext = bpv[NB - 1];
+    unsigned fbase = Fb[NB - 2], fnext = Fb[NB - 1];
+    bool found = false;
+#pragma unroll
+    for (int a2 = 0; a2 < NB - 1; ++a2)
+      if (!found && Fb[a2 + 1] >= y) { found = true; base = bpv[a2]; bnext = bpv[a2 + 1]; fbase = Fb[a2]; fnext = Fb[a2 + 1]; }
+    const int len = bnext - base;
+    int r = bnext;
+    if (len > 0 && fnext > fbase) {
+      const unsigned slope = (fnext - fbase) / (unsigned)len;   // exact: the cost per row is constant inside a piece
+      r = base + (int)((y - fbase + slope - 1) / slope);
     }
-    return (int)(lo * 16);
+    return (r + 15) / 16 * 16;
   };
-  for (long v = blockIdx.x; v < V; v += gridDim.x) {
-    const int r0 = v == 0 ? 0 : row_at((total * v + V - 1) / V);
-    const int r1 = v + 1 == V ? (Mw + 15) / 16 * 16 : row_at((total * (v + 1) + V - 1) / V);
+  auto target = [&](unsigned v) { return tq * v + (trem * v + V - 1) / V; };
+  for (unsigned v = blockIdx.x; v < V; v += gridDim.x) {
+    const int r0 = v == 0 ? 0 : row_at(target(v));
+    const int r1 = v + 1 == V ? (Mw + 15) / 16 * 16 : row_at(target(v + 1));
+    CHAIN_NOTE(12, (unsigned long long)(r1 >= r0 ? wall_clock64() : 0));   // range known
     int nt = (r1 - r0) / 16;
     int rs = r0;
     while (nt > 0) {                                       // (at most one piece unless the rounding overshoots)
@@ -437,6 +479,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void node_chain_kernel(NodeChainA
 
 inline hipError_t launch_node_chain(hipStream_t s, const NodeChainArgs& a, int H, int n_cu) {
   if (a.M <= 0) return hipSuccess;
+  if (a.M > (8 << 20)) return hipErrorInvalidValue;        // the split's 32-bit cost arithmetic (rows x 240 units)
   dim3 grid(n_cu), block(kChainThreads);
   switch (H) {
     case 256: hipLaunchKernelGGL((node_chain_kernel<256>), grid, block, 0, s, a); break;

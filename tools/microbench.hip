@@ -314,7 +314,8 @@ int main(int argc, char** argv) {
           const unsigned long long* t = ts.data() + (size_t)b * 32;
           printf("| ... wg %d r0 %llu rows %llu passes %llu phases (us):", b, t[8], t[9], t[10]);
           for (int k = 1; k < 8; ++k) printf(" %.1f", (double)(t[16 + k] - t[16 + k - 1]) / 100.0);
-          printf(" | | | | | |\n");
+          printf("; entry -> counts loaded %.1f us, -> range known %.1f us, -> chain_range %.1f us | | | | | |\n", (double)(t[11] - t[16]) / 100.0,
+                 (double)(t[12] - t[16]) / 100.0, (double)(t[17] - t[16]) / 100.0);
         }
       }
       printf("| ... entry -> end | | %.0f cycles = %.1f us by the 100 MHz wall clock -> shader clock %.2f GHz | | | |\n", tot / cnt,
