@@ -173,6 +173,7 @@ __device__ __forceinline__ void chain_kloop(f32x4 (&acc)[RT][CT], XOf&& x_of, co
 #ifndef DSBDD_CHAIN_PRE
 #define DSBDD_CHAIN_PRE 1
 #endif
+
 template <int H, int RT>
 __device__ __forceinline__ void chain_range(const NodeChainArgs& p, const int r0, const int M, float* smem,
                                             const int* pcount) {
