@@ -435,7 +435,6 @@ __global__ __launch_bounds__(kChainThreads, 2) void node_chain_kernel(NodeChainA
   const unsigned per_max = (unsigned)kChainRowsMax * w_min;
   unsigned V = (total + per_max - 1) / per_max;
   V = (V + gridDim.x - 1) / gridDim.x * gridDim.x;
-  const unsigned tq = total / V, trem = total % V;         // ceil(total v / V) = tq v + ceil(trem v / V): no 64-bit division
   // first row (multiple of 16) whose cumulative cost reaches y: F inverted piece by piece, one 32-bit division
   auto row_at = [&](unsigned y) {
     if (y == 0) return 0;
@@ -456,10 +455,90 @@ __global__ __launch_bounds__(kChainThreads, 2) void node_chain_kernel(NodeChainA
     }
     return (r + 15) / 16 * 16;
   };
+  // Forced cuts (round 4): a range that STRADDLES the end of a projection problem multiplies all its row tiles for a
+  // projection that covers some of them -- it was the slowest workgroup of every launch (171 vs 153 us in the timeline).
+  // The row list is therefore cut at every problem's start (rounded down to a tile) and end (rounded up), and every
+  // segment between two cuts gets its share of the V ranges by cost and splits them with the same inversion of F.
+  // Only for launches of >= 3 row tiles per workgroup: below that the ranges are 1 - 2 tiles, nothing straddles for long, and
+  // the extra arithmetic (1.5 us) is what shows (measured: 19.8 k rows 165.5 -> 153.9 us, 11.5 k 109.6 -> 111.5, 3.6 k 54.9 -> 57.8).
+  constexpr int NC = 2 * kChainMaxProj + 3;
+  const int Tt = (Mw + 15) >> 4;
+  const bool forced = Tt >= 3 * (int)gridDim.x;
+  const unsigned tq = total / V, trem = total % V;         // ceil(total v / V) = tq v + ceil(trem v / V): no 64-bit division
   auto target = [&](unsigned v) { return tq * v + (trem * v + V - 1) / V; };
-  for (unsigned v = blockIdx.x; v < V; v += gridDim.x) {
-    const int r0 = v == 0 ? 0 : row_at(target(v));
-    const int r1 = v + 1 == V ? (Mw + 15) / 16 * 16 : row_at(target(v + 1));
+  int cut[NC];
+  unsigned fcut[NC], nrg[NC];                              // F at the cuts; ranges of the segment that starts at cut a
+  unsigned Vs = V;
+  if (forced) {
+  {
+    int nc = 0;
+    cut[nc++] = 0;
+#pragma unroll
+    for (int q = 0; q < kChainMaxProj; ++q) {
+      cut[nc++] = (q < p.n_proj && cnt[q] > 0) ? min(Tt, fst[q] >> 4) : Tt;
+      cut[nc++] = (q < p.n_proj && cnt[q] > 0) ? min(Tt, (fst[q] + cnt[q] + 15) >> 4) : Tt;
+    }
+    cut[nc++] = p.do_mlp ? min(Tt, (M + 15) >> 4) : Tt;
+    cut[nc++] = Tt;
+#pragma unroll
+    for (int a2 = 1; a2 < NC; ++a2)
+#pragma unroll
+      for (int b2 = NC - 1; b2 > 0; --b2)
+        if (b2 <= a2 && cut[b2] < cut[b2 - 1]) { const int tmp = cut[b2]; cut[b2] = cut[b2 - 1]; cut[b2 - 1] = tmp; }
+  }
+#pragma unroll
+  for (int a2 = 0; a2 < NC; ++a2) fcut[a2] = cost_to(min(Mw, cut[a2] << 4));
+  Vs = 0;
+  {
+    int big = 0; unsigned cbig = 0;
+#pragma unroll
+    for (int a2 = 0; a2 < NC - 1; ++a2) {
+      const unsigned c = fcut[a2 + 1] - fcut[a2];
+      const int tiles = cut[a2 + 1] - cut[a2];
+      unsigned n = 0;
+      if (tiles > 0) {
+        n = (unsigned)((float)c * (float)V / (float)total + 0.5f);
+        n = max(n, (unsigned)((tiles + kChainRowsMax / 16 - 1) / (kChainRowsMax / 16)));   // every range fits the LDS panels
+        n = min(max(n, 1u), (unsigned)tiles);
+        if (c > cbig) { cbig = c; big = a2; }
+      }
+      nrg[a2] = n; Vs += n;
+    }
+    nrg[NC - 1] = 0;
+    // the ranges left over (or borrowed) by the rounding go to (come from) the most expensive segment
+#pragma unroll
+    for (int a2 = 0; a2 < NC - 1; ++a2)
+      if (a2 == big && Vs != V) {
+        const int tiles = cut[a2 + 1] - cut[a2];
+        const int lo_n = (tiles + kChainRowsMax / 16 - 1) / (kChainRowsMax / 16);
+        int n = (int)nrg[a2] + (int)V - (int)Vs;
+        n = min(max(n, max(lo_n, 1)), tiles);
+        Vs = Vs - nrg[a2] + (unsigned)n;
+        nrg[a2] = (unsigned)n;
+      }
+  }
+  }  // forced
+  for (unsigned v = blockIdx.x; v < Vs; v += gridDim.x) {
+    int r0, r1;
+    if (!forced) {
+      r0 = v == 0 ? 0 : row_at(target(v));
+      r1 = v + 1 == V ? (Mw + 15) / 16 * 16 : row_at(target(v + 1));
+    } else {
+    // segment and position of range v
+    unsigned j = v, ns = 1, f0 = 0, cseg = 0;
+    int b0 = 0, b1 = Tt;
+    bool found = false;
+#pragma unroll
+    for (int a2 = 0; a2 < NC - 1; ++a2) {
+      if (!found && j < nrg[a2]) { found = true; ns = nrg[a2]; f0 = fcut[a2]; cseg = fcut[a2 + 1] - fcut[a2]; b0 = cut[a2]; b1 = cut[a2 + 1]; }
+      if (!found) j -= nrg[a2];
+    }
+    if (!found) break;
+    const unsigned sq = cseg / ns, srem = cseg % ns;       // ceil(cseg j / ns) = sq j + ceil(srem j / ns)
+    auto seg_target = [&](unsigned jj) { return f0 + sq * jj + (srem * jj + ns - 1) / ns; };
+    r0 = j == 0 ? (b0 << 4) : min(max(row_at(seg_target(j)), b0 << 4), b1 << 4);
+    r1 = j + 1 == ns ? (b1 << 4) : min(max(row_at(seg_target(j + 1)), b0 << 4), b1 << 4);
+    }
     CHAIN_NOTE(12, (unsigned long long)(r1 >= r0 ? wall_clock64() : 0));   // range known
     int nt = (r1 - r0) / 16;
     int rs = r0;
