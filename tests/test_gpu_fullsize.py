@@ -153,7 +153,8 @@ def _make_ddpm(arch, sd):
                noise_precision=dd["noise_precision"], loss_type="l2", norm_values=dd["norm_values"]).to(dev())
 
 
-@pytest.mark.parametrize("arch,B,n_steps", [("crossdock_fullatom_cond", 64, 3), ("moad_fullatom_joint", 64, 2)])
+@pytest.mark.parametrize("arch,B,n_steps", [("crossdock_fullatom_cond", 64, 3), ("moad_fullatom_joint", 64, 2),
+                                            ("crossdock_ca_cond", 32, 3)])       # configs[2], [4], [1]
 def test_bench_problem_reverse_steps_teacher_forced(arch, B, n_steps):
     """sample_p_zs_given_zt (conditional_model.py:432-464 / en_diffusion.py:503-557) at the
     benchmark batch: the oracle's z_t goes into both sides every step, the same injected
@@ -181,7 +182,7 @@ def test_bench_problem_reverse_steps_teacher_forced(arch, B, n_steps):
         model.set_noise_source(do.NoiseReplay(draws))
         h_l, h_p = model.sample_p_zs_given_zt(s.to(d), t.to(d), z_l.to(d), z_p.to(d), ml.to(d), mp.to(d))
         er, ec = eng.last_edges(N)
-        if k == 0:
+        if k == 0 and "ca_" not in arch:          # the C-alpha problem is the latency regime (153 tiles)
             assert er.numel() > RESIDENT_TILES * 128
         om.edge_hook = lambda i, e=torch.stack([er, ec]): e
         with oracle_threads():
