@@ -34,4 +34,6 @@ timeout 300 python tools/train_step_bench.py --workload crossdock_fullatom_cond 
 timeout 300 python tools/train_step_bench.py --workload crossdock_ca_cond --steps 5 2>/dev/null | tail -2 >> gpurun_out/${TAG}_train_step.md
 cat gpurun_out/${TAG}_train_step.md
 [ -x tools/bin/mb16 ] && timeout 120 tools/bin/mb16 64 20 > gpurun_out/${TAG}_mb16_fa.md 2>&1
+[ -x tools/bin/mb_node_new ] && timeout 120 tools/bin/mb_node_new 64 30 > gpurun_out/${TAG}_microbench_node.md 2>&1
+timeout 600 python tools/testset_sustained.py 24 500 keyed:0.6 > gpurun_out/${TAG}_testset_sustained.md 2>> gpurun_out/${TAG}_bench.err
 ls gpurun_out | grep "^${TAG}" | tr '\n' ' '

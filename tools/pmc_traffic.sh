@@ -9,7 +9,7 @@ TAG=${1:-r3}
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  (cd /tmp && timeout 200 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p -- python $R/bench.py --steps 1 --warmup 0 --timesteps 5 --no-cpu-baseline --no-kernel-timing --no-other-leg > /tmp/pmc_$C.log 2>&1)
+  (cd /tmp && timeout 200 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p -- python $R/bench.py --steps 1 --warmup 0 --timesteps 5 --no-cpu-baseline --no-kernel-timing --no-other-leg --no-other-workloads > /tmp/pmc_$C.log 2>&1)
   DB=$(find /tmp/pmc_$C -name "*.db" | head -1)
   if [ -z "$DB" ]; then echo "no db for $C"; tail -3 /tmp/pmc_$C.log; continue; fi
   L=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
