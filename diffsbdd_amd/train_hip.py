@@ -327,6 +327,124 @@ class EdgeCoord(torch.autograd.Function):
         return (d_pq, d_x, d_mean, gd0_tot, *gq, d_w3, None, None)
 
 
+class EdgeFirstLayer(torch.autograd.Function):
+    """First Linear of an edge MLP (egnn_new.py:35,99) in the layouts the edge kernels read:
+    weight [H][2H + 2 (+ emb)], bias [H], edge-embedding table [3][emb] (or None) ->
+    W_pq [2H][H] (the per-node projections P | Q), wd, wd0 [H] (the two distance columns), tab [3][H] (bias + embedded
+    edge type).  One autograd node instead of six slicing / concatenation nodes per MLP: their backward was a zero fill
+    and a copy of the whole weight each (a third of the step's small launches)."""
+
+    @staticmethod
+    def forward(ctx, w, bias, emb_w):
+        H = w.shape[0]
+        ctx.H = H
+        ctx.save_for_backward(w, emb_w if emb_w is not None else bias)
+        ctx.has_emb = emb_w is not None
+        w_pq = torch.cat((w[:, :H], w[:, H:2 * H]), 0)
+        wd, wd0 = w[:, 2 * H].contiguous(), w[:, 2 * H + 1].contiguous()
+        if emb_w is not None:
+            tab = torch.addmm(bias[None, :].expand(emb_w.shape[0], H), emb_w, w[:, 2 * H + 2:].t())
+        else:
+            tab = bias[None, :].expand(3, H).contiguous()
+        return w_pq, wd, wd0, tab
+
+    @staticmethod
+    def backward(ctx, d_wpq, d_wd, d_wd0, d_tab):
+        w, emb_w = ctx.saved_tensors
+        H = ctx.H
+        dw = torch.zeros_like(w) if (d_wpq is None or d_wd is None or d_wd0 is None or (ctx.has_emb and d_tab is None)) \
+            else torch.empty_like(w)
+        if d_wpq is not None:
+            dw[:, :H] = d_wpq[:H]
+            dw[:, H:2 * H] = d_wpq[H:]
+        if d_wd is not None:
+            dw[:, 2 * H] = d_wd
+        if d_wd0 is not None:
+            dw[:, 2 * H + 1] = d_wd0
+        d_bias = d_emb = None
+        if d_tab is not None:
+            d_bias = d_tab.sum(0)
+            if ctx.has_emb:
+                dw[:, 2 * H + 2:] = d_tab.t() @ emb_w
+                d_emb = d_tab @ w[:, 2 * H + 2:]
+        elif ctx.needs_input_grad[1]:
+            d_bias = torch.zeros(H, dtype=w.dtype, device=w.device)
+        return dw, d_bias, d_emb
+
+
+def _wgrad(dy, x):
+    """dW [n_out][n_in] = dy^T x on dsbdd_train_wgrad (ordered split-K: bitwise reproducible)."""
+    lib = _lib.load()
+    M, n_out = dy.shape
+    n_in = x.shape[1]
+    dW = torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)
+    if M == 0:
+        return dW.zero_()
+    nb = lib.dsbdd_train_wgrad_scratch_bytes(M, n_out, n_in)
+    scr = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.dsbdd_train_wgrad(_stream(dy.device), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, n_out,
+                                     n_in, dW.data_ptr(), scr.data_ptr(), nb), "dsbdd_train_wgrad")
+    return dW
+
+
+def _colsum(dy):
+    lib = _lib.load()
+    M, n_out = dy.shape
+    db = torch.empty(n_out, dtype=torch.float32, device=dy.device)
+    if M == 0:
+        return db.zero_()
+    nb = 4 * ((M + 31) // 32) * n_out
+    scr = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.dsbdd_train_colsum(_stream(dy.device), dy.data_ptr(), dy.stride(0), M, n_out, db.data_ptr(),
+                                      scr.data_ptr(), nb), "dsbdd_train_colsum")
+    return db
+
+
+class NodeMLP(torch.autograd.Function):
+    """GCL.node_model (egnn_new.py:53-58): h + Linear2(SiLU(Linear1([h | agg]))) as one autograd node: the concatenation is
+    the two-operand form of dsbdd_node_linear, the residual its R operand; backward = two dX GEMMs, two ordered
+    weight-gradient GEMMs, two column sums and aten's fused SiLU backward."""
+
+    @staticmethod
+    def forward(ctx, h, agg, W1, b1, W2, b2):
+        lib = _lib.load()
+        h, agg = h.contiguous(), agg.contiguous()
+        W1, W2 = W1.contiguous(), W2.contiguous()
+        M, H = h.shape
+        Ka = agg.shape[1]
+        n_hid, n_out = W1.shape[0], W2.shape[0]
+        dev = h.device
+        z = torch.empty(M, n_hid, dtype=torch.float32, device=dev)
+        out = torch.empty(M, n_out, dtype=torch.float32, device=dev)
+        if M:
+            w1t = _pad_cols(W1.t())
+            _lib.check(lib.dsbdd_node_linear(_stream(dev), h.data_ptr(), h.stride(0), H, agg.data_ptr(), agg.stride(0), Ka,
+                                             w1t.data_ptr(), w1t.stride(0), _ptr(b1.contiguous()), None, 0, z.data_ptr(),
+                                             n_hid, M, n_hid, 0), "dsbdd_node_linear")
+            a = F.silu(z)
+            w2t = _pad_cols(W2.t())
+            _lib.check(lib.dsbdd_node_linear(_stream(dev), a.data_ptr(), a.stride(0), n_hid, None, 0, 0, w2t.data_ptr(),
+                                             w2t.stride(0), _ptr(b2.contiguous()), h.data_ptr(), h.stride(0),
+                                             out.data_ptr(), n_out, M, n_out, 0), "dsbdd_node_linear")
+        else:
+            a = z
+        ctx.save_for_backward(h, agg, z, a, W1, W2)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        h, agg, z, a, W1, W2 = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        H = h.shape[1]
+        da = _node_linear(d_out, _pad_cols(W2), None, W2.shape[1])
+        dW2, db2 = _wgrad(d_out, a), _colsum(d_out)
+        dz = torch.ops.aten.silu_backward(da, z)
+        d_cat = _node_linear(dz, _pad_cols(W1), None, W1.shape[1])
+        xcat = torch.cat((h, agg), 1)
+        dW1, db1 = _wgrad(dz, xcat), _colsum(dz)
+        return d_out + d_cat[:, :H], d_cat[:, H:], dW1, db1, dW2, db2
+
+
 def _lin(layer, x):
     return HipLinear.apply(x, layer.weight, layer.bias)
 
@@ -338,14 +456,7 @@ def _mlp2(seq, x):
 
 def _edge_params(first, H, emb):
     """First layer of an edge MLP (egnn_new.py:35,99) -> (W_pq [2H][H], wd, wd0, tab [3][H])."""
-    w = first.weight
-    w_pq = torch.cat((w[:, :H], w[:, H:2 * H]), 0)
-    wd, wd0 = w[:, 2 * H], w[:, 2 * H + 1]
-    if emb is not None:
-        tab = first.bias[None, :] + emb.weight @ w[:, 2 * H + 2:].t()          # [3][H]
-    else:
-        tab = first.bias[None, :].expand(3, H)
-    return w_pq, wd, wd0, tab
+    return EdgeFirstLayer.apply(first.weight, first.bias, emb.weight if emb is not None else None)
 
 
 def dynamics_forward_hip(m, xh_atoms, xh_residues, t, mask_atoms, mask_residues):
@@ -387,8 +498,8 @@ def dynamics_forward_hip(m, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
             else:
                 aw = ab = None
             agg = EdgeGCL.apply(pq, x_cur, ed0, wd, wd0, tab, gcl.edge_mlp[2].weight, gcl.edge_mlp[2].bias, aw, ab, g, nf)
-            z = _lin(gcl.node_mlp[0], torch.cat((h, agg), 1))                                          # :53-58
-            h = h + _lin(gcl.node_mlp[2], F.silu(z))
+            h = NodeMLP.apply(h, agg, gcl.node_mlp[0].weight, gcl.node_mlp[0].bias, gcl.node_mlp[2].weight,
+                              gcl.node_mlp[2].bias)                                                    # :53-58
         eq = blk.gcl_equiv                                                                             # :96-122
         wc_pq, wd_c, wd0_c, tab_c = _edge_params(eq.coord_mlp[0], H, emb)
         if eq.cross_product_mlp is not None:

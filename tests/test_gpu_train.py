@@ -94,6 +94,51 @@ def test_hip_linear_forward_backward(M, K, N, bias):
         assert rel_err(b.grad, bd.grad) < 3e-6
 
 
+@pytest.mark.parametrize("M,H", [(777, 256), (300, 192), (37, 128)])
+def test_node_mlp_function(M, H):
+    """NodeMLP (GCL.node_model, egnn_new.py:53-58, as one autograd node) vs the same expression in fp64 torch."""
+    from diffsbdd_amd.train_hip import NodeMLP
+    g = torch.Generator().manual_seed(M + H)
+    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dev()).requires_grad_(True)
+    h, agg = mk(M, H), mk(M, H)
+    W1, b1, W2, b2 = mk(H, 2 * H, sc=(2 * H) ** -0.5), mk(H), mk(H, H, sc=H ** -0.5), mk(H)
+    gy = torch.randn(M, H, generator=g).to(dev())
+    y = NodeMLP.apply(h, agg, W1, b1, W2, b2)
+    y.backward(gy)
+    leaves = [t.detach().double().requires_grad_(True) for t in (h, agg, W1, b1, W2, b2)]
+    hd, ad, W1d, b1d, W2d, b2d = leaves
+    yr = hd + F.linear(F.silu(F.linear(torch.cat((hd, ad), 1), W1d, b1d)), W2d, b2d)
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < 3e-6
+    for a, b in zip((h, agg, W1, b1, W2, b2), leaves):
+        assert rel_err(a.grad, b.grad) < 5e-6, rel_err(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("H,emb", [(256, None), (192, 8), (64, 4)])
+def test_edge_first_layer_function(H, emb):
+    """EdgeFirstLayer: the re-layout of an edge MLP's first Linear (P | Q projections, the two distance columns, the
+    bias + edge-type table) and its backward vs autograd over the slicing expression it replaces."""
+    from diffsbdd_amd.train_hip import EdgeFirstLayer
+    g = torch.Generator().manual_seed(H)
+    cols = 2 * H + 2 + (emb or 0)
+    w = (torch.randn(H, cols, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    b = torch.randn(H, generator=g).to(dev()).requires_grad_(True)
+    e = torch.randn(3, emb, generator=g).to(dev()).requires_grad_(True) if emb else None
+    outs = EdgeFirstLayer.apply(w, b, e)
+    gs = [torch.randn(o.shape, generator=g).to(dev()) for o in outs]
+    torch.autograd.backward(outs, gs)
+    wd_, bd_ = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    ed_ = e.detach().double().requires_grad_(True) if emb else None
+    ref = (torch.cat((wd_[:, :H], wd_[:, H:2 * H]), 0), wd_[:, 2 * H], wd_[:, 2 * H + 1],
+           (bd_[None, :] + ed_ @ wd_[:, 2 * H + 2:].t()) if emb else bd_[None, :].expand(3, H))
+    torch.autograd.backward(ref, [x.double() for x in gs])
+    for o, r in zip(outs, ref):
+        assert rel_err(o, r) < 1e-6
+    assert rel_err(w.grad, wd_.grad) < 1e-6 and rel_err(b.grad, bd_.grad) < 1e-6
+    if emb:
+        assert rel_err(e.grad, ed_.grad) < 1e-6
+
+
 def _graph_problem(arch, n_lig, n_poc, seed):
     from diffsbdd_amd.train_hip import TrainGraph
     cfg, _ = W.arch_cfg(arch)
