@@ -191,7 +191,7 @@ class DistributionNodes:
         assert (n1 is None) ^ (n2 is None), "Exactly one input argument must be None"
         dists = self.n1_given_n2 if n2 is not None else self.n2_given_n1
         c = n2 if n2 is not None else n1
-        return torch.tensor([dists[int(i)].sample() for i in c], device=c.device)
+        return torch.tensor([dists[int(i)].sample() for i in c.tolist()], device=c.device)
 
     def log_prob(self, batch_n_nodes_1, batch_n_nodes_2):
         assert batch_n_nodes_1.dim() == 1 and batch_n_nodes_2.dim() == 1
@@ -201,13 +201,15 @@ class DistributionNodes:
 
     def log_prob_n1_given_n2(self, n1, n2):
         assert n1.dim() == 1 and n2.dim() == 1
-        return torch.stack([self.n1_given_n2[int(c)].log_prob(i.cpu())
-                            for i, c in zip(n1, n2)]).to(n1.device)
+        n1c, n2c = n1.cpu(), n2.cpu()             # one copy each (a device tensor would synchronise per sample)
+        return torch.stack([self.n1_given_n2[int(c)].log_prob(i)
+                            for i, c in zip(n1c, n2c)]).to(n1.device)
 
     def log_prob_n2_given_n1(self, n2, n1):
         assert n1.dim() == 1 and n2.dim() == 1
-        return torch.stack([self.n2_given_n1[int(c)].log_prob(i.cpu())
-                            for i, c in zip(n2, n1)]).to(n2.device)
+        n1c, n2c = n1.cpu(), n2.cpu()
+        return torch.stack([self.n2_given_n1[int(c)].log_prob(i)
+                            for i, c in zip(n2c, n1c)]).to(n2.device)
 
 
 # ---------------------------------------------------------------------------
