@@ -1528,9 +1528,11 @@ struct WgradPlan { int chunks, kc; size_t floats; };
 static WgradPlan wgrad_plan(int64_t K, int64_t M, int64_t N) {
   // short chunks for the node-level gradients (K = a few thousand rows: the launch is a latency chain), at most
   // 768 / tiles chunks for the edge-level ones (the reduction reads every partial once)
+  static const int min_kc = [] { const char* v = getenv("DSBDD_WGRAD_MINKC"); return v && atoi(v) >= 32 ? atoi(v) : 64; }();
+  static const int max_wg = [] { const char* v = getenv("DSBDD_WGRAD_MAXWG"); return v && atoi(v) >= 1 ? atoi(v) : 768; }();
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int64_t chunks = (K + 63) / 64;
-  const int64_t cap = 768 / tiles > 1 ? 768 / tiles : 1;
+  int64_t chunks = (K + min_kc - 1) / min_kc;
+  const int64_t cap = max_wg / tiles > 1 ? max_wg / tiles : 1;
   if (chunks > cap) chunks = cap;
   if (chunks < 1) chunks = 1;
   int64_t kc = ((K + chunks - 1) / chunks + 31) / 32 * 32;

@@ -640,14 +640,50 @@ __global__ void partial_reduce_kernel(const float* part, int n_part, size_t stri
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient:  Cp[z][m][n] = sum over k in chunk z of A[k][m] B[k][n]   (A [K][lda], B [K][ldb]); the chunks are
-// added by partial_reduce_kernel.  Workgroup tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles of 32 x 32), the
-// operands come straight from global memory (32 consecutive words of a row per half-wave and load).
+// added by partial_reduce_kernel.  Workgroup tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles of 32 x 32).  The operands
+// go through LDS in slabs of 16 k rows (16-byte coalesced loads one slab ahead in registers, two LDS buffers, one barrier per
+// slab); a wave reads its A / B words with ds_read_b32 (lane = column, the two half-waves one k row apart: the row stride of
+// 160 words puts them on disjoint banks).  First version (operands straight from global memory, one dword load per lane
+// and MFMA): 43 - 48 TFLOP/s on the edge-level gradients (profiles/r4m_wgrad_sweep.md).
 struct WgradArgs { const float* A; int lda; const float* B; int ldb; int K; int M; int N; float* Cp; int kc; };
 
+constexpr int kWgBK = 16, kWgLd = 160;
+
+__device__ __forceinline__ void wgrad_slab_load(const float* X, int ld, int K1, int k, int c0, int C, bool vec, int t,
+                                                f32x4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = t + kThreads * i, row = q >> 5, col = c0 + 4 * (q & 31);
+    const int kk = k + row;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kk < K1) {
+      const float* src = X + (size_t)kk * ld + col;
+      if (vec && col + 3 < C) v = ldv4(src);
+      else {
+        if (col < C) v[0] = src[0];
+        if (col + 1 < C) v[1] = src[1];
+        if (col + 2 < C) v[2] = src[2];
+        if (col + 3 < C) v[3] = src[3];
+      }
+    }
+    r[i] = v;
+  }
+}
+
+__device__ __forceinline__ void wgrad_slab_store(float* buf, int t, const f32x4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = t + kThreads * i;
+    *reinterpret_cast<f32x4*>(buf + (q >> 5) * kWgLd + 4 * (q & 31)) = r[i];
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][kWgBK * kWgLd];
+  __shared__ __attribute__((aligned(16))) float sB[2][kWgBK * kWgLd];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1, j = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.x * 128 + wm * 64, n0 = blockIdx.y * 128 + wn * 64;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
   const int k0 = blockIdx.z * p.kc, k1 = min(p.K, k0 + p.kc);
   f32x16 acc[2][2];
 #pragma unroll
@@ -657,51 +693,51 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
   if (k0 < k1) {
-    const bool mv0 = m0 + j < p.M, mv1 = m0 + 32 + j < p.M, nv0 = n0 + j < p.N, nv1 = n0 + 32 + j < p.N;
-    const float* A0 = p.A + (mv0 ? m0 + j : 0);
-    const float* A1 = p.A + (mv1 ? m0 + 32 + j : 0);
-    const float* B0 = p.B + (nv0 ? n0 + j : 0);
-    const float* B1 = p.B + (nv1 ? n0 + 32 + j : 0);
-    // two register sets: the loads of block k + 16 are in flight while block k multiplies (the loop is a latency chain
-    // for the short K of the node-level gradients)
-    float a0[2][8], a1[2][8], b0[2][8], b1[2][8];
-    auto load = [&](int k, int sel) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int kk = k + 2 * s + kh;
-        const bool ok = kk < k1;
-        const size_t row = ok ? kk : k0;
-        const float va0 = A0[row * p.lda], va1 = A1[row * p.lda], vb0 = B0[row * p.ldb], vb1 = B1[row * p.ldb];
-        a0[sel][s] = (ok && mv0) ? va0 : 0.f; a1[sel][s] = (ok && mv1) ? va1 : 0.f;
-        b0[sel][s] = (ok && nv0) ? vb0 : 0.f; b1[sel][s] = (ok && nv1) ? vb1 : 0.f;
-      }
-    };
-    auto mult = [&](int sel) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        acc[0][0] = mfma32(a0[sel][s], b0[sel][s], acc[0][0]);
-        acc[0][1] = mfma32(a0[sel][s], b1[sel][s], acc[0][1]);
-        acc[1][0] = mfma32(a1[sel][s], b0[sel][s], acc[1][0]);
-        acc[1][1] = mfma32(a1[sel][s], b1[sel][s], acc[1][1]);
-      }
-    };
-    load(k0, 0);
+    const bool va = (p.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0;
+    const bool vb = (p.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0;
+    f32x4 ra[2], rb[2];
+    wgrad_slab_load(p.A, p.lda, k1, k0, m0, p.M, va, t, ra);
+    wgrad_slab_load(p.B, p.ldb, k1, k0, n0, p.N, vb, t, rb);
+    wgrad_slab_store(sA[0], t, ra);
+    wgrad_slab_store(sB[0], t, rb);
+    __syncthreads();
+    int cur = 0;
+    const int oa = kh * kWgLd + wm * 64 + j, ob = kh * kWgLd + wn * 64 + j;
 #pragma unroll 1
-    for (int k = k0; k < k1; k += 32) {
-      load(k + 16, 1);            // (rows past k1 load row k0 and count as zero)
-      mult(0);
-      load(k + 32, 0);
-      mult(1);
+    for (int k = k0; k < k1; k += kWgBK) {
+      const bool more = k + kWgBK < k1;
+      if (more) {
+        wgrad_slab_load(p.A, p.lda, k1, k + kWgBK, m0, p.M, va, t, ra);
+        wgrad_slab_load(p.B, p.ldb, k1, k + kWgBK, n0, p.N, vb, t, rb);
+      }
+      const float* a_ = sA[cur] + oa;
+      const float* b_ = sB[cur] + ob;
+#pragma unroll
+      for (int s = 0; s < kWgBK / 2; ++s) {
+        const float a0 = a_[2 * s * kWgLd], a1 = a_[2 * s * kWgLd + 32];
+        const float b0 = b_[2 * s * kWgLd], b1 = b_[2 * s * kWgLd + 32];
+        acc[0][0] = mfma32(a0, b0, acc[0][0]);
+        acc[0][1] = mfma32(a0, b1, acc[0][1]);
+        acc[1][0] = mfma32(a1, b0, acc[1][0]);
+        acc[1][1] = mfma32(a1, b1, acc[1][1]);
+      }
+      if (more) {
+        wgrad_slab_store(sA[cur ^ 1], t, ra);
+        wgrad_slab_store(sB[cur ^ 1], t, rb);
+      }
+      __syncthreads();
+      cur ^= 1;
     }
   }
   float* C = p.Cp + (size_t)blockIdx.z * p.M * p.N;
+  const int mb = m0 + wm * 64, nb = n0 + wn * 64;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int m = m0 + 32 * a + mfma_row(q, lane), n = n0 + 32 * b + j;
+        const int m = mb + 32 * a + mfma_row(q, lane), n = nb + 32 * b + j;
         if (m < p.M && n < p.N) C[(size_t)m * p.N + n] = acc[a][b][q];
       }
 }
