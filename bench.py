@@ -350,11 +350,14 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the HIP-event timing of the dominant kernel (roofline = null); the engine "
                          "then replays its captured hipGraph instead of launching eagerly")
-    ap.add_argument("--pockets", default="same", choices=["same", "mixed"],
+    ap.add_argument("--pockets", default="same", choices=["same", "mixed", "grouped"],
                     help="'same' (default, BASELINE configs[2]): one pocket repeated over the batch, what "
                          "prepare_pocket(repeats=n) hands the samplers; 'mixed' (SURVEY.md 8d, heterogeneous variant): "
                          "3rfm and 5ndu alternating, every sample under its own random rigid rotation (seed 0) -- "
-                         "no two pockets of the batch are identical")
+                         "no two pockets of the batch are identical; 'grouped': the first 5/8 of the batch one pocket, "
+                         "the rest distinct (a test-set batch of one large job plus refills)")
+    ap.add_argument("--n-same", type=int, default=None,
+                    help="--pockets grouped: number of samples that share the first pocket (default 5/8 of the batch)")
     ap.add_argument("--states", default="anchored", choices=["anchored", "free"],
                     help="pocket-conditioned workloads: 'anchored' (default, the headline) keeps every step's ligand "
                          "state on the forward process of a pose inside the pocket -- ConditionalDDPM.inpaint with "
@@ -403,8 +406,9 @@ def main():
     eng = model.dynamics.engine()
     replicas, n_streams = None, 1
     anchor = None if joint else anchor_ligand(B, args.n_lig, cfg["atom_nf"], device)
-    if args.pockets == "mixed":
-        pocket0, anchor_m = synthetic.mixed_pockets(key, B, args.n_lig, cfg["atom_nf"], device)
+    if args.pockets in ("mixed", "grouped"):      # grouped: 5/8 of the batch one pocket, the rest singletons (40 + 24 at B = 64)
+        pocket0, anchor_m = synthetic.mixed_pockets(key, B, args.n_lig, cfg["atom_nf"], device,
+                                                    n_same=((args.n_same or 5 * B // 8) if args.pockets == "grouped" else 0))
         anchor = None if joint else anchor_m
 
     def chain(seed, states=None):
@@ -565,7 +569,9 @@ def main():
                 cpu["config0"] = cpu_config0(max_threads=args.cpu_threads)
         value = n_ligands_total / elapsed
         pocket_desc = (f"3rfm {key} pocket, {pocket0['x'].shape[0] // B} nodes" if args.pockets == "same" else
-                       f"3rfm / 5ndu {key} pockets alternating, each under its own rigid rotation: no two identical")
+                       f"3rfm / 5ndu {key} pockets alternating, each under its own rigid rotation: no two identical"
+                       if args.pockets == "mixed" else
+                       f"{args.n_same or 5 * B // 8} x one 3rfm {key} pocket + {B - (args.n_same or 5 * B // 8)} distinct 3rfm / 5ndu pockets")
         line = {
             "metric": METRIC, "value": value, "unit": "ligands/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,

@@ -594,7 +594,7 @@ class EnVariationalDiffusion(nn.Module):
     # forward cone of the engine (csrc/engine.hip): 2 = on, 0 = off (1 = the engine's own cost model, for direct C-API
     # callers).  Cone on / off differ in rounding (the canonical pocket is evaluated on the raw pocket coordinates), so the
     # mode is decided HERE, once per chain and from the pocket groups alone (`_cone_for_groups`: on while the distinct
-    # pockets are at most 0.4 of the batch -- one pocket repeated, the reference's generate_ligands / test.py case: on;
+    # pockets are at most 0.2 of the batch (measured break-even at B = 64: 12 groups, profiles/r4n_cone_rule.md) -- one pocket repeated, the reference's generate_ligands / test.py case: on;
     # every pocket different: off), never by an engine heuristic in the middle of a chain.  A driver that wants
     # bit-identical molecules for ANY packing of pockets into batches pins the mode (testset.make_hip_sampler: 2 for
     # the duration of a batch); the environment variable DSBDD_CONE overrides both.
@@ -604,7 +604,7 @@ class EnVariationalDiffusion(nn.Module):
     def _cone_for_groups(rep, batch):
         """2 (on) / 0 (off) from representative[b] (None: every sample its own pocket)."""
         n_groups = batch if rep is None else int(torch.unique(rep).numel())
-        return 2 if 5 * n_groups <= 2 * batch else 0
+        return 2 if 5 * n_groups <= batch else 0
     # 16-edge-granule edge kernels (csrc/edge_wave16.h, include/diffsbdd_hip.h DSBDD_OPT_GRANULE16): bit mask of the stages
     # that use them; None leaves the engine's setting (default 0, environment DSBDD_GRANULE16) alone.  The variants agree to
     # rounding, so the mask is part of a chain's definition like `cone_mode`: set once, never changed by the engine.

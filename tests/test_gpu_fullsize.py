@@ -398,6 +398,7 @@ def test_full_atom_chains_with_identical_pockets_vs_oracle():
     om = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], dd["timesteps"], dd["noise_schedule"],
                         dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
     model = _make_ddpm(arch, sd)
+    model.cone_mode = 2          # three samples are below the rule's break-even (one group per >= 5 samples): pin the cone on
     # sample_given_pocket
     tape = do.NoiseTape(5)
     with oracle_threads():

@@ -533,9 +533,10 @@ def test_per_chain_engine_choices_are_pure_functions_of_the_batch():
     assert D._cone_for_groups(torch.zeros(64, dtype=torch.int64), 64) == 2          # one pocket repeated
     assert D._cone_for_groups(torch.arange(64), 64) == 0 and D._cone_for_groups(None, 64) == 0
     two = torch.cat([torch.zeros(40, dtype=torch.int64), torch.full((24,), 40)])
-    assert D._cone_for_groups(two, 64) == 2                                         # 2 groups of 64: 10 <= 128
-    many = torch.cat([torch.zeros(40, dtype=torch.int64), torch.arange(40, 64)])
-    assert D._cone_for_groups(many, 64) == 2 and D._cone_for_groups(torch.arange(64) // 2, 64) == 0
+    assert D._cone_for_groups(two, 64) == 2                                         # 2 groups of 64: 10 <= 64
+    many = torch.cat([torch.zeros(40, dtype=torch.int64), torch.arange(40, 64)])    # 40 x A + 24 singletons: measured slower
+    assert D._cone_for_groups(many, 64) == 0 and D._cone_for_groups(torch.arange(64) // 2, 64) == 0
+    assert D._cone_for_groups(torch.arange(64) // 6, 64) == 2 and D._cone_for_groups(torch.arange(64) // 4, 64) == 0   # 11 / 16 groups
     # coordinate stages on the 16-edge kernels: C-alpha x 32 (274 -> 548 items: a round saved) yes, full-atom x 64 no
     ca = torch.repeat_interleave(torch.arange(32), 23)
     fa = torch.repeat_interleave(torch.arange(64), 23)
