@@ -665,13 +665,13 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   // Cost model: the canonical network is extra work -- its G/2 ascending stages on every ghost row (the frame's pockets:
   // frame_n3 rows, one per group of identical pockets) -- against the rows the cone's first stages skip.  On the
   // benchmark pocket the skipped part is (1 - 0.28) + (1 - 0.69) + (1 - 0.97) = 1.06 edge lists per call and the
-  // pocket-pocket edges of the ghosts are 0.83 of a list per stage: by edge counts the cone would pay while the frame holds
-  // less than 1.06 / (3 x 0.83) = 0.43 of the batch's pocket rows.  MEASURED at B = 64 (profiles/r4n_cone_rule.md): cone on
-  // minus off = +455 ms per chain with 64 groups, +111 ms with 25 (40 x one pocket + 24 singletons), about -100 ms with one
-  // group -- 8.8 ms per ghost pocket against 1.7 ms saved per sample (the ascending stages' short launches run at 0.63
-  // instead of 0.75 of the peak): break-even at 12 groups.  The rule is 0.2 of the pocket rows.  DSBDD_CONE=2 / option
-  // value 2 forces the cone on.
-  const bool cone_pays = e->cone >= 2 || 5 * e->frame_n3 <= (int64_t)n_pocket;
+  // pocket-pocket edges of the ghosts are 0.83 of a list per stage, so by edge counts the cone pays while the frame holds less
+  // than 1.06 / (3 x 0.83) = 0.43 of the batch's pocket rows: this rule (option value 1) is kept for direct C-API callers.
+  // MEASURED at B = 64 (profiles/r4n_cone_rule.md) the break-even is lower -- 12 distinct pockets of 64: 8.8 ms per chain
+  // and ghost pocket (the ascending stages' short launches run at 0.63 instead of 0.75 of the peak) against 1.7 ms saved
+  // per sample -- and a size-dependent rule inside the engine would let a batch and its half take different modes; the
+  // DDPM modules therefore decide per chain from the pocket groups (5 groups <= batch) and pass 0 / 2.
+  const bool cone_pays = e->cone >= 2 || 5 * e->frame_n3 <= 2 * (int64_t)n_pocket;
   const bool cone = prune && split0 && e->cone && cone_pays && t_count == 1 && G_stages >= 2;
   // with a frame, the frame's pockets are the ghost rows N .. N + n_frame_rows; in the level-ordered list they own the
   // first n_ghost entries of lvl_list and the first ghost_slots edge slots

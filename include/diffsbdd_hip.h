@@ -213,7 +213,8 @@ int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghos
 
 /* Switches of the dead-row elimination (environment: DSBDD_PRUNE, DSBDD_CONE).  DSBDD_OPT_PRUNE: 0 / 1.
  * DSBDD_OPT_CONE: 0 = never, 1 = when the engine's cost model says the canonical-pocket network pays (default: the
- * frame's representatives hold at most 0.2 of the batch's pocket rows), 2 = always.  Cone on / off agree to rounding.
+ * frame's representatives hold at most 0.4 of the batch's pocket rows; the DDPM modules decide per chain from the
+ * pocket groups with the measured break-even 0.2 and pass 0 / 2), 2 = always.  Cone on / off agree to rounding.
  * DSBDD_OPT_GRANULE16: bit mask of the stages that run on the 16-edge-granule variant of the fused edge kernels
  * (csrc/edge_wave16.h: a wave owns 16 edges on v_mfma_f32_16x16x4_f32 instead of 32 on 32x32x2; half the work unit, for
  * launches too small to fill the SIMDs a whole number of times): bit g (g < 16) = message stage g (block * inv_sublayers +

@@ -295,7 +295,10 @@ def test_ligand_only_call_evaluates_live_rows(arch, B, frame, monkeypatch):
     else:
         raw = xp[:, :3]
 
-    def run(want_pocket, lo=0, cone=True):
+    def run(want_pocket, lo=0, cone=None):
+        # the mode a chain pins per batch (EnVariationalDiffusion._cone_for_groups): on for identical pockets, off otherwise
+        # -- never the engine's own size-dependent rule, which may differ between a batch and its half
+        cone = (2 if shared else 0) if cone is None else int(cone)
         sl, sp, batch = slice(lo * nl, None), slice(lo * n0, None), B - lo
         m = make_dynamics(cfg, sd)
         eng = m.engine()
@@ -583,6 +586,7 @@ def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps, gran
     d = dev()
     dl = 3 + cfg["atom_nf"]
     model = _make_ddpm(arch, sd)
+    model.cone_mode = 2          # the plan of the benchmark (B = 3 is below the per-chain rule's break-even of 5 samples per pocket)
     om = do.OracleModel(sd, cfg, cfg["atom_nf"], cfg["residue_nf"], T, dd["noise_schedule"],
                         dd["noise_precision"], norm_values=dd["norm_values"], conditional=True)
     # the benchmark's inputs (bench.py: load_pocket + anchor_ligand), once per side
