@@ -209,11 +209,25 @@ class TestSetDriver:
                     f.write(f"{name} {sec}\n")
 
 
-def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bias=0, n_nodes_min=0, **kwargs):
+def cone_mode_for_jobs(jobs: List[PocketJob]) -> int:
+    """Forward-cone mode of a WHOLE test-set run (one value for every batch and every rank, so that molecules do not
+    depend on the packing or the sharding): on (2) when the jobs ask for at least 5 samples per pocket on average --
+    the measured break-even of the canonical-pocket network is one distinct pocket per 5 samples of a batch
+    (profiles/r4n_cone_rule.md) and a batch packs jobs in proportion to their requests; the reference's runs
+    (n_samples = 100, test.py:75) are far above it.  Decide on the complete job list, before assign_to_ranks."""
+    n = sum(j.n_samples for j in jobs)
+    return 2 if n >= 5 * max(len(jobs), 1) else 0
+
+
+def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bias=0, n_nodes_min=0, cone_mode=2, **kwargs):
     """`sample_batch` for TestSetDriver on a `generate.LigandGenerator`: one packed sampling batch on
     the GPU (LigandGenerator.generate_for_pockets).  Global sample id of slot k of a job's r-th round =
-    index * 2^20 + (samples generated for the job so far) + k: independent of the packing."""
+    index * 2^20 + (samples generated for the job so far) + k: independent of the packing.
+    cone_mode: the engine's forward cone for EVERY batch of the run (2 = on, the default; 0 = off;
+    `cone_mode_for_jobs(all jobs)` picks by the requested samples per pocket)."""
     import torch
+    if cone_mode not in (0, 2):
+        raise ValueError("cone_mode must be 0 or 2 (a per-batch choice would make molecules depend on the packing)")
 
     def ligand_sizes(job, ids):
         """Ligand sizes of the slots `ids` of one job: fixed, or drawn from p(n_lig | n_pocket)
@@ -232,10 +246,10 @@ def make_hip_sampler(gen, timesteps=None, seed=0, largest_frag=True, n_nodes_bia
         ids = [job.index * (1 << 20) + job.n_generated + torch.arange(n) for job, n in plan]
         jobs = [(job.residues, n, ligand_sizes(job, i)) for (job, n), i in zip(plan, ids)]
         # bit-identical molecules for any packing: the engine's forward cone must not switch with the number of
-        # distinct pockets in a batch (en_diffusion.cone_mode) -- pinned on for this batch only, the generator's own
-        # setting is restored afterwards
+        # distinct pockets in a batch (en_diffusion.cone_mode) -- pinned to the run's mode for this batch only, the
+        # generator's own setting is restored afterwards
         saved, saved_g = gen.ddpm.cone_mode, gen.ddpm.edge_granule16
-        gen.ddpm.cone_mode = 2
+        gen.ddpm.cone_mode = cone_mode
         if saved_g == "auto":
             gen.ddpm.edge_granule16 = 0        # (the automatic choice looks at the batch: pinned for the same reason)
         try:
@@ -315,7 +329,8 @@ def main(argv=None):
     mine = assign_to_ranks(number_jobs(jobs), world)[rank]
     extra = dict(resamplings=a.resamplings, jump_length=a.jump_length) if gen.mode == "joint" else {}
     driver = TestSetDriver(make_hip_sampler(gen, a.timesteps, a.seed, largest_frag=not a.all_frags,
-                                            n_nodes_bias=a.n_nodes_bias, n_nodes_min=a.n_nodes_min, **extra),
+                                            n_nodes_bias=a.n_nodes_bias, n_nodes_min=a.n_nodes_min,
+                                            cone_mode=cone_mode_for_jobs(jobs), **extra),
                            a.batch_size, is_valid=valence_filter if a.sanitize else None)
     failed = None
     try:

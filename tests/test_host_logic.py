@@ -537,6 +537,13 @@ def test_per_chain_engine_choices_are_pure_functions_of_the_batch():
     many = torch.cat([torch.zeros(40, dtype=torch.int64), torch.arange(40, 64)])    # 40 x A + 24 singletons: measured slower
     assert D._cone_for_groups(many, 64) == 0 and D._cone_for_groups(torch.arange(64) // 2, 64) == 0
     assert D._cone_for_groups(torch.arange(64) // 6, 64) == 2 and D._cone_for_groups(torch.arange(64) // 4, 64) == 0   # 11 / 16 groups
+    # the test-set driver pins one mode for a whole run, from the complete job list: samples per pocket >= 5 -> on
+    from diffsbdd_amd import testset as ts
+    mk = lambda n: ts.PocketJob("p", [], 100, n)
+    assert ts.cone_mode_for_jobs([mk(100)] * 3) == 2 and ts.cone_mode_for_jobs([mk(4)] * 10) == 0
+    assert ts.cone_mode_for_jobs([mk(2)] * 9 + [mk(40)]) == 2 and ts.cone_mode_for_jobs([]) == 0
+    with pytest.raises(ValueError):
+        ts.make_hip_sampler(None, cone_mode=1)
     # coordinate stages on the 16-edge kernels: C-alpha x 32 (274 -> 548 items: a round saved) yes, full-atom x 64 no
     ca = torch.repeat_interleave(torch.arange(32), 23)
     fa = torch.repeat_interleave(torch.arange(64), 23)
