@@ -195,9 +195,13 @@ class EGNNDynamics(nn.Module):
         in the predicted velocity (eval-mode behaviour of the reference).
 
         Training mode with autograd recording (the training step, lightning_modules.py:337-363): the HIP forward /
-        backward kernel pairs of train_hip.py; everything else -- sampling, validation, any call under no_grad -- the
-        fused HIP inference engine."""
-        if self.training and torch.is_grad_enabled():
+        backward kernel pairs of train_hip.py; so does an eval-mode call whose INPUTS require grad (gradients w.r.t. the
+        state, e.g. guidance).  Everything else -- sampling, validation, any call under no_grad, and eval-mode calls
+        whose only grad-requiring tensors are the parameters (every nn.Module by default) -- runs the fused HIP
+        inference engine and returns tensors without a grad_fn: call .train() to get parameter gradients."""
+        wants_grad = torch.is_grad_enabled() and (self.training or any(
+            isinstance(v, torch.Tensor) and v.requires_grad for v in (xh_atoms, xh_residues, t)))
+        if wants_grad:
             # the training step (SURVEY.md 8f-3): forward AND backward on the HIP kernels (train_hip.py: autograd
             # Functions over csrc/train.h); DSBDD_TRAIN=torch selects round 3's eager torch path (train_path.py, A/B)
             import os

@@ -378,3 +378,11 @@ def test_input_gradients_match_the_torch_path(arch):
     assert rel_err(o_h, o_t) < 1e-5
     assert rel_err(ga_h, ga_t) < 1e-4, rel_err(ga_h, ga_t)
     assert rel_err(gb_h, gb_t) < 1e-4, rel_err(gb_h, gb_t)
+    # eval mode: inputs that require grad still get their gradients (same kernels, same bits); without them the call is
+    # the inference engine and carries no grad_fn (dynamics.py forward docstring)
+    m.eval()
+    o_e, ga_e, gb_e = run()
+    assert torch.equal(ga_e, ga_h) and torch.equal(gb_e, gb_h) and torch.equal(o_e, o_h)
+    o_l, o_p = m(xl.to(dev()), xp.to(dev()), t.to(dev()), ml.to(dev()), mp.to(dev()))
+    assert o_l.grad_fn is None and not o_l.requires_grad
+    assert rel_err(o_l, o_h) < 1e-4
