@@ -589,3 +589,33 @@ def test_oracle_ref_archive_matches_the_reference_sources():
         for f in make_ref.FILES:
             assert hashlib.sha256(z.read(f)).hexdigest() == man["sha256"][f] == \
                 hashlib.sha256(open(os.path.join(make_ref.SRC, f), "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("H,emb", [(64, None), (64, 4), (192, 8)])
+def test_edge_first_layer_relayout_on_cpu(H, emb):
+    """train_hip.EdgeFirstLayer is plain torch (no kernel): the re-layout of an edge MLP's first Linear (egnn_new.py:35,99)
+    and its hand-written backward against autograd over the slicing expression, on the CPU."""
+    from diffsbdd_amd.train_hip import EdgeFirstLayer
+    g = torch.Generator().manual_seed(H + (emb or 0))
+    cols = 2 * H + 2 + (emb or 0)
+    w = (torch.randn(H, cols, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = torch.randn(H, generator=g, dtype=torch.float64).requires_grad_(True)
+    e = torch.randn(3, emb, generator=g, dtype=torch.float64).requires_grad_(True) if emb else None
+    outs = EdgeFirstLayer.apply(w, b, e)
+    gs = [torch.randn(o.shape, generator=g, dtype=torch.float64) for o in outs]
+    torch.autograd.backward(outs, gs)
+    w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    e2 = e.detach().clone().requires_grad_(True) if emb else None
+    ref = (torch.cat((w2[:, :H], w2[:, H:2 * H]), 0), w2[:, 2 * H], w2[:, 2 * H + 1],
+           (b2[None, :] + e2 @ w2[:, 2 * H + 2:].t()) if emb else b2[None, :].expand(3, H))
+    torch.autograd.backward(ref, gs)
+    for o, r in zip(outs, ref):
+        assert torch.allclose(o, r, atol=1e-12)
+    assert torch.allclose(w.grad, w2.grad, atol=1e-12) and torch.allclose(b.grad, b2.grad, atol=1e-12)
+    if emb:
+        assert torch.allclose(e.grad, e2.grad, atol=1e-12)
+    # a missing upstream gradient (an unused output) is a zero gradient, not an error
+    outs = EdgeFirstLayer.apply(w, b, e)
+    w.grad = None
+    outs[0].sum().backward()
+    assert torch.equal(w.grad[:, :2 * H], torch.ones(H, 2 * H, dtype=torch.float64)) and (w.grad[:, 2 * H:] == 0).all()
