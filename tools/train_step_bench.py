@@ -5,7 +5,8 @@ reference's configs train with (configs/crossdock_fullatom_cond.yml:13: 16; cros
 Synthetic batch: the 3rfm pocket x B with the anchored 23-atom ligand pose (diffsbdd_amd/synthetic.py), random-init weights.
 
     python tools/train_step_bench.py [--workload crossdock_fullatom_cond] [--batch 16] [--steps 5]
-Prints one markdown table row per path."""
+Prints one markdown table row per path: the step with a synchronisation after every phase (forward / backward / optimiser
+times) and the same step in a free-running loop (no synchronisation inside: how a training loop runs it)."""
 import argparse
 import os
 import sys
@@ -52,8 +53,8 @@ def main():
     dev = torch.device("cuda:0")
     key = "ca" if "ca_" in a.workload else "fa"
     B = a.batch or (96 if key == "ca" else 16)
-    print(f"| workload | batch | path | ms / training step | forward ms | backward ms | optimiser ms | nodes | edges |")
-    print(f"|---|---|---|---|---|---|---|---|---|")
+    print(f"| workload | batch | path | ms / training step | forward ms | backward ms | optimiser ms | nodes | edges | ms / step, free-running loop |")
+    print(f"|---|---|---|---|---|---|---|---|---|---|")
     for path in a.paths.split(","):
         os.environ["DSBDD_TRAIN"] = path
         model, cfg, dd = build(a.workload, dev)
@@ -78,13 +79,24 @@ def main():
             t3 = time.perf_counter()
             if it >= a.warmup:
                 tf += t1 - t0; tb += t2 - t1; to += t3 - t2
+        # the same step as a training loop runs it: no synchronisation between forward, backward and the optimiser (the
+        # host issues the next phase while the GPU works), batches prepared beforehand, one synchronisation at the end
+        batches = [(S.load_pocket(key, B, dev), S.anchor_ligand(B, 23, cfg["atom_nf"], dev)) for _ in range(a.steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for pocket, ligand in batches:
+            opt.zero_grad(set_to_none=True)
+            loss_of(model(ligand, pocket)).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        t_free = (time.perf_counter() - t0) / a.steps
         n_nodes = int(pocket["mask"].numel() + ligand["mask"].numel())
         with torch.no_grad():
             e = model.dynamics.get_edges(ligand["mask"], pocket["mask"], ligand["x"], pocket["x"])
         n_edges = int(e.shape[1])
         k = 1e3 / a.steps
         print(f"| {a.workload} | {B} | {path} | {(tf + tb + to) * k:.2f} | {tf * k:.2f} | {tb * k:.2f} | {to * k:.2f} | "
-              f"{n_nodes} | {n_edges} |", flush=True)
+              f"{n_nodes} | {n_edges} | {t_free * 1e3:.2f} |", flush=True)
         del model, opt
         torch.cuda.empty_cache()
 
