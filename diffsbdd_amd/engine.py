@@ -130,21 +130,23 @@ def edge_capacity(mask_lig, mask_pocket, batch, check_sorted=True):
     kernels locate a sample's rows by binary search, so the masks must be sorted
     ascending with ids in [0, batch) (the reference's scatter ops would accept any
     order; here it is an error, raised before anything is launched)."""
+    ok = torch.ones((), dtype=torch.bool, device=mask_lig.device)
     if check_sorted:
-        ok = torch.ones((), dtype=torch.bool, device=mask_lig.device)
         for m in (mask_lig, mask_pocket):
             if m.numel() > 1:
                 ok = ok & (m[1:] >= m[:-1]).all()
             if m.numel():
                 ok = ok & (m[0] >= 0) & (m[-1] < batch)
-        if not bool(ok.item()):
-            raise ValueError("batch masks must be sorted ascending with ids in [0, batch): the HIP kernels "
-                             "locate a sample's rows by binary search")
     nl = torch.bincount(mask_lig, minlength=batch).to(torch.int64)
     np_ = torch.bincount(mask_pocket, minlength=batch).to(torch.int64)
     n = nl + np_
     seg = lambda v: (v + 31) // 32 * 32
-    return int((seg(nl * n) + seg(np_ * n)).sum().item())
+    cap = (seg(nl * n) + seg(np_ * n)).sum()
+    ok_h, cap_h = torch.stack((ok.to(torch.int64), cap)).tolist()          # the one host sync
+    if not ok_h:
+        raise ValueError("batch masks must be sorted ascending with ids in [0, batch): the HIP kernels "
+                         "locate a sample's rows by binary search")
+    return int(cap_h)
 
 
 def frame_layout(sizes, representative, mask_pocket):

@@ -40,7 +40,7 @@ def _stream(dev):
 class TrainGraph:
     """Radius graph of one training batch (dynamics.py:169-187) + what the backward kernels need on top of it."""
 
-    def __init__(self, module, mask_atoms, mask_residues, x):
+    def __init__(self, module, mask_atoms, mask_residues, x, batch=None):
         eng_cfg = make_config(**module._hp)  # dsbdd_config (cut-offs); no inference engine is built for a training step
         lib = _lib.load()
         dev = x.device
@@ -49,7 +49,8 @@ class TrainGraph:
         mp = mask_residues.to(device=dev, dtype=torch.int64).contiguous()
         n_l, n_p = ml.numel(), mp.numel()
         N = n_l + n_p
-        batch = int(max(int(ml.max()) if n_l else 0, int(mp.max()) if n_p else 0)) + 1
+        if batch is None:       # (a training step passes it: one t per sample -- two host syncs less)
+            batch = int(max(int(ml.max()) if n_l else 0, int(mp.max()) if n_p else 0)) + 1
         cap = max(edge_capacity(ml, mp, batch), 1)
         i32 = dict(dtype=torch.int32, device=dev)
         self.node_batch = torch.empty(N, **i32)
@@ -473,7 +474,7 @@ def dynamics_forward_hip(m, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
     mask_residues = mask_residues.to(dev, torch.int64)
     n_l = xh_atoms.shape[0]
     x = torch.cat((xh_atoms[:, :nd], xh_residues[:, :nd]), 0).contiguous()
-    g = TrainGraph(m, mask_atoms, mask_residues, x)
+    g = TrainGraph(m, mask_atoms, mask_residues, x, batch=int(t.numel()) if t.numel() > 1 else None)
     h = torch.cat((_mlp2(m.atom_encoder, xh_atoms[:, nd:]), _mlp2(m.residue_encoder, xh_residues[:, nd:])), 0)   # :96-97
     mask = torch.cat((mask_atoms, mask_residues))
     t = t.to(dev, torch.float32)
@@ -518,11 +519,10 @@ def dynamics_forward_hip(m, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
     h = h[:, :-1]                                                                                  # drop the time column
     h_atoms = _mlp2(m.atom_decoder, h[:n_l])
     h_res = _mlp2(m.residue_decoder, h[n_l:])
-    if torch.isnan(vel).any():                                                                     # :155-159
-        if m.training:
-            vel = torch.where(torch.isnan(vel), torch.zeros_like(vel), vel)
-        else:
-            raise ValueError("NaN detected in EGNN output")
+    if m.training:                                                                                 # :155-159
+        vel = torch.where(torch.isnan(vel), torch.zeros_like(vel), vel)     # (unconditionally: no host sync per step)
+    elif torch.isnan(vel).any():
+        raise ValueError("NaN detected in EGNN output")
     if m.update_pocket_coords:                                                                     # :161-164
         vel = vel - SampleMean.apply(vel.contiguous(), g)[g.node_batch.long()]
     return torch.cat((vel[:n_l], h_atoms), 1), torch.cat((vel[n_l:], h_res), 1)
