@@ -460,9 +460,9 @@ class EnVariationalDiffusion(nn.Module):
 
     # ---- loss terms (en_diffusion.py:109-262, 336-469) --------------------------------------
     # Evaluation (eval mode / no_grad: validation_step, likelihood estimates): the network passes run on the HIP
-    # kernels.  Training step (training mode with autograd recording): the network passes go through the
-    # differentiable GPU path of train_path.py and every loss term carries its graph, so `loss.backward()` reaches the
-    # parameters (lightning_modules.py:337-363).
+    # kernels.  Training step (training mode with autograd recording): the network passes go through the autograd
+    # Functions of train_hip.py (HIP forward and backward kernels; DSBDD_TRAIN=torch: the eager path of train_path.py) and
+    # every loss term carries its graph, so `loss.backward()` reaches the parameters (lightning_modules.py:337-363).
     t_int_source = None          # optional callable(batch) -> [B,1] float tensor (tests); default torch.randint
 
     def _draw_t_int(self, batch, device):
