@@ -28,7 +28,7 @@ GCL_NAMES = ["E1_WT", "E1_WD", "E1_WD0", "E1_TAB", "E2_WT", "E2_B", "ATT_W", "AT
              "N1_WT", "N1_B", "N2_WT", "N2_B"]
 EQ_NAMES = ["C1_WT", "C_WD", "C_WD0", "C_TAB", "C_W2T", "C_B2",
             "X_WD", "X_WD0", "X_TAB", "X_W2T", "X_B2", "W3"]
-OPT_PRUNE, OPT_CONE, OPT_GRANULE16 = 0, 1, 2
+OPT_PRUNE, OPT_CONE, OPT_GRANULE16, OPT_EMU = 0, 1, 2, 3
 (BUF_EDGE_ROW, BUF_EDGE_COL, BUF_EDGE_D0, BUF_ROW_PTR, BUF_H, BUF_X, BUF_NODE_BATCH, BUF_DEG,
  BUF_LEVEL, BUF_LEVEL_LIST, BUF_LEVEL_COUNT, BUF_LEVEL_END, BUF_LROW_PTR, BUF_LEDGE_ROW, BUF_LEDGE_COL,
  BUF_LEDGE_D0, BUF_LEVEL_STATS) = range(17)
@@ -88,6 +88,7 @@ SIGNATURES = {
     "dsbdd_engine_last_plan": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dsbdd_engine_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dsbdd_engine_get_option": (C.c_int, [_P, C.c_int]),
     "dsbdd_engine_profile": (C.c_int, [_P, C.c_int, C.c_int]),
     "dsbdd_engine_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "dsbdd_cond_reverse_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
@@ -112,6 +113,7 @@ SIGNATURES = {
     # training-step building blocks (struct arguments are passed by pointer: ctypes.byref / arrays)
     "dsbdd_train_scratch_bytes": (C.c_size_t, [_I32, _I64, _I64]),
     "dsbdd_train_wgrad_scratch_bytes": (C.c_size_t, [_I64, _I64, _I64]),
+    "dsbdd_train_wgrad_plan_bytes": (C.c_size_t, [_I64, _I64, _I64]),
     "dsbdd_train_edge_rev": (C.c_int, [_P, _P, _P]),
     "dsbdd_train_sample_mean": (C.c_int, [_P, _P, _P, _P]),
     "dsbdd_train_gcl_forward": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, C.c_size_t]),

@@ -58,6 +58,9 @@ struct EdgeMlpW {
   const float* W2TP;
   // optional: the lane-grouped copy of the 16-edge-granule kernel (edge_wave16.h), W2TP16[k][16 n + c] = W2T[k][16 c + n]
   const float* W2TP16;
+  // optional: the three bf16 planes of W2T in the operand layout of v_mfma_f32_32x32x16_bf16 (edge_wave.h, emulated
+  // path; pack_w2e_kernel): [H/16 k steps][H/32 column tiles][3 planes][64 lanes][8 bf16] = 6 H^2 bytes
+  const void* W2E;
 };
 
 struct EdgeArgs {

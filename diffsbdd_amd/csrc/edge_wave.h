@@ -43,10 +43,14 @@
 
 namespace dsbdd {
 
-template <int H, int MODE>
+// EMU = 0: exact fp32 (v_mfma_f32_32x32x2_f32).  EMU = 6 / 9: fp32 EMULATED on the bf16 matrix cores -- both operands of
+// the H x H layer split into three bf16 terms (x = hi + mid + lo exactly), 6 (or all 9) partial products per k step on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulators; see "emulated path" below.
+template <int H, int MODE, int EMU = 0>
 struct WaveLayout {
-  static constexpr int BK = 32;
-  static constexpr int B_BUF = BK * H;
+  static constexpr int BK = EMU ? 16 : 32;
+  // emulated path: a K slice holds the three bf16 planes of 16 k x H columns = 96 H bytes = 24 H floats
+  static constexpr int B_BUF = EMU ? 24 * H : BK * H;
   static constexpr int NV = (MODE == MODE_GCL) ? 1 : 2;
   static constexpr int VEC_PER = 7 * H;
   // the per-MLP vectors come first: every in-loop read of them is then `base register + 16-bit immediate`
@@ -119,17 +123,63 @@ __device__ __forceinline__ float reduce16_half_wave(const float (&part)[16], int
   return k1 + dpp_xor1(k1);                                                           // lanes ^ 1: both hold the total
 }
 
-template <int H, int MODE, bool BPERM>
+// ---- emulated path (EMU = 6 / 9): fp32 on the bf16 matrix cores ------------------------------------------------------
+// The fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950 (MI355X_MICROARCH.md), and it runs ON the vector ALUs.  The
+// H x H layer  z2 = a1 W2^T  is therefore also available as
+//     a1 = a_hi + a_mid + a_lo,   W2^T = b_hi + b_mid + b_lo     (bf16 terms, round-to-nearest splits: EXACT, 3 x 8 bits)
+//     z2 ~= sum over k of  a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_mid b_mid + a_lo b_hi   [+ the 3 terms <= 2^-24 |a||b|]
+// every bf16 x bf16 product exact in fp32, accumulated in the fp32 accumulators of v_mfma_f32_32x32x16_bf16: 6 MFMAs of
+// 32 cycles per 16 k instead of 8 MFMAs of 64 cycles -- 2.7 x less matrix time, and the vector ALUs are free beside it.
+// Error (tools/emu_error_study.py, profiles/r5_emu_error.md): not larger than the exact fp32 chain's own rounding error
+// (one rounding per 16-k partial sum instead of one per k).  Lane l of the MFMA supplies A[l & 31][8 (l >> 5) + i] as a
+// bf16x8: the lane still IS edge l & 31 and evaluates its 8 activations of the k step from 32-byte chunks of its P / Q
+// rows.  B: the three planes of W2^T are split ONCE (pack_w2e_kernel) into the MFMA's own operand layout
+//     W2E[k step][column tile c][plane][lane l][i] = plane(W2T[16 ks + 8 (l >> 5) + i][32 c + (l & 31)]),
+// a K slice (96 H bytes) is copied to LDS as it lies, and a lane's operand of (c, plane) is ONE ds_read_b128 at
+// `lane base + immediate` -- 1 KiB contiguous per wave and read, conflict-free.  Same tile walk, same epilogue, same
+// aggregation protocol as the exact path; results differ from it in rounding only (both are <= 1e-4 from the oracle).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_rne_f(float x) {     // nearest bf16 (ties to even) as a float; finite inputs
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xFFFF0000u);
+}
+
+// one thread per (k step, column tile, lane, i): the three bf16 planes of W2T[k][col] in the MFMA B-operand layout
+__global__ __launch_bounds__(256) void pack_w2e_kernel(const float* __restrict__ W2T, unsigned short* __restrict__ out, int H) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * H) return;
+  const int CT = H / 32;
+  const int i = idx & 7, l = (idx >> 3) & 63, c = (idx >> 9) % CT, ks = (idx >> 9) / CT;
+  const int k = 16 * ks + 8 * (l >> 5) + i, col = 32 * c + (l & 31);
+  const float w = W2T[(size_t)k * H + col];
+  const float hi = bf16_rne_f(w), r1 = w - hi, mid = bf16_rne_f(r1), lo = bf16_rne_f(r1 - mid);
+  const size_t base = (((size_t)(ks * CT + c) * 3) * 64 + l) * 8 + i;
+  out[base] = (unsigned short)(__float_as_uint(hi) >> 16);
+  out[base + 512] = (unsigned short)(__float_as_uint(mid) >> 16);
+  out[base + 1024] = (unsigned short)(__float_as_uint(lo) >> 16);
+}
+
+template <int H, int MODE, bool BPERM, int EMU = 0>
 __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
-  using L = WaveLayout<H, MODE>;
+  using L = WaveLayout<H, MODE, EMU>;
   constexpr int BK = L::BK;
   constexpr int CT = H / 32;            // 32-col MFMA tiles per wave (all features)
   constexpr int NK = H / BK;            // K slices per unit
   constexpr int NQ = H / 4;
-  constexpr int BI = BK * NQ / kThreads;   // float4 of a W2^T slice per thread
+  // staging units of a W2^T slice per thread: float4 (exact path; emulated path when the 96 H bytes of a slice split
+  // evenly), else float2
+  constexpr int UNIT = EMU ? (((6 * H) % kThreads == 0) ? 4 : 2) : 4;      // floats per unit
+  constexpr int BI = EMU ? (24 * H) / (kThreads * UNIT) : BK * NQ / kThreads;
+  constexpr int NG = EMU ? CT / 2 : BK / 8;                                // groups of a K step (staging cadence)
   constexpr int BMW = 32, BMB = 128;    // edges per wave / per workgroup
   static_assert(H % 64 == 0 && H <= 256, "hidden_nf must be 64,128,192 or 256");
-  static_assert((BK * NQ) % kThreads == 0, "B slice split");
+  static_assert(EMU || (BK * NQ) % kThreads == 0, "B slice split");
+  static_assert(!EMU || (24 * H) % (kThreads * UNIT) == 0, "emulated B slice split");
+  static_assert(EMU == 0 || EMU == 6 || EMU == 9, "partial products of the emulated path");
+  static_assert(!EMU || !BPERM, "the emulated path has its own B layout");
   // s_setprio 1 around every MFMA cluster: the two workgroups sharing a CU are in different
   // phases, so favouring the wave that has MFMAs ready keeps the matrix pipe fed (+2.7 %)
   constexpr bool SETPRIO = true;
@@ -245,27 +295,29 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // from the slice being read), so a DMA burst costs each wave one exposed L2 round trip per K step.  Plain loads
   // carry no such dependence: quarter g of the next slice is requested at the top of group g and written to LDS one
   // group later (its latency sits behind the 32 MFMAs in between); nobody reads that buffer before the barrier.
-  constexpr int SG = (BI + 3) / 4;                         // staging registers (float4) per thread
-  f32x4 stg[SG];
-  auto stage_lo = [](int g) { return BI * g / 4; };
+  constexpr int SG = EMU ? BI : (BI + 3) / 4;              // staging registers (units) per thread (emulated path: indexed by unit, the two halves of a slice reuse them)
+  typedef float stg_t __attribute__((ext_vector_type(UNIT)));
+  stg_t stg[SG];
+  auto stage_lo = [](int g) { return BI * g / NG; };
   auto stage_load = [&](int q, int ks, int g) {
 #ifdef DSBDD_DIAG_NODMA
     return;
 #endif
-    const char* src = reinterpret_cast<const char*>((bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H);
-    const unsigned toff = (unsigned)t * 16u;
+    const char* src = EMU ? reinterpret_cast<const char*>(p.mlp[qsel + q].W2E) + (size_t)ks * (96 * H)
+                          : reinterpret_cast<const char*>((bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H);
+    const unsigned toff = (unsigned)t * (4u * UNIT);
 #pragma unroll
     for (int i = stage_lo(g); i < stage_lo(g + 1); ++i)
-      stg[i - stage_lo(g)] = *reinterpret_cast<const f32x4*>(src + (size_t)(kThreads * 16 * i) + toff);
+      stg[EMU ? i : i - stage_lo(g)] = *reinterpret_cast<const stg_t*>(src + (size_t)(kThreads * 4 * UNIT * i) + toff);
   };
   auto stage_store = [&](int buf, int g) {
 #ifdef DSBDD_DIAG_NODMA
     return;
 #endif
-    float* dst = sB + buf * L::B_BUF + t * 4;
+    float* dst = sB + buf * L::B_BUF + t * UNIT;
 #pragma unroll
     for (int i = stage_lo(g); i < stage_lo(g + 1); ++i)
-      *reinterpret_cast<f32x4*>(dst + kThreads * 4 * i) = stg[i - stage_lo(g)];
+      *reinterpret_cast<stg_t*>(dst + kThreads * UNIT * i) = stg[EMU ? i : i - stage_lo(g)];
   };
 
   // ---- this lane's edge (current unit) and the prefetched one (next tile) ----------------
@@ -333,7 +385,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   streamB(0, 0, 0);
 #else
 #pragma unroll
-  for (int g = 0; g < 4; ++g) { stage_load(0, 0, g); stage_store(0, g); }
+  for (int g = 0; g < NG; ++g) { stage_load(0, 0, g); stage_store(0, g); }
 #endif
   fetch_idx(cbase + kx);
   fetch_x();
@@ -342,9 +394,13 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   DSBDD_TS();               // mark 1: prologue done (vectors, first W2^T slice, first edge)
   int bslice = 0;           // running slice counter (buffer = bslice & 1)
 
-  const float* Pp = p.mlp[qsel].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + 4 * half;
-  const float* Qp = p.mlp[qsel].Q + (size_t)my_c * p.ldpq + 4 * half;
+  // this lane's k of a step: exact path 8 g + 4 half + i (float4 chunks), emulated path 16 kt + 8 half + i (two float4)
+  constexpr int KH = EMU ? 8 : 4;
+  const float* Pp = p.mlp[qsel].P + (size_t)(my_r < 0 ? 0 : my_r) * p.ldpq + KH * half;
+  const float* Qp = p.mlp[qsel].Q + (size_t)my_c * p.ldpq + KH * half;
   f32x4 pc = ldv4(Pp), qc = ldv4(Qp), pn = pc, qn4 = qc;
+  f32x4 pc1 = pc, qc1 = qc;                                // emulated path: second half of the 8-float chunk
+  if constexpr (EMU != 0) { pc1 = ldv4(Pp + 4); qc1 = ldv4(Qp + 4); }
   float phi0 = 0.f, phi1 = 0.f;
 
   int li = kx, q = 0, next_li = 0, ticket = 0;
@@ -396,10 +452,78 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #ifdef DSBDD_EDGE_DMA
       if (more || !last_unit_k) streamB(sq, sks, (bslice + 1) & 1);
 #endif
+      const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
+      if constexpr (EMU != 0) {
+        // ---- emulated path: one 16-k step = 8 activations per lane, split into three bf16x8, 6 (9) MFMAs per column tile
+        const float* vk = vq + kt * 16 + 8 * half;         // this lane's k = 16 kt + 8 half + i
+        const float* vt = vk + (2 + my_ty) * H;
+        // the next slice in two halves: the first requested here and written after half of the column tiles, the second
+        // requested then and written at the end of the step (each with half a step of MFMAs to arrive)
+        constexpr int NG1 = (NG + 1) / 2;
+#pragma unroll
+        for (int g = 0; g < NG1; ++g) stage_load(sq, sks, g);
+        float av[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x4 pp = hh ? pc1 : pc, qq = hh ? qc1 : qc;
+          const f32x4 wd4 = *reinterpret_cast<const f32x4*>(vk + 4 * hh);
+          const f32x4 wz4 = *reinterpret_cast<const f32x4*>(vk + H + 4 * hh);
+          const f32x4 tb4 = *reinterpret_cast<const f32x4*>(vt + 4 * hh);
+          f32x2 alo = pk_fma(dz, wz4.xy, pk_fma(dd, wd4.xy, pp.xy + qq.xy)) + tb4.xy;   // (the exact path's arithmetic)
+          f32x2 ahi = pk_fma(dz, wz4.zw, pk_fma(dd, wd4.zw, pp.zw + qq.zw)) + tb4.zw;
+          alo = silu2(alo);
+          ahi = silu2(ahi);
+          av[4 * hh] = alo.x; av[4 * hh + 1] = alo.y; av[4 * hh + 2] = ahi.x; av[4 * hh + 3] = ahi.y;
+        }
+        {                                                  // next step's P / Q chunk (its registers are free now);
+          const int kn = more ? 16 * (kt + 1) : 0;         // unconditional, so that the loads in flight are counted exactly
+          pc = ldv4(Pp + kn); pc1 = ldv4(Pp + kn + 4);
+          qc = ldv4(Qp + kn); qc1 = ldv4(Qp + kn + 4);
+        }
+        bf16x8 a_h, a_m, a_l;                              // exact three-way split: v_cvt_pk_bf16_f32 rounds to nearest even
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const __bf16 h1 = (__bf16)av[i];
+          const float r1 = av[i] - (float)h1;
+          const __bf16 m1 = (__bf16)r1;
+          const float r2 = r1 - (float)m1;
+          a_h[i] = h1; a_m[i] = m1; a_l[i] = (__bf16)r2;
+        }
+        const float* bl = sB + (bslice & 1) * L::B_BUF + lane * 4;       // + (c * 3 + plane) * 256 floats
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) {
+          bf16x8 bh[2], bm[2], blo[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float* bc = bl + (2 * cp + u) * 768;
+            bh[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bc));
+            bm[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bc + 256));
+            blo[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bc + 512));
+          }
+          auto mm = [&](const bf16x8& a, const bf16x8 (&b)[2]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              acc[2 * cp + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[2 * cp + u], 0, 0, 0);
+          };
+          if constexpr (EMU == 9) { mm(a_l, blo); mm(a_l, bm); mm(a_m, blo); }
+          mm(a_l, bh); mm(a_m, bm); mm(a_h, blo);          // the small terms first, the leading product last
+          mm(a_m, bh); mm(a_h, bm);
+          mm(a_h, bh);
+          if (NG > 1 && cp == CT / 4 - 1) {                // half way: first half of the slice -> LDS, request the second
+#pragma unroll
+            for (int g = 0; g < NG1; ++g) stage_store((bslice + 1) & 1, g);
+#pragma unroll
+            for (int g = NG1; g < NG; ++g) stage_load(sq, sks, g);
+          }
+        }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int g = (NG > 1 ? NG1 : 0); g < NG; ++g) stage_store((bslice + 1) & 1, g);
+      } else {
       const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
       const float* vk = vq + kt * BK + 4 * half;           // this lane's k = kt*BK + 8g + 4*half + i
       const float* vt = vk + (2 + my_ty) * H;
-      const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
@@ -447,6 +571,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #ifndef DSBDD_EDGE_DMA
       stage_store((bslice + 1) & 1, BK / 8 - 1);
 #endif
+      }   // exact path
       ++bslice;
 #ifdef DSBDD_DIAG_NOBARRIER
       __builtin_amdgcn_s_waitcnt(0x0f70);   // DIAGNOSTIC ONLY (racy): vmcnt(0) without the workgroup barrier
@@ -460,9 +585,10 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     // first P/Q chunk of the NEXT unit: in flight during the epilogue
     if (!last_unit) {
       const int r_n = tile_ends ? nx_r : my_r, c_n = tile_ends ? nx_c : my_c;
-      Pp = p.mlp[qsel + qn].P + (size_t)(r_n < 0 ? 0 : r_n) * p.ldpq + 4 * half;
-      Qp = p.mlp[qsel + qn].Q + (size_t)c_n * p.ldpq + 4 * half;
+      Pp = p.mlp[qsel + qn].P + (size_t)(r_n < 0 ? 0 : r_n) * p.ldpq + KH * half;
+      Qp = p.mlp[qsel + qn].Q + (size_t)c_n * p.ldpq + KH * half;
       pc = ldv4(Pp); qc = ldv4(Qp);
+      if constexpr (EMU != 0) { pc1 = ldv4(Pp + 4); qc1 = ldv4(Qp + 4); }
     }
 
     // ================= wave-private epilogue =================

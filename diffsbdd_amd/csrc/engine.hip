@@ -82,6 +82,9 @@ struct dsbdd_engine {
   unsigned granule16 = 0;               // DSBDD_OPT_GRANULE16: bit g = message stage g, bit 16 + b = coordinate stage of block b
                                         // run on the 16-edge-granule kernels (default: none; DSBDD_GRANULE16=<mask> in the environment)
   bool w2tp16_ready = false;            // their lane-grouped W2^T copies are current
+  int emu = 0;                          // DSBDD_OPT_EMU: 0 = exact fp32 edge kernels (default), 6 / 9 = fp32 emulated on the bf16 matrix
+                                        // cores with 6 / 9 partial products (edge_wave.h, "emulated path"); DSBDD_EMU=<k> in the environment
+  bool w2e_ready = false;               // the bf16 planes of every W2^T are current
   float *trace_h = nullptr, *trace_x = nullptr;
   int n_cu = 256;
   bool w2tp_ready = false;   // lane-grouped W2^T copies in the workspace are current
@@ -176,7 +179,7 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * JP * 4,                                                                           // 18 hout
       (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
       (size_t)NG * 2 * H * 4,                                                                       // 22 pqg (GCL P|Q)
-      (size_t)2 * c.n_layers * (c.inv_sublayers + 2) * H * H * 4,                                  // 23 lane-grouped W2^T copies (32- and 16-edge kernels)
+      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 14 + 4096,                              // 23 lane-grouped W2^T copies (32- and 16-edge kernels: 2 x 4 B) + the bf16 planes of the emulated path (6 B)
       (size_t)2 * T * H * 4, (size_t)2 * T * 2 * 16,                                                // 24 agg_head, 25 xagg_head[2][T][4] (16-edge tiles: 2 T slots)
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4,                       // 26 scan_tmp 27 seg_base 28 tile_ctr
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 29-33 list 2: erow ecol ed0 row_ptr deg
@@ -240,6 +243,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
   if (const char* fk = getenv("DSBDD_FORK")) e->fork_front = atoi(fk) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
+  if (const char* em = getenv("DSBDD_EMU")) { const int v = atoi(em); e->emu = (v == 6 || v == 9) ? v : 0; }
   const char* cn = getenv("DSBDD_CONE");
   if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
   const char* nch = getenv("DSBDD_NODE_CHAIN");
@@ -283,6 +287,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
   e->drop_graphs();
   e->w2tp_ready = false;
   e->w2tp16_ready = false;
+  e->w2e_ready = false;
   e->wchain_ready = false;
   e->h0_pocket_valid = false;
   e->has_weights = true;
@@ -345,6 +350,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->h0_pocket_valid = false;
   e->w2tp_ready = false;
   e->w2tp16_ready = false;
+  e->w2e_ready = false;
   return DSBDD_OK;
 }
 
@@ -440,10 +446,24 @@ int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value) {
     case DSBDD_OPT_PRUNE: e->prune = value ? 1 : 0; break;
     case DSBDD_OPT_CONE: e->cone = value <= 0 ? 0 : (value >= 2 ? 2 : 1); break;   // 0 off, 1 by the cost model, 2 always
     case DSBDD_OPT_GRANULE16: e->granule16 = (unsigned)value; break;               // bit g: message stage g, bit 16 + b: coordinate stage b
+    case DSBDD_OPT_EMU:                                                            // 0 exact fp32; 6 / 9: emulated on the bf16 matrix cores
+      if (value != 0 && value != 6 && value != 9) return fail(DSBDD_ERR_ARG, "DSBDD_OPT_EMU takes 0, 6 or 9");
+      e->emu = value; break;
     default: return fail(DSBDD_ERR_ARG, "unknown option");
   }
   e->drop_graphs();
   return DSBDD_OK;
+}
+
+int dsbdd_engine_get_option(const dsbdd_engine* e, int which) {
+  if (!e) return fail(DSBDD_ERR_ARG, "null argument");
+  switch (which) {
+    case DSBDD_OPT_PRUNE: return e->prune;
+    case DSBDD_OPT_CONE: return e->cone;
+    case DSBDD_OPT_GRANULE16: return (int)e->granule16;
+    case DSBDD_OPT_EMU: return e->emu;
+  }
+  return fail(DSBDD_ERR_ARG, "unknown option");
 }
 
 int dsbdd_engine_set_trace(dsbdd_engine* e, float* th, float* tx) {
@@ -529,6 +549,18 @@ static hipError_t nl_rows(hipStream_t s, const float* A1, int lda1, int K1, cons
 }
 
 template <int H>
+static hipError_t launch_wave_emu_t(hipStream_t s, int mode, const EdgeArgs& a, int grid, int emu) {
+  if (emu == 9) {
+    if (mode == MODE_GCL) hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, false, 9>), dim3(grid), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, false, 9>), dim3(grid), dim3(kThreads), 0, s, a);
+  } else {
+    if (mode == MODE_GCL) hipLaunchKernelGGL((edge_wave_kernel<H, MODE_GCL, false, 6>), dim3(grid), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((edge_wave_kernel<H, MODE_COORD, false, 6>), dim3(grid), dim3(kThreads), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+template <int H>
 static hipError_t launch_wave_t(hipStream_t s, int mode, const EdgeArgs& a, int grid) {
   // lane-grouped W2^T copies present (EdgeMlpW::W2TP): 16-byte B-operand reads
   constexpr bool can_perm = (H == 256 || H == 128);
@@ -586,6 +618,14 @@ static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, co
   const int q8 = split ? 16 : 8;                      // 8 XCDs (x 2 MLPs)
   int grid = (int)((g + q8 - 1) / q8 * q8);
   if (grid < q8) grid = q8;
+  if (e->emu && a.mlp[0].W2E && a.mlp[1].W2E) {   // fp32 emulated on the bf16 matrix cores (engine option, opt-in)
+    switch (H) {
+      case 64: return launch_wave_emu_t<64>(s, mode, a, grid, e->emu);
+      case 128: return launch_wave_emu_t<128>(s, mode, a, grid, e->emu);
+      case 192: return launch_wave_emu_t<192>(s, mode, a, grid, e->emu);
+      case 256: return launch_wave_emu_t<256>(s, mode, a, grid, e->emu);
+    }
+  }
   switch (H) {
     case 64: return launch_wave_t<64>(s, mode, a, grid);
     case 128: return launch_wave_t<128>(s, mode, a, grid);
@@ -858,6 +898,22 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   auto w2tp16_of = [&](int blk, int which) -> const float* {
     return e->granule16 ? e->w2tp + (n_w2 + (size_t)blk * (c.inv_sublayers + 2) + which) * H * H : nullptr;
   };
+  auto w2e_of = [&](int blk, int which) -> const void* {     // bf16 planes behind the two fp32 copies: 6 H^2 bytes each
+    return e->emu ? reinterpret_cast<const char*>(e->w2tp + 2 * n_w2 * H * H) + ((size_t)blk * (c.inv_sublayers + 2) + which) * 6 * H * H
+                  : nullptr;
+  };
+  if (e->emu && !e->w2e_ready) {
+    for (int blk = 0; blk < c.n_layers; ++blk)
+      for (int which = 0; which < c.inv_sublayers + 2; ++which) {
+        const float* src = which < c.inv_sublayers ? W[gcl_slot(c, blk, which, DSBDD_GCL_E2_WT)]
+                         : W[eq_slot(c, blk, which == c.inv_sublayers ? DSBDD_EQ_C_W2T : DSBDD_EQ_X_W2T)];
+        if (!src) continue;
+        hipLaunchKernelGGL(pack_w2e_kernel, dim3((H * H + 255) / 256), dim3(256), 0, s, src,
+                           reinterpret_cast<unsigned short*>(const_cast<void*>(w2e_of(blk, which))), H);
+        HIP_TRY(hipGetLastError());
+      }
+    e->w2e_ready = true;
+  }
   if (e->granule16 && !e->w2tp16_ready) {
     for (int blk = 0; blk < c.n_layers; ++blk)
       for (int which = 0; which < c.inv_sublayers + 2; ++which) {
@@ -959,7 +1015,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.e_cap = L_cap - (int)begin; ea.wt_base = (int)(begin / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
-                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub), w2tp16_of(blk, sub)};
+                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub), w2tp16_of(blk, sub), w2e_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
       // 16-edge-granule variant of this stage (engine option; never for block 0's two-list launch of a framed call)
       const bool g16 = ((e->granule16 >> (g & 15)) & 1u) && !(split0 && blk == 0 && sub == 0);
@@ -1114,11 +1170,12 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.e_cap = L_cap - (int)ghost_slots; ea.wt_base = (int)(ghost_slots / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
-                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers), w2tp16_of(blk, c.inv_sublayers)};
+                           Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers), w2tp16_of(blk, c.inv_sublayers),
+                           w2e_of(blk, c.inv_sublayers)};
       if (n_mlp == 2)
         ea.mlp[1] = EdgeMlpW{e->pq + QW + H, e->pq + H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
                              Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2), w2tp_of(blk, c.inv_sublayers + 1),
-                             w2tp16_of(blk, c.inv_sublayers + 1)};
+                             w2tp16_of(blk, c.inv_sublayers + 1), w2e_of(blk, c.inv_sublayers + 1)};
       else
         ea.mlp[1] = ea.mlp[0];
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
@@ -1294,6 +1351,9 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
                         nullptr, nullptr, 0, eps_lig, eps_pocket, status);
   // second call with the same arguments: capture the sequence, then replay it
   if (!e->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+  // (pack kernels enqueued during a capture have not run if the capture fails: remember what was current before)
+  const bool rdy[4] = {e->w2tp_ready, e->w2tp16_ready, e->w2e_ready, e->wchain_ready};
+  auto restore_ready = [&]() { e->w2tp_ready = rdy[0]; e->w2tp16_ready = rdy[1]; e->w2e_ready = rdy[2]; e->wchain_ready = rdy[3]; };
   HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
   const int rc = forward_impl(e, e->cap_stream, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig,
                               n_pocket, batch, nullptr, nullptr, 0, eps_lig, eps_pocket, status);
@@ -1302,6 +1362,7 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
   if (rc != DSBDD_OK || ec != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);
     e->use_graph = 0;                  // do not try again; fall back to plain launches
+    restore_ready();
     if (rc != DSBDD_OK) return rc;
     return forward_impl(e, s, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig, n_pocket, batch,
                         nullptr, nullptr, 0, eps_lig, eps_pocket, status);
@@ -1310,6 +1371,7 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
   if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
     (void)hipGraphDestroy(graph);
     e->use_graph = 0;
+    restore_ready();
     return forward_impl(e, s, xh_lig, xh_pocket, t, t_count, mask_lig, mask_pocket, n_lig, n_pocket, batch,
                         nullptr, nullptr, 0, eps_lig, eps_pocket, status);
   }
@@ -1546,10 +1608,25 @@ static WgradPlan wgrad_plan(int64_t K, int64_t M, int64_t N) {
   p.floats = (size_t)chunks * M * N + (size_t)((chunks + 31) / 32) * M * N;
   return p;
 }
+// Scratch floats that cover wgrad_plan(K, M, N) for EVERY K <= K_max.  The plan is not monotonic in K (kc is rounded up
+// to a multiple of 32 after the chunk cap, so a smaller K can end with more chunks: K = 160 000 -> 186, K = 30 000 -> 188
+// at 256 x 256), but its chunk count never exceeds min(ceil(K / min_kc), cap), which is.  (the coordinate
+// stage's backward calls wgrad with K = e_upd < E on a scratch sized for E.)
+static size_t wgrad_floats_upto(int64_t K_max, int64_t M, int64_t N) {
+  static const int min_kc = [] { const char* v = getenv("DSBDD_WGRAD_MINKC"); return v && atoi(v) >= 32 ? atoi(v) : 64; }();
+  static const int max_wg = [] { const char* v = getenv("DSBDD_WGRAD_MAXWG"); return v && atoi(v) >= 1 ? atoi(v) : 768; }();
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const int64_t cap = max_wg / tiles > 1 ? max_wg / tiles : 1;
+  int64_t chunks = (K_max + min_kc - 1) / min_kc;
+  if (chunks > cap) chunks = cap;
+  if (chunks < 1) chunks = 1;
+  return (size_t)chunks * M * N + (size_t)((chunks + 31) / 32) * M * N;
+}
 
 static int wgrad_impl(hipStream_t s, const float* A, int lda, const float* B, int ldb, int64_t K, int M, int N, float* C,
-                      float* scratch) {
+                      float* scratch, size_t scratch_floats) {
   const WgradPlan pl = wgrad_plan(K, M, N);
+  if (pl.floats > scratch_floats) return fail(DSBDD_ERR_CAPACITY, "weight-gradient scratch too small for this plan");
   WgradArgs a{A, lda, B, ldb, (int)K, M, N, scratch, pl.kc};
   hipLaunchKernelGGL(wgrad_kernel, dim3((M + 127) / 128, (N + 127) / 128, pl.chunks), dim3(kThreads), 0, s, a);
   HIP_TRY(hipGetLastError());
@@ -1559,7 +1636,7 @@ static int wgrad_impl(hipStream_t s, const float* A, int lda, const float* B, in
 
 struct TrainScratch {
   float *dz2, *a1, *dz1, *partA, *partB, *rtmp, *wg, *gd, *gxr, *gxc, *gm, *agg_head, *xagg, *xagg_head, *vec;
-  size_t bytes;
+  size_t bytes, wg_floats;
 };
 static int train_grid(int64_t E) {
   int64_t tiles = (E + 127) / 128;
@@ -1575,7 +1652,8 @@ static TrainScratch carve_train(char* base, int H, int64_t N, int64_t E) {
   t.dz2 = take(EH); t.a1 = take(EH); t.dz1 = take(EH);
   t.partA = take((size_t)slots * kPartA * H); t.partB = take((size_t)slots * kPartB * H);
   t.rtmp = take((size_t)(slots / 32 + 1) * kPartB * H);
-  t.wg = take(wgrad_plan(E > N ? E : N, H, H).floats);
+  t.wg_floats = wgrad_floats_upto(E > N ? E : N, H, H);   // any K <= max(E, N): the coordinate stage runs on an edge prefix
+  t.wg = take(t.wg_floats);
   t.gd = take(E + 1); t.gxr = take(3 * (size_t)E + 4); t.gxc = take(3 * (size_t)E + 4); t.gm = take(3 * (size_t)E + 4);
   t.agg_head = take((size_t)((E + 31) / 32 + 2) * H);
   t.xagg = take(3 * (size_t)N + 4); t.xagg_head = take(4 * (size_t)((E + 31) / 32 + 2));
@@ -1634,7 +1712,7 @@ static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph*
   HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
   HIP_TRY(reduce_parts(s, ts.partA, slots, (size_t)kPartA * H, kPartA * H, out->d_vec + 5 * (size_t)H, ts.rtmp));
   // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
-  { const int rc = wgrad_impl(s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg); if (rc != DSBDD_OK) return rc; }
+  { const int rc = wgrad_impl(s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg, ts.wg_floats); if (rc != DSBDD_OK) return rc; }
   // B: dz1, partial first-layer vectors, per-edge distance gradients
   a.Bmat = m->W2; a.dz_in = ts.dz2; a.dz_out = ts.dz1; a.part = ts.partB;
   HIP_TRY(launch_bwd_b(H, s, a, grid));
@@ -1656,7 +1734,12 @@ size_t dsbdd_train_scratch_bytes(int32_t H, int64_t n_nodes, int64_t n_edges) {
 
 size_t dsbdd_train_wgrad_scratch_bytes(int64_t K, int64_t M, int64_t N) {
   if (K < 1 || M < 1 || N < 1) return 0;
-  return wgrad_plan(K, M, N).floats * 4;
+  return wgrad_floats_upto(K, M, N) * 4;      // covers every K' <= K (the plan is not monotonic in K)
+}
+
+size_t dsbdd_train_wgrad_plan_bytes(int64_t K, int64_t M, int64_t N) {
+  if (K < 1 || M < 1 || N < 1) return 0;
+  return wgrad_plan(K, M, N).floats * 4;      // what a call with exactly this K writes (tests: <= the bound above)
 }
 
 int dsbdd_train_edge_rev(void* stream, const dsbdd_train_graph* g, int32_t* rev) {
@@ -1799,7 +1882,7 @@ int dsbdd_train_wgrad(void* stream, const float* A, int32_t lda, const float* B,
                       int32_t N, float* C, void* scratch, size_t scratch_bytes) {
   if (!A || !B || !C || K < 1 || M < 1 || N < 1 || lda < M || ldb < N || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
   if (wgrad_plan(K, M, N).floats * 4 > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small");
-  return wgrad_impl(static_cast<hipStream_t>(stream), A, lda, B, ldb, K, M, N, C, static_cast<float*>(scratch));
+  return wgrad_impl(static_cast<hipStream_t>(stream), A, lda, B, ldb, K, M, N, C, static_cast<float*>(scratch), scratch_bytes / 4);
 }
 
 int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int32_t N, float* out, void* scratch,

@@ -634,6 +634,23 @@ class EnVariationalDiffusion(nn.Module):
             return -(-items64 // n_cu) * 0.5 <= 0.8 * -(-items128 // n_cu)
         return (((1 << n_blocks) - 1) << 16) if (pays(lo) and pays(hi)) else 0
 
+    # Arithmetic of the H x H layer of the fused edge kernels (include/diffsbdd_hip.h DSBDD_OPT_EMU; csrc/edge_wave.h,
+    # "emulated path"): None leaves the engine's setting alone (default 0 = exact fp32 MFMA; environment DSBDD_EMU),
+    # 6 / 9 = fp32 emulated on the bf16 matrix cores (three-way bf16 split of both operands, 6 / 9 partial products, fp32
+    # accumulate).  Opt-in; part of a chain's definition like the granule mask (the two paths differ in rounding).
+    edge_emulation = None
+
+    def _apply_engine_option(self, which, value, default_env):
+        """value None = "not set by this module": if an earlier chain of this module wrote the option, restore the
+        engine's default (the environment variable, else 0) -- ADVICE r4: a stale mask must not outlive the attribute."""
+        eng = self.dynamics.engine()
+        if value is None:
+            if which not in getattr(eng, "_options", {}):
+                return
+            env = os.environ.get(default_env)
+            value = int(env, 0) if env not in (None, "") else 0
+        eng.set_option(which, value)
+
     frame_min_pocket_nodes = 128     # pockets smaller than this (C-alpha models) keep the single-list block 0: the
                                      # extra launches of the split cost more than their few pocket-pocket edges
 
@@ -654,6 +671,7 @@ class EnVariationalDiffusion(nn.Module):
         cap = edge_capacity(lm, pm, batch)
         self._chain = (cap,)
         self._framed = False
+        g16 = None
         if self.edge_granule16 is not None:
             if self.edge_granule16 == "auto":
                 hp = self.dynamics._hp
@@ -662,7 +680,12 @@ class EnVariationalDiffusion(nn.Module):
                     if not self.dynamics.update_pocket_coords else 0
             else:
                 g16 = int(self.edge_granule16) & 0xFFFFFFFF
-            self.dynamics.engine().set_option(_lib.OPT_GRANULE16, g16 - (1 << 32) if g16 >= (1 << 31) else g16)
+            g16 = g16 - (1 << 32) if g16 >= (1 << 31) else g16
+        self._apply_engine_option(_lib.OPT_GRANULE16, g16, "DSBDD_GRANULE16")
+        emu = None if self.edge_emulation is None else int(self.edge_emulation)
+        if emu not in (None, 0, 6, 9):
+            raise ValueError("edge_emulation must be None, 0, 6 or 9")
+        self._apply_engine_option(_lib.OPT_EMU, emu, "DSBDD_EMU")
         if pocket is not None and not self.dynamics.update_pocket_coords and pm.numel() > 0 and \
                 int(pocket['size'].min()) >= self.frame_min_pocket_nodes:
             # (the size rule looks at every sample's pocket: in practice a property of the model's pocket

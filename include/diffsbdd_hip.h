@@ -220,9 +220,18 @@ int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghos
  * launches too small to fill the SIMDs a whole number of times): bit g (g < 16) = message stage g (block * inv_sublayers +
  * sublayer), bit 16 + b = the coordinate stage of block b.  Default 0 (environment: DSBDD_GRANULE16=<mask>).  The two
  * variants agree to rounding (< 1e-6 relative measured); each is bitwise reproducible; the mask is never changed by the
- * engine itself. */
-enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1, DSBDD_OPT_GRANULE16 = 2 };
+ * engine itself.
+ * DSBDD_OPT_EMU (round 5; environment DSBDD_EMU): arithmetic of the H x H layer of the fused edge kernels.  0 (default) =
+ * exact fp32 on v_mfma_f32_32x32x2_f32.  6 / 9 = fp32 EMULATED on the bf16 matrix cores: both operands split exactly into
+ * three bf16 terms, the 6 largest (or all 9) partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16
+ * (csrc/edge_wave.h, "emulated path").  Same inputs, same edge order, same aggregation protocol; the results differ from
+ * the exact path in rounding only (error vs a float64 evaluation not larger than the exact path's own:
+ * profiles/r5_emu_error.md) and every parity test of the exact path holds at the same tolerance
+ * (tests/test_gpu_emu.py).  Part of a chain's definition like the granule mask: never changed by the engine. */
+enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1, DSBDD_OPT_GRANULE16 = 2, DSBDD_OPT_EMU = 3 };
 int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value);
+/* current value of an option (what the environment / set_option left); DSBDD_ERR_ARG (< 0) for an unknown id */
+int dsbdd_engine_get_option(const dsbdd_engine* e, int which);
 
 /* Introspection of the last forward (device pointers into the workspace). */
 enum {
@@ -376,7 +385,11 @@ typedef struct dsbdd_train_mlp_grad {
 } dsbdd_train_mlp_grad;
 
 size_t dsbdd_train_scratch_bytes(int32_t H, int64_t n_nodes, int64_t n_edges);
+/* scratch of dsbdd_train_wgrad: enough for every K' <= K (the split-K plan is not monotonic in K, so a scratch sized
+   for an edge count E also serves the calls on an edge prefix); dsbdd_train_wgrad_plan_bytes = what a call with exactly
+   this K uses (never more than the former; a call whose plan does not fit returns DSBDD_ERR_CAPACITY) */
 size_t dsbdd_train_wgrad_scratch_bytes(int64_t K, int64_t M, int64_t N);
+size_t dsbdd_train_wgrad_plan_bytes(int64_t K, int64_t M, int64_t N);
 int dsbdd_train_edge_rev(void* stream, const dsbdd_train_graph* g, int32_t* rev);
 /* mean[b] = mean position of ALL nodes of sample b (coord2cross, egnn_new.py:307-310) */
 int dsbdd_train_sample_mean(void* stream, const float* x, const dsbdd_train_graph* g, float* mean);

@@ -1,0 +1,131 @@
+"""The emulated-fp32 edge kernels (csrc/edge_wave.h "emulated path", DSBDD_OPT_EMU = 6 / 9: both operands of the H x H
+layer split exactly into three bf16 terms, 6 / 9 partial products accumulated in fp32 on v_mfma_f32_32x32x16_bf16) behind
+the gate the round-4 verdict set:
+
+  (1) every existing parity test of the exact path holds UNCHANGED, at the same 1e-4, with the path enabled -- the tests
+      below re-run the other GPU test modules' functions as they are, with DSBDD_EMU=6 in the environment (every engine
+      those tests create then launches the emulated kernels; `DSBDD_EMU=6 pytest tests -m gpu` runs the whole suite that
+      way: profiles/r5_emu_gate_pytest.log);
+  (2) the error against a FLOAT64 evaluation of the reference graph (the oracle in double precision) is at most 2 x the
+      exact fp32 path's own error, on the three BASELINE architectures (H = 256 / 192), per block and on the output.
+
+Tolerances are stated next to each assert.  The exact path stays the default; nothing here changes it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import egnn_oracle as eo
+from oracle import weights as W
+from tests import test_gpu_fullsize as FS
+from tests import test_gpu_parity as GP
+from tests._golden import DYN_CASES
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture
+def emu6(monkeypatch):
+    monkeypatch.setenv("DSBDD_EMU", "6")      # read by dsbdd_engine_create: every engine created from here on emulates
+
+
+def _engine_emulates(model):
+    from diffsbdd_amd import _lib
+    eng = model.engine()
+    return eng.lib.dsbdd_engine_get_option(eng.handle, _lib.OPT_EMU)
+
+
+def test_environment_switch_reaches_the_engine(emu6):
+    cfg, _ = W.arch_cfg("small_cond")
+    m = FS.make_dynamics(cfg, W.random_state_dict(cfg, 0))
+    assert _engine_emulates(m) == 6
+
+
+# ---- (1) the existing parity tests, unchanged, on the emulated path ------------------------------------------------------
+@pytest.mark.parametrize("arch,B,saturated", [("crossdock_fullatom_cond", 64, True), ("moad_fullatom_joint", 64, True),
+                                              ("crossdock_ca_cond", 32, False)])
+def test_emulated_bench_problem_forward_vs_oracle(arch, B, saturated, emu6):
+    FS.test_bench_problem_forward_vs_oracle(arch, B, saturated)                 # eps and per-block h / x <= 1e-4
+
+
+@pytest.mark.parametrize("arch,B,n_steps", [("crossdock_fullatom_cond", 64, 3), ("moad_fullatom_joint", 64, 2),
+                                            ("crossdock_ca_cond", 32, 3)])
+def test_emulated_reverse_steps_teacher_forced(arch, B, n_steps, emu6):
+    FS.test_bench_problem_reverse_steps_teacher_forced(arch, B, n_steps)        # z_s <= 1e-4 per step
+
+
+@pytest.mark.parametrize("B,n_lig,mode,n_steps", [(64, 23, "inpaint", 3), (64, 23, "sample", 2), (3, 14, "inpaint2", 4)])
+def test_emulated_bench_plan_steps_vs_oracle(B, n_lig, mode, n_steps, emu6, monkeypatch):
+    FS.test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps, "32", monkeypatch)
+
+
+def test_emulated_frame_chains_and_ragged_batches(emu6):
+    FS.test_pocket_frame_block0_split_and_shared_pockets()
+    FS.test_full_atom_chains_with_identical_pockets_vs_oracle()
+    FS.test_ligand_only_call_with_ragged_and_empty_samples()
+
+
+@pytest.mark.parametrize("name", DYN_CASES)
+def test_emulated_dynamics_vs_reference_golden(name, emu6):
+    GP.test_dynamics_forward_teacher_forced_edges(name)                         # against the reference-generated vectors
+    GP.test_dynamics_forward_public_api(name)
+
+
+@pytest.mark.parametrize("arch,max_wg", [("small_cond", 0), ("small_variant", 8), ("small_joint", 8)])
+def test_emulated_rows_spanning_many_tiles(arch, max_wg, emu6, monkeypatch):
+    GP.test_rows_spanning_many_tiles(arch, max_wg, "32", monkeypatch)
+
+
+def test_emulated_chains_vs_golden_and_invariances(emu6):
+    GP.test_bitwise_reproducible_and_forced_multi_tile_loop()                   # the emulated path is bitwise reproducible too
+    GP.test_batch_composition_invariance_bitwise()                              # ... and independent of the batch composition
+    for name in ("ddpm_small_cond", "ddpm_small_variant"):
+        GP.test_sample_given_pocket_free_running(name)
+    GP.test_cond_inpaint_and_diversify_vs_golden()
+    GP.test_joint_step_sample_and_inpaint_vs_golden()
+    GP.test_full_size_chain_properties()
+    for arch in ("crossdock_fullatom_cond", "moad_fullatom_joint"):
+        GP.test_se3_equivariance_full_size(arch)
+
+
+# ---- (2) error against float64: not worse than 2 x the exact path's ----------------------------------------------------------
+@pytest.mark.parametrize("arch,B", [("crossdock_fullatom_cond", 8), ("moad_fullatom_joint", 8), ("crossdock_ca_cond", 32)])
+@pytest.mark.parametrize("products", [6, 9])
+def test_error_vs_float64_within_2x_of_the_exact_path(arch, B, products, monkeypatch):
+    """One EGNNDynamics.forward on the benchmark problem, teacher-forced edge list (the device-built one), per-block
+    trace: exact engine, emulated engine, and the oracle evaluated in float64 on the same fp32 inputs and weights."""
+    cfg, dd, xl, xp, t, ml, mp = FS.bench_problem(arch, B)
+    sd = W.random_state_dict(cfg, 0)
+    N = len(ml) + len(mp)
+    outs = {}
+    for emu in (0, products):
+        monkeypatch.setenv("DSBDD_EMU", str(emu))
+        m = FS.make_dynamics(cfg, sd)
+        assert _engine_emulates(m) == emu
+        if emu == 0:
+            m(*[v.to(FS.dev()) for v in (xl, xp, t, ml, mp)])
+            er, ec = m.engine().last_edges(N)
+            edges = torch.stack([er, ec])
+        th, tx = m.engine().set_trace(N)
+        e_l, e_p, status = m.forward_async(xl, xp, t, ml, mp, edges=edges)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        outs[emu] = (e_l.cpu().double(), e_p.cpu().double(), th.cpu().double().clone(), tx.cpu().double().clone())
+        m.engine().clear_trace()
+    with FS.oracle_threads():
+        sd64 = {k: v.double() for k, v in sd.items()}
+        trace = []
+        o_l, o_p, _ = eo.dynamics_forward(sd64, cfg, xl.double(), xp.double(), t.double(), ml, mp, edges=edges, trace=trace)
+    assert o_l.dtype == torch.float64
+
+    def errs(o):
+        e = {"eps": max((o[0] - o_l).abs().max().item(), (o[1] - o_p).abs().max().item())}
+        e["h"] = max(((o[2][i] - h).abs().max() / max(1.0, h.abs().max().item())).item() for i, (h, x) in enumerate(trace))
+        e["x"] = max((o[3][i] - x).abs().max().item() for i, (h, x) in enumerate(trace))
+        return e
+    ex, em = errs(outs[0]), errs(outs[products])
+    print(f"[{arch} B={B}, {products} products] error vs float64 -- exact fp32: {ex}; emulated: {em}; "
+          f"emulated vs exact eps: {(outs[0][0] - outs[products][0]).abs().max().item():.2e}")
+    for k in ex:
+        assert em[k] <= 2.0 * ex[k] + 1e-7, (k, em[k], ex[k])      # <= 2 x the exact path's own error (+ 1e-7 absolute floor)
+        assert em[k] < TOL                                         # and far inside the 1e-4 of the north star

@@ -563,6 +563,15 @@ def test_training_c_abi_argument_errors_and_sizes():
     assert lib.dsbdd_train_wgrad_scratch_bytes(0, 4, 4) == 0
     w = lib.dsbdd_train_wgrad_scratch_bytes(91152, 256, 256)
     assert 256 * 256 * 4 <= w <= 200 * 256 * 256 * 4
+    # the split-K plan is not monotonic in K (K = 30 000 needs more chunks than K = 160 000 at 256 x 256);
+    # the scratch bound must cover every prefix K' <= K -- the coordinate stage's backward runs on an edge prefix
+    assert lib.dsbdd_train_wgrad_plan_bytes(30000, 256, 256) > lib.dsbdd_train_wgrad_plan_bytes(160000, 256, 256)
+    rng = np.random.default_rng(0)
+    for H in (64, 128, 192, 256):
+        for E in [int(v) for v in rng.integers(1, 400000, 40)] + [30857, 160000, 91152]:
+            bound = lib.dsbdd_train_wgrad_scratch_bytes(E, H, H)
+            ks = [int(v) for v in rng.integers(1, E + 1, 60)] + [E, max(1, E // 2), 17228 if E >= 17228 else 1]
+            assert all(lib.dsbdd_train_wgrad_plan_bytes(k, H, H) <= bound for k in ks), (H, E)
     one = ctypes.c_void_p(4096)
     assert lib.dsbdd_train_wgrad(None, None, 4, one, 4, 8, 4, 4, one, one, 1 << 20) == _lib.ERR_ARG
     assert lib.dsbdd_train_wgrad(None, one, 4, one, 4, 8, 4, 4, one, one, 16) == _lib.ERR_CAPACITY
