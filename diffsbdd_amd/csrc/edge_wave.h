@@ -43,6 +43,17 @@
 
 namespace dsbdd {
 
+// scheduling fence between the MFMA groups and the B-operand reads of the emulated path (the compiler otherwise sinks the
+// reads to just in front of their first use and waits for each); -DDSBDD_EMU_NOFENCE: leave the order to the compiler
+#ifndef DSBDD_EMU_FENCE_MASK
+#define DSBDD_EMU_FENCE_MASK 0
+#endif
+#ifdef DSBDD_EMU_NOFENCE
+#define EMU_FENCE() do { } while (0)
+#else
+#define EMU_FENCE() __builtin_amdgcn_sched_barrier(DSBDD_EMU_FENCE_MASK)
+#endif
+
 // EMU = 0: exact fp32 (v_mfma_f32_32x32x2_f32).  EMU = 6 / 9: fp32 EMULATED on the bf16 matrix cores -- both operands of
 // the H x H layer split into three bf16 terms (x = hi + mid + lo exactly), 6 (or all 9) partial products per k step on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulators; see "emulated path" below.
@@ -183,6 +194,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // s_setprio 1 around every MFMA cluster: the two workgroups sharing a CU are in different
   // phases, so favouring the wave that has MFMAs ready keeps the matrix pipe fed (+2.7 %)
   constexpr bool SETPRIO = true;
+#ifdef DSBDD_EMU_NOPRIO
+  constexpr bool SETPRIO_EMU = false;
+#else
+  constexpr bool SETPRIO_EMU = true;
+#endif
+  (void)SETPRIO_EMU;
   // B operand from the lane-grouped W2^T copy (EdgeMlpW::W2TP): lane j finds the values of all its
   // column tiles in CT consecutive words -> one (CT = 4) or two (CT = 8) ds_read_b128 per k step
   // instead of CT/2 ds_read2_b32.  For CT = 8 the two 16-byte halves are read in swapped order by
@@ -403,6 +420,8 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   if constexpr (EMU != 0) { pc1 = ldv4(Pp + 4); qc1 = ldv4(Qp + 4); }
   float phi0 = 0.f, phi1 = 0.f;
 
+  bf16x8 a_h = {}, a_m = {}, a_l = {};                     // emulated path: the current k step's activations (three bf16 planes)
+  (void)a_h; (void)a_m; (void)a_l;
   int li = kx, q = 0, next_li = 0, ticket = 0;
   bool has_next = false;
 #pragma unroll 1
@@ -454,72 +473,118 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #endif
       const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
       if constexpr (EMU != 0) {
-        // ---- emulated path: one 16-k step = 8 activations per lane, split into three bf16x8, 6 (9) MFMAs per column tile
-        const float* vk = vq + kt * 16 + 8 * half;         // this lane's k = 16 kt + 8 half + i
-        const float* vt = vk + (2 + my_ty) * H;
-        // the next slice in two halves: the first requested here and written after half of the column tiles, the second
-        // requested then and written at the end of the step (each with half a step of MFMAs to arrive)
+        // ---- emulated path: one 16-k step = 8 activations per lane, split into three bf16x8, 6 (9) MFMAs per column tile.
+        // Software pipeline of a step (the bf16 MFMAs do not use the vector ALUs, so everything else can hide behind them
+        // -- but only inside ONE wave: the two waves of a SIMD drift into phase, tools/microbench_emu.hip):
+        //   * the B operands of a pair of column tiles are read one pair ahead, plane by plane, into the registers the
+        //     MFMAs just released (lo plane: 1 product, mid: 2, hi: 3 -> the order lo, mid, hi frees them early);
+        //   * the activations of the NEXT step are computed between this step's MFMAs (n_*), from the P / Q chunk that
+        //     was requested one step earlier; the chunk after that is requested as soon as its registers are free;
+        //   * the next W2E slice travels through staging registers in two halves, as before.
         constexpr int NG1 = (NG + 1) / 2;
+        auto act8 = [&](int ks, bf16x8& o_h, bf16x8& o_m, bf16x8& o_l) {       // activations of k step ks from pc / qc
+          const float* vk = vq + ks * 16 + 8 * half;       // this lane's k = 16 ks + 8 half + i
+          const float* vt = vk + (2 + my_ty) * H;
+          float av[8];
+#ifdef DSBDD_DIAG_NOACT
+          {   // DIAGNOSTIC ONLY: no activation arithmetic (the P / Q chunk is consumed with four adds)
+            const f32x4 sm = pc + qc + pc1 + qc1;
+            const unsigned u0 = __float_as_uint(sm.x + sm.y), u1 = __float_as_uint(sm.z + sm.w);
+            const u32x4 w = {u0, u1, u0 ^ u1, u0 + u1};
+            o_h = __builtin_bit_cast(bf16x8, w); o_m = o_h; o_l = o_h;
+            return;
+          }
+#endif
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 pp = hh ? pc1 : pc, qq = hh ? qc1 : qc;
+            const f32x4 wd4 = *reinterpret_cast<const f32x4*>(vk + 4 * hh);
+            const f32x4 wz4 = *reinterpret_cast<const f32x4*>(vk + H + 4 * hh);
+            const f32x4 tb4 = *reinterpret_cast<const f32x4*>(vt + 4 * hh);
+            f32x2 alo = pk_fma(dz, wz4.xy, pk_fma(dd, wd4.xy, pp.xy + qq.xy)) + tb4.xy;   // (the exact path's arithmetic)
+            f32x2 ahi = pk_fma(dz, wz4.zw, pk_fma(dd, wd4.zw, pp.zw + qq.zw)) + tb4.zw;
+            alo = silu2(alo);
+            ahi = silu2(ahi);
+            av[4 * hh] = alo.x; av[4 * hh + 1] = alo.y; av[4 * hh + 2] = ahi.x; av[4 * hh + 3] = ahi.y;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {                    // exact three-way split: v_cvt_pk_bf16_f32 rounds to nearest even
+            const __bf16 h1 = (__bf16)av[i];
+            const float r1 = av[i] - (float)h1;
+            const __bf16 m1 = (__bf16)r1;
+            const float r2 = r1 - (float)m1;
+            o_h[i] = h1; o_m[i] = m1; o_l[i] = (__bf16)r2;
+          }
+        };
+        auto load_pq = [&](int ks) {                       // this lane's P / Q chunk of k step ks (32 bytes of either row)
+#ifdef DSBDD_DIAG_NOGATHER
+          pc = f32x4{0.1f, 0.2f, 0.3f, 0.4f} * (float)ks; pc1 = pc; qc = pc; qc1 = pc; return;   // DIAGNOSTIC ONLY
+#endif
+          pc = ldv4(Pp + 16 * ks); pc1 = ldv4(Pp + 16 * ks + 4);
+          qc = ldv4(Qp + 16 * ks); qc1 = ldv4(Qp + 16 * ks + 4);
+        };
+#ifdef DSBDD_EMU_NOPIPE_A
+        act8(kt, a_h, a_m, a_l);                           // (A/B timing: activations in front of the step's MFMAs)
+        load_pq(more ? kt + 1 : 0);
+#else
+        if (kt == 0) {                                     // first step of a unit: nothing to hide behind
+          act8(0, a_h, a_m, a_l);
+          load_pq(NK > 1 ? 1 : 0);
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < NG1; ++g) stage_load(sq, sks, g);
-        float av[8];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const f32x4 pp = hh ? pc1 : pc, qq = hh ? qc1 : qc;
-          const f32x4 wd4 = *reinterpret_cast<const f32x4*>(vk + 4 * hh);
-          const f32x4 wz4 = *reinterpret_cast<const f32x4*>(vk + H + 4 * hh);
-          const f32x4 tb4 = *reinterpret_cast<const f32x4*>(vt + 4 * hh);
-          f32x2 alo = pk_fma(dz, wz4.xy, pk_fma(dd, wd4.xy, pp.xy + qq.xy)) + tb4.xy;   // (the exact path's arithmetic)
-          f32x2 ahi = pk_fma(dz, wz4.zw, pk_fma(dd, wd4.zw, pp.zw + qq.zw)) + tb4.zw;
-          alo = silu2(alo);
-          ahi = silu2(ahi);
-          av[4 * hh] = alo.x; av[4 * hh + 1] = alo.y; av[4 * hh + 2] = ahi.x; av[4 * hh + 3] = ahi.y;
-        }
-        {                                                  // next step's P / Q chunk (its registers are free now);
-          const int kn = more ? 16 * (kt + 1) : 0;         // unconditional, so that the loads in flight are counted exactly
-          pc = ldv4(Pp + kn); pc1 = ldv4(Pp + kn + 4);
-          qc = ldv4(Qp + kn); qc1 = ldv4(Qp + kn + 4);
-        }
-        bf16x8 a_h, a_m, a_l;                              // exact three-way split: v_cvt_pk_bf16_f32 rounds to nearest even
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const __bf16 h1 = (__bf16)av[i];
-          const float r1 = av[i] - (float)h1;
-          const __bf16 m1 = (__bf16)r1;
-          const float r2 = r1 - (float)m1;
-          a_h[i] = h1; a_m[i] = m1; a_l[i] = (__bf16)r2;
-        }
         const float* bl = sB + (bslice & 1) * L::B_BUF + lane * 4;       // + (c * 3 + plane) * 256 floats
-        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+        bf16x8 bh[2], bm[2], blo[2];
+        auto rdb = [&](int cp, int plane, bf16x8 (&dst)[2]) {
+#ifdef DSBDD_DIAG_NOBREAD
+          dst[0] = plane == 0 ? a_h : a_m; dst[1] = plane == 2 ? a_l : a_h; return;   // DIAGNOSTIC ONLY: no B reads
+#endif
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            dst[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bl + (2 * cp + u) * 768 + plane * 256));
+        };
+        rdb(0, 2, blo); rdb(0, 1, bm); rdb(0, 0, bh);
+#ifndef DSBDD_EMU_NOPIPE_A
+        // next step's activations (the last step of a unit computes step 0's again: no branch inside the pipeline)
+        bf16x8 n_h, n_m, n_l;
+        act8(more ? kt + 1 : 0, n_h, n_m, n_l);
+        load_pq(kt + 2 < NK ? kt + 2 : 0);
+#endif
+#define EMU_MM(a, b) do { _Pragma("unroll") for (int u = 0; u < 2; ++u) \
+          acc[2 * cp + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[2 * cp + u], 0, 0, 0); } while (0)
+        if (SETPRIO_EMU) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int cp = 0; cp < CT / 2; ++cp) {
-          bf16x8 bh[2], bm[2], blo[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const float* bc = bl + (2 * cp + u) * 768;
-            bh[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bc));
-            bm[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bc + 256));
-            blo[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bc + 512));
-          }
-          auto mm = [&](const bf16x8& a, const bf16x8 (&b)[2]) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-              acc[2 * cp + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[2 * cp + u], 0, 0, 0);
-          };
-          if constexpr (EMU == 9) { mm(a_l, blo); mm(a_l, bm); mm(a_m, blo); }
-          mm(a_l, bh); mm(a_m, bm); mm(a_h, blo);          // the small terms first, the leading product last
-          mm(a_m, bh); mm(a_h, bm);
-          mm(a_h, bh);
+          const bool nxt = cp + 1 < CT / 2;
+          if constexpr (EMU == 9) { EMU_MM(a_l, blo); EMU_MM(a_m, blo); }
+          EMU_MM(a_h, blo);
+          EMU_FENCE();
+          if (nxt) rdb(cp + 1, 2, blo);
+          EMU_FENCE();
+          if constexpr (EMU == 9) EMU_MM(a_l, bm);
+          EMU_MM(a_m, bm); EMU_MM(a_h, bm);
+          EMU_FENCE();
+          if (nxt) rdb(cp + 1, 1, bm);
+          EMU_FENCE();
+          EMU_MM(a_l, bh); EMU_MM(a_m, bh); EMU_MM(a_h, bh);           // (the leading product last)
+          EMU_FENCE();
+          if (nxt) rdb(cp + 1, 0, bh);
           if (NG > 1 && cp == CT / 4 - 1) {                // half way: first half of the slice -> LDS, request the second
 #pragma unroll
             for (int g = 0; g < NG1; ++g) stage_store((bslice + 1) & 1, g);
 #pragma unroll
             for (int g = NG1; g < NG; ++g) stage_load(sq, sks, g);
           }
+          EMU_FENCE();
         }
-        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+#undef EMU_MM
+        if (SETPRIO_EMU) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int g = (NG > 1 ? NG1 : 0); g < NG; ++g) stage_store((bslice + 1) & 1, g);
+#ifndef DSBDD_EMU_NOPIPE_A
+        a_h = n_h; a_m = n_m; a_l = n_l;
+#endif
       } else {
       const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
       const float* vk = vq + kt * BK + 4 * half;           // this lane's k = kt*BK + 8g + 4*half + i
