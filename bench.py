@@ -54,8 +54,9 @@ from diffsbdd_amd import sharding, synthetic  # noqa: E402
 from diffsbdd_amd.pocket import prepare_pocket  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / fp32 vector peak
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), no sparsity
 HBM_PEAK_GBPS = 8000.0
-PMC_TRAFFIC_FILE = "r4z_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r5z_pmc_traffic.json"
 METRIC = "sampled ligands/sec (500-step DDPM, fullatom_cond) at 1/2/4/8 MI355X"
 
 WORKLOADS = {
@@ -69,6 +70,10 @@ WORKLOADS = {
 
 
 load_pocket, anchor_ligand = synthetic.load_pocket, synthetic.anchor_ligand
+
+
+def emu_dtype(k):
+    return f"f32-emulated (3 x bf16 split of both operands, fp32 accumulate, {k} partial products)"
 
 
 def build_model(arch, device):
@@ -374,6 +379,15 @@ def main():
                     help="skip the end-to-end CPU run of BASELINE configs[0] (C-alpha, 4 samples, 50 steps)")
     ap.add_argument("--granule16", default=None,
                     help="16-edge-granule edge kernels: 'auto' or a stage bit mask (DSBDD_OPT_GRANULE16); default: off")
+    ap.add_argument("--emulation", type=int, default=0, choices=[0, 6, 9],
+                    help="arithmetic of the main legs' H x H edge layers: 0 (default) exact fp32 MFMA; 6 / 9: fp32 emulated on "
+                         "the bf16 matrix cores (DSBDD_OPT_EMU); `dtype` of the line then says so")
+    ap.add_argument("--no-emulated-leg", action="store_true",
+                    help="skip the separate leg that runs the headline chain with the emulated-fp32 edge kernels")
+    ap.add_argument("--emulated-steps", type=int, default=3, help="timed chains of the emulated leg")
+    ap.add_argument("--dump-ligands", default=None,
+                    help="rank 0 writes the gathered ligands of the LAST timed chain (all_lig [rows, 3 + atom_nf], all_mask = "
+                         "global sample ids) to this .npz (tests: the gathered result of W ranks == W sequential world-1 runs)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
@@ -397,6 +411,8 @@ def main():
     cfg, dd, model = build_model(arch, device)
     if args.granule16 is not None:
         model.edge_granule16 = "auto" if args.granule16 == "auto" else int(args.granule16, 0)
+    if args.emulation:
+        model.edge_emulation = args.emulation
     T = args.timesteps or dd["timesteps"]
     joint = not dd["conditional"]
     n_calls = (sum(model.get_repaint_schedule(2, 1, T)) + 1) if joint else T + 1
@@ -489,6 +505,29 @@ def main():
                  "steps": args.other_steps, "live_levels": eng.level_stats(since=lv1),
                  "_raw": (k_ms, k_n, eng.level_stats(since=lv1), eng.last_plan(), el_o,
                           eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]))}
+    # separate leg: the headline chain with the edge kernels' H x H layer EMULATED on the bf16 matrix cores
+    # (csrc/edge_wave.h "emulated path"; same inputs, same states, same seeds as the main leg's protocol)
+    emulated = None
+    if world == 1 and not args.no_emulated_leg and not args.emulation and args.workload == "crossdock_fullatom_cond":
+        model.edge_emulation = 6
+        chain(400)
+        sync()
+        if not args.no_kernel_timing:
+            eng.profile(args.time_every, max_launches=(args.emulated_steps * n_calls // args.time_every + 2) * per_call)
+        lv2 = eng.level_stats(raw=True)
+        t2 = time.perf_counter()
+        for k in range(args.emulated_steps):
+            chain(401 + k)
+        sync()
+        el_e = time.perf_counter() - t2
+        k_ms, k_n = (eng.profile_read() if not args.no_kernel_timing else (0.0, 0))
+        eng.profile(False, 0)
+        emulated = {"dtype": emu_dtype(6), "states": args.states, "value": B * args.emulated_steps / el_e, "unit": "ligands/s",
+                    "ms_per_step": el_e / args.emulated_steps * 1e3, "steps": args.emulated_steps, "warmup": 1,
+                    "engine_option": "DSBDD_OPT_EMU = %d" % eng.lib.dsbdd_engine_get_option(eng.handle, 3),
+                    "_raw": (k_ms, k_n, eng.level_stats(since=lv2), eng.last_plan(), el_e,
+                             eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]))}
+        model.edge_emulation = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -496,6 +535,15 @@ def main():
 
     n_ligands_total = B * world * args.steps
     assert all_lig.shape[0] == B * world * args.n_lig and torch.isfinite(all_lig).all()
+    # global index of every rank's first sample, as the ranks used it (gathered: the record shows the sharding that ran)
+    offsets = [lo]
+    if world > 1:
+        ot = torch.tensor([lo], dtype=torch.int64, device=red_dev)
+        buf = [torch.zeros_like(ot) for _ in range(world)]
+        torch.distributed.all_gather(buf, ot)
+        offsets = [int(b.item()) for b in buf]
+    if rank == 0 and args.dump_ligands:
+        np.savez(args.dump_ligands, all_lig=all_lig.cpu().numpy(), all_mask=all_mask.cpu().numpy())
 
     if rank == 0:
         N = B * args.n_lig + pocket0["x"].shape[0]
@@ -503,8 +551,10 @@ def main():
         H = cfg["hidden_nf"]
         A = 2 + (cfg.get("edge_embedding_dim") or 0)
 
-        def roofline_of(kern_ms, kern_n, lv, plan, elapsed_s, n_chains, e_last, with_traffic):
-            """The roofline block of one leg: the dominant kernel's timed launches and the whole call."""
+        def roofline_of(kern_ms, kern_n, lv, plan, elapsed_s, n_chains, e_last, with_traffic, emu=0):
+            """The roofline block of one leg: the dominant kernel's timed launches and the whole call.  emu = k: the launches
+            ran the emulated path -- `achieved` / `peak` / `frac` are then the bf16 matrix FLOPs the kernel EXECUTES
+            (k products x 2 E H^2) against the dense bf16 peak; the algorithmic fp32 figure rides along."""
             t_level = plan[2]
             # the timed launches are those of the largest radius of the call's plan (csrc/engine.hip): the rows of
             # level <= t_level, a prefix of the edge list whose mean length the engine accumulated
@@ -519,20 +569,36 @@ def main():
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
             if with_traffic and args.workload == "crossdock_fullatom_cond" and B == 64 and args.states == "anchored" and \
-                    args.pockets == "same" and os.path.isfile(tpath):
+                    args.pockets == "same" and not args.emulation and os.path.isfile(tpath):
                 # PMC counters cannot be read from inside this process; the figure is the one measured
-                # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload
+                # with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same workload (tools/pmc_traffic.sh) --
+                # valid only for the kernel it was measured on: the file carries the hash of the kernel's sources
+                from diffsbdd_amd.build import kernel_source_hash
                 tj = json.load(open(tpath))
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc, gfx950-corrected)"
+                now = kernel_source_hash()
+                if tj.get("kernel_source_sha16") == now:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_src = (f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc, gfx950-corrected), measured on kernel "
+                                   f"sources sha256/16 {now}")
+                else:
+                    traffic_src = (f"stale: profiles/{PMC_TRAFFIC_FILE} was measured on kernel sources "
+                                   f"{tj.get('kernel_source_sha16')}, this build is {now} (re-run tools/pmc_traffic.sh)")
             # algorithmic work of a WHOLE call from what the stages evaluated (mean over the timed chains): SURVEY.md
             # 8d's F_min restricted to the rows / edges of every stage's radius
             call = call_flops(cfg, lv, plan, N, e_last, joint)
             whole = call * n_calls * n_chains / elapsed_s / 1e12 if call else None
+            head = {"bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
+                    "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None}
+            if emu:
+                ex = emu * 2.0 * E_timed * H * H / (avg_ms * 1e-3) / 1e12 if kern_n else None
+                head = {"bound": "mfma", "kernel": f"edge_wave_kernel<H, MODE_GCL, EMU = {emu}> (csrc/edge_wave.h, emulated path)",
+                        "achieved": ex, "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s (bf16 MFMA FLOPs executed: "
+                        f"{emu} partial products x 2 E H^2)", "frac": (ex / BF16_MATRIX_PEAK_TFLOPS) if ex else None,
+                        "algorithmic_fp32_tflops": achieved,
+                        "algorithmic_fp32_vs_exact_peak": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None}
             return {
-                "bound": "mfma", "kernel": "edge_wave_kernel<H, MODE_GCL> (fused GCL edge stage, csrc/edge_wave.h)",
-                "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
+                **head,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms, "timed_launches": kern_n, "edges_per_launch": E_timed,
                 "algorithmic_flops_per_launch": flops_per_launch,
@@ -553,10 +619,16 @@ def main():
                 "hbm_frac_of_8TBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_n else None,
             }
 
-        roofline = roofline_of(kern_ms, kern_n, lv_main, plan_main, elapsed, args.steps, e_main, True)
+        roofline = roofline_of(kern_ms, kern_n, lv_main, plan_main, elapsed, args.steps, e_main, True, emu=args.emulation)
         if other is not None:
             k_ms, k_n, lv_o, plan_o, el_o, e_o = other.pop("_raw")
-            other["roofline"] = roofline_of(k_ms, k_n, lv_o, plan_o, el_o, args.other_steps, e_o, False)
+            other["roofline"] = roofline_of(k_ms, k_n, lv_o, plan_o, el_o, args.other_steps, e_o, False, emu=args.emulation)
+        if emulated is not None:
+            k_ms, k_n, lv_e, plan_e, el_e, e_e = emulated.pop("_raw")
+            emulated["roofline"] = roofline_of(k_ms, k_n, lv_e, plan_e, el_e, args.emulated_steps, e_e, False, emu=6)
+            emulated["vs_exact_value"] = emulated["value"] / (n_ligands_total / elapsed)
+            emulated["gate"] = ("opt-in (ddpm.edge_emulation = 6 / DSBDD_OPT_EMU); every -m gpu parity test holds at 1e-4 with it on, "
+                                "error vs float64 <= 2 x the exact path's: tests/test_gpu_emu.py, profiles/r5_emu_*")
         other_workloads = None
         if world == 1 and not args.no_other_workloads and args.workload == "crossdock_fullatom_cond" and \
                 args.pockets == "same" and args.timesteps is None and args.batch is None:
@@ -575,8 +647,12 @@ def main():
         line = {
             "metric": METRIC, "value": value, "unit": "ligands/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {B} pockets/GPU ({pocket_desc}) x {args.n_lig} ligand atoms, "
+            "scaling": "weak", "vs_baseline": None, "dtype": emu_dtype(args.emulation) if args.emulation else "f32",
+            "data": "synthetic",
+            # (states / pockets / batch first: the driver's record keeps the first 120 characters)
+            "config": {"workload": f"{args.workload} states={'n/a' if joint else args.states}"
+                                   f"{'' if joint or args.states != 'anchored' else ' (inpaint, all atoms known)'} "
+                                   f"pockets={args.pockets} batch={B}/GPU T={T}: ({pocket_desc}) x {args.n_lig} ligand atoms, "
                                    f"T={T} reverse steps" + (" (RePaint, resamplings=2)" if joint else "") +
                                    f" + final decode = {n_calls} EGNN calls per chain" +
                                    ("" if joint else (", ligand states anchored to the forward process of a pose in "
@@ -586,10 +662,12 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T,
                        "nodes_per_gpu": N, "edges_per_call": E, "parallelism": f"dp{world} (pocket sharding)",
                        "weights": "seeded random (diffsbdd_amd/synthetic.py, seed 0)"},
-            "roofline": roofline, "cpu_baseline": cpu, "other_states": other, "other_workloads": other_workloads,
+            "roofline": roofline, "cpu_baseline": cpu, "other_states": other, "emulated": emulated,
+            "other_workloads": other_workloads,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
             "hipgraph": dict(zip(("replays", "captures", "eager_calls"), eng.graph_stats())),
             "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "rank_sample_offsets": offsets,
             "backend": torch.distributed.get_backend() if world > 1 else None,
             "host_cores": os.cpu_count(),
         }

@@ -18,6 +18,17 @@ def deps():
         [os.path.join(ROOT, "include", "diffsbdd_hip.h")]
 
 
+def kernel_source_hash(names=("edge_wave.h", "edge_mlp.h", "common.h")):
+    """sha256 / 16 hex digits of the sources of the dominant kernel (edge_wave_kernel): what a PMC measurement of that
+    kernel is valid for (tools/pmc_traffic.sh stamps it into profiles/<tag>_pmc_traffic.json, bench.py compares)."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(HERE, "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc_path():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.isfile(cand):

@@ -175,8 +175,14 @@ class EGNNDynamics(nn.Module):
             self._plist = list(self.parameters())
         return sum(p._version for p in self._plist)
 
-    def engine(self) -> HipEngine:
+    def engine(self, validate=True) -> HipEngine:
+        """The HIP engine with this module's current weights.  validate=True (every public entry point) compares the
+        parameters' version counters with those the kernel weights were packed from; the reverse steps inside one
+        sampling chain pass False -- the chain validated once at its start (`_begin_chain`), and nobody updates parameters
+        in the middle of a chain (142 counter reads per EGNN call otherwise)."""
         p = self.egnn.embedding.weight
+        if not validate and self._engine is not None and self._engine.device == p.device:
+            return self._engine
         sig = self._param_signature()
         if self._engine is not None and sig != getattr(self, "_engine_sig", sig):
             self._engine = None           # parameters changed since the kernel weights were packed: repack
@@ -225,15 +231,16 @@ class EGNNDynamics(nn.Module):
     @torch.no_grad()
     def forward_async(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues, edges=None,
                       status=None, want_pocket=True, eps_lig=None, batch=None, eps_pocket=None,
-                      edge_cap=None):
+                      edge_cap=None, in_chain=False):
         """Same as forward() but without the host sync: returns
         (eps_atoms, eps_residues, status) where `status` is an int32 device
         word (bit 0: NaN, bit 1: edge overflow).  `edges` ([2,E]) teacher-forces
         the edge list (parity tests).  `edge_cap` = upper bound on the number of
         edges (engine.edge_capacity of these masks): a sampling chain computes it
         once and passes it; without it the bound is recomputed from the mask
-        contents on every call (one host sync) -- never cached by pointer."""
-        eng = self.engine()
+        contents on every call (one host sync) -- never cached by pointer.  `in_chain`: a reverse step of a sampling
+        chain whose start validated the packed weights (see engine())."""
+        eng = self.engine(validate=not in_chain)
         dev = eng.device
         xh_atoms = xh_atoms.to(device=dev, dtype=torch.float32).contiguous()
         xh_residues = xh_residues.to(device=dev, dtype=torch.float32).contiguous()

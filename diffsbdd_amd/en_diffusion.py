@@ -744,7 +744,8 @@ class EnVariationalDiffusion(nn.Module):
         return self.dynamics.forward_async(z_lig, z_pocket, t, lig_mask, pocket_mask, status=status,
                                            want_pocket=want_pocket, batch=batch, eps_lig=eps_l,
                                            eps_pocket=eps_p,
-                                           edge_cap=self._chain[0] if self._chain is not None else None)
+                                           edge_cap=self._chain[0] if self._chain is not None else None,
+                                           in_chain=self._chain is not None)
 
     # ---- joint noise (en_diffusion.py:559-578) ------------------------------------------
     def sample_combined_position_feature_noise(self, lig_indices, pocket_indices):

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import sys
 
 import numpy as np
 import torch
@@ -290,6 +291,8 @@ def main(argv=None):
             relax_iter=(200 if a.relax else 0), resamplings=a.resamplings, jump_length=a.jump_length,
             timesteps=a.timesteps)
     write_sdf(a.outfile, molecules)
+    from .molecules import PROCESS_MOLECULE_COVERAGE
+    print("[generate] " + PROCESS_MOLECULE_COVERAGE, file=sys.stderr)
     print(f"wrote {len(molecules)} molecules to {a.outfile}")
 
 

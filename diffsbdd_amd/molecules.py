@@ -109,6 +109,18 @@ class Molecule:
         return mol
 
 
+# What of the reference's molecule post-processing (analysis/molecule_builder.py:58-214) this package does -- printed by the
+# generation / test-set CLIs and written next to their outputs, so that a run's record says it:
+PROCESS_MOLECULE_COVERAGE = (
+    "molecule post-processing vs the reference (analysis/molecule_builder.py): "
+    "bond perception = the reference's distance-table path (make_mol_edm / get_bond_order_batch, :30-55,101-137: bit-exact, "
+    "GPU kernel) -- NOT its default OpenBabel path (make_mol_openbabel, :58-98: third-party, absent here); "
+    "largest_frag = exact (connected components of the bond graph); "
+    "sanitize = APPROXIMATED by a valence-table + connectivity filter (RDKit's SanitizeMol is absent); "
+    "relax_iter (UFF) = ABSENT (refused); add_hydrogens = ABSENT (the samplers' callers pass False). "
+    "Molecule.to_rdkit() hands the same atoms / bonds to RDKit where it is installed.")
+
+
 def write_sdf(path, molecules, names=None):
     with open(path, "w") as f:
         for k, m in enumerate(molecules):

@@ -10,7 +10,8 @@ so the data-parallel scheme has NO collective on the data path:
   * noise is keyed by the GLOBAL sample index (dsbdd_randn_keyed), so a chain
     does not depend on W;
   * one exchange at the very end: all_gather of the per-rank row counts, then a
-    padded all_gather of the finished ligands (KB-scale: latency bound).
+    padded all_gather of the finished ligands and of their global sample ids
+    (KB-scale: latency bound).
 
 The reference has no multi-GPU sampling path at all.
 """
@@ -68,23 +69,31 @@ def gather_ligands(out_lig: torch.Tensor, lig_mask: torch.Tensor, sample_lo: int
     out_dev = out_lig.device
     dev = out_dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
     out_lig, lig_mask = out_lig.to(dev), lig_mask.to(dev)
-    # row count and feature width of every rank (a rank with an empty shard does not know D)
+    # row count and feature width of every rank (a rank with an empty shard does not know D): one small all_gather,
+    # read back with ONE host sync
     shape = torch.tensor([out_lig.shape[0], out_lig.shape[1] if out_lig.dim() == 2 else 0],
                          dtype=torch.int64, device=dev)
-    shapes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(shapes, shape, group=group)
-    counts = [int(c[0].item()) for c in shapes]
-    D = max(int(c[1].item()) for c in shapes)
+    shapes = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(shapes, shape, group=group) if dist.get_backend(group) == "nccl" else \
+        dist.all_gather(list(shapes.unbind(0)), shape, group=group)
+    table = shapes.tolist()
+    counts = [int(c[0]) for c in table]
+    D = max(int(c[1]) for c in table)
     max_rows = max(max(counts), 1)
-    # one padded payload: [max_rows, D + 1] with the global sample id as last column
-    payload = torch.zeros((max_rows, D + 1), dtype=torch.float64, device=dev)
+    # padded payloads in their own types (fp32 rows as they are, int64 global sample ids): no float64 detour
+    dt = out_lig.dtype if out_lig.dim() == 2 and out_lig.shape[1] == D and out_lig.is_floating_point() else torch.float32
+    rows = torch.zeros((max_rows, D), dtype=dt, device=dev)
+    ids = torch.zeros((max_rows,), dtype=torch.int64, device=dev)
     if out_lig.shape[0]:
-        payload[:out_lig.shape[0], :D] = out_lig.to(torch.float64)
-        payload[:out_lig.shape[0], D] = (lig_mask + sample_lo).to(torch.float64)
-    bufs = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(bufs, payload, group=group)
-    rows = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(out_dev)
-    return rows[:, :D].to(out_lig.dtype), rows[:, D].round().to(torch.int64)
+        rows[:out_lig.shape[0]] = out_lig
+        ids[:out_lig.shape[0]] = lig_mask + sample_lo
+    rbuf = [torch.zeros_like(rows) for _ in range(world)]
+    ibuf = [torch.zeros_like(ids) for _ in range(world)]
+    dist.all_gather(rbuf, rows, group=group)
+    dist.all_gather(ibuf, ids, group=group)
+    all_rows = torch.cat([b[:c] for b, c in zip(rbuf, counts)], dim=0).to(out_dev)
+    all_ids = torch.cat([b[:c] for b, c in zip(ibuf, counts)], dim=0).to(out_dev)
+    return all_rows, all_ids
 
 
 def sample_sharded(sample_fn, n_total: int, group=None, force_collective=False):

@@ -313,6 +313,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--trusted-checkpoint", action="store_true")
     a = ap.parse_args(argv)
+    from .molecules import PROCESS_MOLECULE_COVERAGE
+    print("[testset] " + PROCESS_MOLECULE_COVERAGE, file=sys.stderr)
     if a.relax:
         raise SystemExit("--relax (UFF relaxation) is an RDKit operation (see generate.py)")
     if a.sanitize:
@@ -346,6 +348,9 @@ def main(argv=None):
     order = {j.name: k for k, j in enumerate(jobs)}
     times.sort(key=lambda t: order.get(t[0], 0))
     TestSetDriver.write_outputs(mine, a.outdir, write_sdf, summary=times if rank == 0 else False)
+    if rank == 0:
+        with open(os.path.join(a.outdir, "process_molecule.txt"), "w") as f:
+            f.write(PROCESS_MOLECULE_COVERAGE + "\n")
     if rank == 0 and times:
         secs = [t[1] for t in times]
         mean = sum(secs) / len(secs)

@@ -15,8 +15,9 @@ Third-party modules that are absent from this image get stand-ins here
 do the three reference modules that only wrap those libraries
 (analysis.metrics / docking / visualization).  `constants.py`, `utils.py`,
 `dataset.py` and `lightning_modules.py` are the reference's own files, imported
-from /root/reference (nothing is copied).  /root/reference does not exist on the
-GPU box: only CPU tests that skip without it may import this module.
+from /root/reference (nothing is copied) -- or, where /root/reference does not exist
+(the GPU box), from oracle/_ref/reference_path.zip (oracle/make_ref.py: the same files,
+unmodified, SHA-256 manifest; git-ignored, shipped with the push): `use_archive()`.
 """
 import importlib
 import os
@@ -30,6 +31,28 @@ from . import ref_shim
 
 REF_ROOT = ref_shim.REF_ROOT
 HERE_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def use_archive():
+    """Point this module (and oracle.ref_shim) at oracle/_ref/reference_path.zip when the reference checkout is absent.
+    Returns the root in use, or None when neither exists."""
+    global REF_ROOT
+    from . import make_ref
+    if os.path.isfile(os.path.join(ref_shim.REF_ROOT, "lightning_modules.py")):
+        REF_ROOT = ref_shim.REF_ROOT
+        return REF_ROOT
+    if make_ref.callers_available():
+        REF_ROOT = ref_shim.REF_ROOT = make_ref.ARCHIVE
+        return REF_ROOT
+    return None
+
+
+def example_files(tmpdir):
+    """(3rfm.pdb, 3rfm_B_CFF.sdf) of the reference's example directory as file paths."""
+    if REF_ROOT.endswith(".zip"):
+        from . import make_ref
+        return make_ref.extract_examples(str(tmpdir))
+    return os.path.join(REF_ROOT, "example", "3rfm.pdb"), os.path.join(REF_ROOT, "example", "3rfm_B_CFF.sdf")
 
 
 # ---- a minimal Bio.PDB structure model on top of diffsbdd_amd.pocket's reader -------------------

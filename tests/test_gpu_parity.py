@@ -495,6 +495,56 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert d["value"] > 0 and d["unit"] == "ligands/s" and d["cpu_baseline"] is None
 
 
+def test_bench_eight_ranks_config3_shape_equals_sequential_runs(tmp_path):
+    """BASELINE configs[3] as the driver launches it -- `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`:
+    64 pockets per rank = 512 -- with the eight ranks sharing the one GPU of this box over gloo (RCCL refuses several
+    ranks per device; the one-rank RCCL path is tests/test_gpu_rccl.py).  The JSON line reports 8 ranks and the sample
+    offsets 0, 64, ..., 448; the gathered 512 x 23 rows are BITWISE those of eight sequential world-1 chains (one per
+    shard, same seed, offset = the shard's first global sample id)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dump = str(tmp_path / "lig8.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    T = 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+           "--timesteps", str(T), "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-kernel-timing",
+           "--dump-ligands", dump]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 512 and d["config"]["batch_per_gpu"] == 64
+    assert d["rank_sample_offsets"] == [0, 64, 128, 192, 256, 320, 384, 448]
+    z = np.load(dump)
+    assert z["all_lig"].shape == (512 * 23, 13) and z["all_mask"].shape == (512 * 23,)
+    assert np.array_equal(z["all_mask"], np.repeat(np.arange(512), 23))
+    # eight sequential world-1 chains in this process: bench.py's own protocol (chain(200): seed 200, anchored states)
+    d0 = dev()
+    cfg, dd, model = bench.build_model("crossdock_fullatom_cond", d0)
+    rows = []
+    for r in range(8):
+        model.seed(200, sample_offset=64 * r)
+        pocket = bench.load_pocket("fa", 64, d0)
+        ligand = bench.anchor_ligand(64, 23, cfg["atom_nf"], d0)
+        o_l, _, lmask, _ = model.inpaint(ligand, pocket, torch.ones(64 * 23, device=d0), resamplings=1, timesteps=T)
+        rows.append(o_l.cpu())
+    seq = torch.cat(rows).numpy()
+    assert np.array_equal(seq, z["all_lig"])                                         # bitwise
+
+
 # ---------------------------------------------------------------------------
 # edge cases beyond the goldens (oracle computed on the spot)
 # ---------------------------------------------------------------------------

@@ -592,10 +592,11 @@ def test_oracle_ref_archive_matches_the_reference_sources():
     from oracle import make_ref
     if not os.path.isfile(os.path.join(make_ref.SRC, make_ref.FILES[0])):
         pytest.skip("reference sources not present on this machine")
-    assert make_ref.make(verbose=False) and make_ref.available()
+    assert make_ref.make(verbose=False) and make_ref.available() and make_ref.callers_available()
     with zipfile.ZipFile(make_ref.ARCHIVE) as z:
         man = json.loads(z.read("MANIFEST.json"))
-        for f in make_ref.FILES:
+        assert "MIT" in z.read("LICENSE").decode()[:40]           # the reference's licence travels with the copy
+        for f in make_ref.FILES + make_ref.CALLER_FILES:
             assert hashlib.sha256(z.read(f)).hexdigest() == man["sha256"][f] == \
                 hashlib.sha256(open(os.path.join(make_ref.SRC, f), "rb").read()).hexdigest()
 

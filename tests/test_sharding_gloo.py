@@ -32,22 +32,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, q, width=13):
+def _worker(rank, world, port, n_total, q, width=13, n_fixed=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, lr, w = sharding.init_distributed("gloo")
     assert (r, w) == (rank, world)
-    out, mask = sharding.sample_sharded(fake_sampler(lambda g: 5 + g % 4, width), n_total)
+    out, mask = sharding.sample_sharded(fake_sampler((lambda g: n_fixed) if n_fixed else (lambda g: 5 + g % 4), width), n_total)
     q.put((rank, out.clone(), mask.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_world(world, n_total, width=13):
+def _run_world(world, n_total, width=13, n_fixed=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, width)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, width, n_fixed)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -74,6 +74,21 @@ def test_world2_equals_world1():
     for rank, out, mask in res:          # all_gather: every rank holds the global result
         assert torch.equal(mask, single_mask)
         assert torch.equal(out, single_out)
+
+
+def test_world8_config3_shape_equals_eight_sequential_world1_runs():
+    """BASELINE configs[3]: 512 samples over 8 ranks -- the shards are [0, 64), [64, 128), ... [448, 512), and the padded
+    all_gather returns, on every rank, exactly the rows of 8 sequential world-1 runs (one per shard) in global order."""
+    n_total, world = 512, 8
+    fn = fake_sampler(lambda g: 23)
+    seq = [sharding.gather_ligands(*fn(lo, hi), lo) for lo, hi in (sharding.shard_range(n_total, world, r) for r in range(world))]
+    assert [int(m[0]) for _, m in seq] == [0, 64, 128, 192, 256, 320, 384, 448]
+    ref_out, ref_mask = torch.cat([o for o, _ in seq]), torch.cat([m for _, m in seq])
+    assert ref_out.shape == (512 * 23, 13)
+    res = _run_world(world, n_total, n_fixed=23)
+    assert len(res) == world
+    for rank, out, mask in res:
+        assert torch.equal(mask, ref_mask) and torch.equal(out, ref_out)
 
 
 def test_world2_with_empty_shard():

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-prof}; shift
 export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_$TAG -o p -- python $R/bench.py --timesteps 50 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-leg "$@" > /tmp/prof_$TAG.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_$TAG -o p -- python $R/bench.py --timesteps 50 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-leg --no-emulated-leg "$@" > /tmp/prof_$TAG.log 2>&1)
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 if [ -z "$DB" ]; then echo "no rocpd database"; tail -5 /tmp/prof_$TAG.log; exit 1; fi
 python $R/tools/rocpd_stats.py $DB 30 > $R/gpurun_out/${TAG}_kernel_stats.md
