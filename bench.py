@@ -309,6 +309,63 @@ def secondary_workloads(device, n_lig_atoms):
     return out
 
 
+def training_leg(device, n_lig_atoms, steps=10, warmup=3):
+    """SURVEY.md 8f-3, so that the driver's record holds it: the reference's training step (lightning_modules.py:337-363:
+    `ddpm(ligand, pocket)` -> l2 objective -> `backward()` -> AdamW(amsgrad), :183-185) on crossdock_fullatom_cond at the
+    reference's batch size (configs/crossdock_fullatom_cond.yml:13: 16), forward AND backward on the HIP kernels
+    (diffsbdd_amd/train_hip.py over csrc/train.h), free-running (no synchronisation inside a step), batches resident.
+    Roofline: forward + input-gradient + weight-gradient FLOPs of what the step evaluates (every row in every stage;
+    coordinate MLPs on the ligand-row edges) against the fp32 matrix peak; the recomputation the kernels choose instead of
+    storing [E][H] activations is stated separately and NOT counted."""
+    arch, key, _ = WORKLOADS["crossdock_fullatom_cond"]
+    B = 16
+    cfg, dd, model = build_model(arch, device)
+    model.train(True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, amsgrad=True, weight_decay=1e-12)
+
+    def loss_of(terms):      # the network-dependent terms of the 12-tuple, reduced like lightning_modules.py:262-275
+        return sum(torch.as_tensor(terms[i]).float().mean() for i in (1, 2, 4, 5, 6))
+
+    batches = [(load_pocket(key, B, device), anchor_ligand(B, n_lig_atoms, cfg["atom_nf"], device)) for _ in range(warmup + steps)]
+    for pocket, ligand in batches[:warmup]:
+        opt.zero_grad(set_to_none=True)
+        loss_of(model(ligand, pocket)).backward()
+        opt.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for pocket, ligand in batches[warmup:]:
+        opt.zero_grad(set_to_none=True)
+        loss = loss_of(model(ligand, pocket))
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss)
+    pocket, ligand = load_pocket(key, B, device), anchor_ligand(B, n_lig_atoms, cfg["atom_nf"], device)
+    with torch.no_grad():
+        e = model.dynamics.get_edges(ligand["mask"], pocket["mask"], ligand["x"], pocket["x"])
+    n_l = int(ligand["mask"].numel())
+    N, E, E_u = n_l + int(pocket["mask"].numel()), int(e.shape[1]), int((e[0] < n_l).sum())
+    H, L, S = cfg["hidden_nf"], cfg["n_layers"], cfg["inv_sublayers"]
+    A = 2 + (cfg.get("edge_embedding_dim") or 0)
+    n_mlp = 1 if cfg["reflection_equivariant"] else 2
+    fwd_mac = L * (S * (E * (H * H + (A + 2) * H) + N * (2 * H * H + 3 * H * H)) +
+                   n_mlp * (E_u * (H * H + (A + 1) * H) + N * 2 * H * H)) + 2 * N * (cfg["joint_nf"] + 1) * H
+    flops = 3 * 2.0 * fwd_mac                                   # forward, input gradients, weight gradients
+    recompute = 2.0 * L * (S * E + n_mlp * E_u) * H * H           # the second-layer pre-activations once more (kernel A)
+    tfl = flops / dt / 1e12
+    del model, opt
+    torch.cuda.empty_cache()
+    return {"workload": "training step: crossdock_fullatom_cond", "pockets": "same", "batch": B, "value": B / dt, "unit": "complexes/s",
+            "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32", "nodes": N, "edges": E,
+            "edges_coordinate_stage": E_u, "optimizer": "AdamW(amsgrad)", "call": "ddpm(ligand, pocket) -> l2 terms -> "
+            "backward() -> opt.step() (lightning_modules.py:337-363,183-185), EGNN forward and backward on HIP kernels",
+            "roofline": {"bound": "mfma", "achieved": tfl, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tfl / FP32_MATRIX_PEAK_TFLOPS, "algorithmic_flops_per_step": flops,
+                         "counted": "forward + dgrad + wgrad of every Linear (3 x 2 x forward MAC)",
+                         "recompute_flops_per_step_not_counted": recompute}}
+
+
 def self_launch(n, attempts=3):
     """Re-exec this script under torch.distributed.run with n ranks on this node
     (rendezvous on 127.0.0.1 and a free port); returns the job's exit code.  The port is probed and released before
@@ -633,6 +690,11 @@ def main():
         if world == 1 and not args.no_other_workloads and args.workload == "crossdock_fullatom_cond" and \
                 args.pockets == "same" and args.timesteps is None and args.batch is None:
             other_workloads = secondary_workloads(device, args.n_lig)
+            try:
+                other_workloads.append(training_leg(device, args.n_lig))
+            except Exception as exc:      # the training leg must not cost the benchmark line
+                other_workloads.append({"workload": "training step: crossdock_fullatom_cond", "pockets": "same", "value": None,
+                                        "error": repr(exc)[:300]})
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not joint:
             cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, steps=args.cpu_steps,

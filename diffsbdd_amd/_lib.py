@@ -102,6 +102,8 @@ SIGNATURES = {
     "dsbdd_cond_repaint_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
                                             _I32, _I32, _F, _F, _F, _F, _I32, _I32]),
     "dsbdd_joint_repaint_update": (C.c_int, [_P] * 15 + [_I64, _I64, _I64, _I32, _I32, _F, _F, _F, _F, _I32]),
+    "dsbdd_cond_step_keyed": (C.c_int, [_P] * 10 + [_I64, _I64, _I64, _I32, _I32, _F, _F, _F, _I32, _F, _F, _F, _I32,
+                                        C.c_uint64, C.c_uint64, _I64, _P, _P, _F]),
     "dsbdd_randn_keyed": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _P, C.c_uint64, C.c_uint64,
                                     C.c_uint32]),
     "dsbdd_node_linear": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _P, _P, _I32,

@@ -12,6 +12,8 @@ host synchronisation.
 from __future__ import annotations
 
 import torch
+import ctypes as C
+
 import torch.nn.functional as F
 
 from . import _lib
@@ -101,18 +103,51 @@ class ConditionalDDPM(EnVariationalDiffusion):
         raise NotImplementedError("Conditional model does not support sampling without given pocket.")
 
     # ---- one reverse step (conditional_model.py:432-464) ------------------------------------
-    def _cond_step(self, s, co, z_lig, xh_pocket, lig_mask, pocket_mask, batch, status):
-        """In place: z_lig (level s+1 -> s) and the pocket translation."""
+    fused_step = True    # keyed noise: one launch per reverse step (csrc/ddpm.h cond_step_keyed_kernel); False: the separate
+                         # randn / update / repaint launches (bitwise the same results: tests/test_gpu_parity.py)
+
+    def _cond_step(self, s, co, z_lig, xh_pocket, lig_mask, pocket_mask, batch, status, repaint=None, t_next=None):
+        """In place: z_lig (level s+1 -> s) and the pocket translation.  `repaint` = (zk_tmp, xh0_lig, com_pocket_0,
+        fixed_f, resample): the RePaint iteration behind the step (conditional_model.py:600-660).  `t_next`: the time of
+        the chain's next denoiser call (written by the fused kernel, so that the call needs no fill launch)."""
         eps, _, _ = self._dyn(z_lig, xh_pocket, co.t_value[s + 1], lig_mask, pocket_mask, batch, status,
                               False)
-        noise = self._randn(lig_mask, self.n_dims + self.atom_nf, batch)
         lib = _lib.load()
+        if self.fused_step and self.noise_source is None and lig_mask.numel() > 0:
+            if self._seed is None:
+                self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            ids = getattr(self, "_sample_ids", None)
+            if ids is not None:
+                if ids.numel() != batch:
+                    raise ValueError(f"seed(sample_ids=...) has {ids.numel()} entries for a batch of {batch}")
+                if ids.device != lig_mask.device:
+                    ids = self._sample_ids = ids.to(lig_mask.device).contiguous()
+            zk, xh0, com0, fixed_f, resample = repaint if repaint is not None else (None, None, None, None, False)
+            mode = 0 if repaint is None else (2 if resample else 1)
+            t_word = getattr(self, "_last_t", None) if t_next is not None else None
+            _lib.check(lib.dsbdd_cond_step_keyed(
+                self._cs(z_lig), z_lig.data_ptr(), xh_pocket.data_ptr(), eps.data_ptr(),
+                zk.data_ptr() if zk is not None else None, xh0.data_ptr() if xh0 is not None else None,
+                com0.data_ptr() if com0 is not None else None, fixed_f.data_ptr() if fixed_f is not None else None,
+                lig_mask.data_ptr(), pocket_mask.data_ptr(), lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf,
+                self.residue_nf, float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s]), mode,
+                float(co.alpha[s]), float(co.sigma_t[s]), float(co.sigma_ts[s]), self._remove_com,
+                C.c_uint64(self._seed & (2 ** 64 - 1)), C.c_uint64(self._draw), self._sample_offset,
+                ids.data_ptr() if ids is not None else None,
+                t_word.data_ptr() if t_word is not None else None, float(t_next) if t_next is not None else 0.0),
+                "dsbdd_cond_step_keyed")
+            self._draw += 1 + (0 if repaint is None else (2 if resample else 1))
+            if t_word is not None:
+                self._t_prefilled = (t_word.data_ptr(), float(t_next))
+            return True
+        noise = self._randn(lig_mask, self.n_dims + self.atom_nf, batch)
         _lib.check(lib.dsbdd_cond_reverse_update(
             torch.cuda.current_stream(z_lig.device).cuda_stream, z_lig.data_ptr(), xh_pocket.data_ptr(),
             eps.data_ptr(), noise.data_ptr(), lig_mask.data_ptr(), pocket_mask.data_ptr(),
             lig_mask.numel(), pocket_mask.numel(), batch, self.atom_nf, self.residue_nf,
             float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s]), self._remove_com),
             "dsbdd_cond_reverse_update")
+        return False
 
     def _step_impl(self, s_int, co, z_l, z_p, lig_mask, pocket_mask, batch, status):
         self._cond_step(s_int, co, z_l, z_p, lig_mask, pocket_mask, batch, status)
@@ -182,7 +217,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         co = self._coefs(timesteps)
         for s in reversed(range(0, timesteps)):
-            self._cond_step(s, co, z_lig, xh_pocket, lig_mask, pm, n, status)
+            self._cond_step(s, co, z_lig, xh_pocket, lig_mask, pm, n, status, t_next=co.t_value[s])
             if (s * return_frames) % timesteps == 0:
                 idx = (s * return_frames) // timesteps
                 out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_lig, xh_pocket)
@@ -209,7 +244,10 @@ class ConditionalDDPM(EnVariationalDiffusion):
         (stable pointers: the engine replays its graph): the unknown part takes one reverse step (which moves the
         pocket with the ligand COM), then ONE kernel noises the known part to level s around the moved pocket,
         aligns the COM of the fixed atoms, blends, and (between resamplings) applies q(z_t | z_s)."""
-        self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
+        if self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status,
+                           repaint=(zk_tmp, xh0_lig, com_pocket_0, fixed_f, resample),
+                           t_next=co.t_value[s + 1] if resample else co.t_value[s]):
+            return                                          # (one fused launch did the step and the iteration)
         dl = self.n_dims + self.atom_nf
         n1 = self._randn(lm, dl, n)
         n2 = self._randn(lm, dl, n) if resample else None
@@ -305,7 +343,7 @@ class ConditionalDDPM(EnVariationalDiffusion):
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         co = self._coefs(self.T)
         for s in reversed(range(0, noising_steps)):
-            self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status)
+            self._cond_step(s, co, z_lig, xh_pocket, lm, pm, n, status, t_next=co.t_value[s])
         self._check_status(status)
         x_lig, h_lig, x_pocket, h_pocket = self.sample_p_xh_given_z0(z_lig, xh_pocket, lm, pm, n, _in_chain=True)
         if self._remove_com:

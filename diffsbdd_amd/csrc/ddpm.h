@@ -23,23 +23,68 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 
+// ---- Philox4x32-10 (Salmon et al. 2011) + Box-Muller -----------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// One standard normal: a pure function of (seed, draw_index, stream_id, global sample id, element index inside the sample's
+// [rows][n_cols] block).  randn_keyed_kernel writes these values to memory; the fused step kernel (cond_step_keyed_kernel)
+// evaluates the SAME function in place of the load -- the same bits either way.
+__device__ __forceinline__ float randn_keyed_value(uint64_t seed, uint64_t draw_index, uint32_t stream_id, uint64_t gs,
+                                                   uint32_t elem) {
+  uint32_t ctr[4] = {(uint32_t)gs, elem, (uint32_t)draw_index,
+                     (uint32_t)(draw_index >> 32) ^ (stream_id * 0x9E3779B1u) ^ (uint32_t)(gs >> 32)};
+  philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  // Box-Muller on two 32-bit uniforms; u1 in (0,1]
+  const float u1 = ((float)(ctr[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(ctr[1] >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// noise sources of the per-sample kernels: a tensor [n_lig][dl] (injected noise, separate randn launch) or the keyed
+// generator evaluated in place (o = flat index into the tensor, l0 = first ligand row of the sample)
+struct NoiseTensor {
+  const float* p;
+  __device__ __forceinline__ float operator()(size_t o, int, int) const { return p[o]; }
+};
+struct NoiseKeyed {
+  uint64_t seed, draw; uint64_t gs;
+  __device__ __forceinline__ float operator()(size_t, int row_in_sample, int elem_in_sample) const {
+    (void)row_in_sample;
+    return randn_keyed_value(seed, draw, 0u, gs, (uint32_t)elem_in_sample);
+  }
+};
+
 // z_lig <- z_lig / alpha_ts - c_eps * eps + sigma * noise ; ligand COM removed
 // from ligand x and pocket x (conditional_model.py:688-696).
-__global__ __launch_bounds__(kThreads) void cond_update_kernel(
-    float* z_lig, float* xh_poc, const float* eps, const float* noise, const int64_t* mask_lig,
-    int n_lig, const int64_t* mask_poc, int n_poc, int dl, int dp, float alpha_ts, float c_eps,
-    float sigma, int remove_com) {
-  __shared__ float red[kThreads];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const int l0 = lower_bound_i64(mask_lig, n_lig, b), l1 = lower_bound_i64(mask_lig, n_lig, b + 1);
-  const int p0 = lower_bound_i64(mask_poc, n_poc, b), p1 = lower_bound_i64(mask_poc, n_poc, b + 1);
+template <class Noise>
+__device__ __forceinline__ void cond_update_body(float* z_lig, float* xh_poc, const float* eps, const Noise& noise, int l0, int l1,
+                                                 int p0, int p1, int dl, int dp, float alpha_ts, float c_eps, float sigma,
+                                                 int remove_com, float* red) {
+  const int t = threadIdx.x;
   const int nl = l1 - l0;
   float s[3] = {0.f, 0.f, 0.f};
   for (int idx = t; idx < nl * dl; idx += kThreads) {
     const int i = l0 + idx / dl, c = idx % dl;
     const size_t o = (size_t)i * dl + c;
     // mu = zt / alpha_{t|s} - (sigma^2_{t|s} / alpha_{t|s} / sigma_t) * eps ; zs = mu + sigma * noise
-    const float v = (z_lig[o] / alpha_ts - c_eps * eps[o]) + sigma * noise[o];
+    const float v = (z_lig[o] / alpha_ts - c_eps * eps[o]) + sigma * noise(o, idx / dl, idx);
     z_lig[o] = v;
     if (c < 3) s[c] += v;
   }
@@ -50,6 +95,17 @@ __global__ __launch_bounds__(kThreads) void cond_update_kernel(
   for (int idx = t; idx < nl * 3; idx += kThreads) z_lig[(size_t)(l0 + idx / 3) * dl + idx % 3] -= m[idx % 3];
   for (int idx = t; idx < (p1 - p0) * 3; idx += kThreads)
     xh_poc[(size_t)(p0 + idx / 3) * dp + idx % 3] -= m[idx % 3];
+}
+
+__global__ __launch_bounds__(kThreads) void cond_update_kernel(
+    float* z_lig, float* xh_poc, const float* eps, const float* noise, const int64_t* mask_lig,
+    int n_lig, const int64_t* mask_poc, int n_poc, int dl, int dp, float alpha_ts, float c_eps,
+    float sigma, int remove_com) {
+  __shared__ float red[kThreads];
+  const int b = blockIdx.x;
+  const int l0 = lower_bound_i64(mask_lig, n_lig, b), l1 = lower_bound_i64(mask_lig, n_lig, b + 1);
+  const int p0 = lower_bound_i64(mask_poc, n_poc, b), p1 = lower_bound_i64(mask_poc, n_poc, b + 1);
+  cond_update_body(z_lig, xh_poc, eps, NoiseTensor{noise}, l0, l1, p0, p1, dl, dp, alpha_ts, c_eps, sigma, remove_com, red);
 }
 
 // Joint model: both node sets are denoised, then the COM over ligand+pocket is
@@ -226,10 +282,10 @@ struct CondRepaintArgs {
   int renoise, remove_com;
 };
 
-__global__ __launch_bounds__(kThreads) void cond_repaint_kernel(CondRepaintArgs p) {
-  __shared__ float red[kThreads];
-  const int t = threadIdx.x, b = blockIdx.x, dl = p.dl, dp = p.dp;
-  const SampleRows r = sample_rows(p.mask_lig, p.n_lig, p.mask_poc, p.n_poc, b);
+template <class Noise>
+__device__ __forceinline__ void cond_repaint_body(const CondRepaintArgs& p, const SampleRows& r, int b, const Noise& noise1,
+                                                  const Noise& noise2, float* red) {
+  const int t = threadIdx.x, dl = p.dl, dp = p.dp;
   const int nl = r.l1 - r.l0, np = r.p1 - r.p0;
   float cp[3];
   rows_sum3(p.xh_poc, dp, r.p0, r.p1, nullptr, red, cp);
@@ -242,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void cond_repaint_kernel(CondRepaintArgs 
     const int c = idx % dl;
     const size_t o = (size_t)(r.l0 + idx / dl) * dl + c;
     const float base = c < 3 ? p.xh0_lig[o] + shift[c] : p.xh0_lig[o];
-    const float v = p.alpha_s * base + p.sigma_s * p.noise1[o];
+    const float v = p.alpha_s * base + p.sigma_s * noise1(o, idx / dl, idx);
     p.zk_tmp[o] = v;
     if (c < 3) s[c] += v;
   }
@@ -272,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void cond_repaint_kernel(CondRepaintArgs 
     if (c < 3) zk += dx[c];
     float v = zk * f + p.z_lig[o] * (1.f - f);
     if (p.renoise) {
-      v = p.alpha_ts * v + p.sigma_ts * p.noise2[o];
+      v = p.alpha_ts * v + p.sigma_ts * noise2(o, idx / dl, idx);
       if (c < 3) s2[c] += v;
     }
     p.z_lig[o] = v;
@@ -291,6 +347,41 @@ __global__ __launch_bounds__(kThreads) void cond_repaint_kernel(CondRepaintArgs 
     if (p.renoise && p.remove_com) v -= m2[c];
     *q = v;
   }
+}
+
+__global__ __launch_bounds__(kThreads) void cond_repaint_kernel(CondRepaintArgs p) {
+  __shared__ float red[kThreads];
+  const SampleRows r = sample_rows(p.mask_lig, p.n_lig, p.mask_poc, p.n_poc, blockIdx.x);
+  cond_repaint_body(p, r, blockIdx.x, NoiseTensor{p.noise1}, NoiseTensor{p.noise2}, red);
+}
+
+// ONE launch per reverse step of a pocket-conditioned chain with the keyed generator (round 5): the posterior update
+// (cond_update_body, draw d), optionally the RePaint iteration behind it (cond_repaint_body, draws d + 1 and d + 2), the
+// noise evaluated in place instead of 1 - 3 randn_keyed launches, and the NEXT denoiser call's time written to its device
+// word (instead of a fill launch).  Same arithmetic as the separate kernels: the results are bitwise those.
+struct CondStepArgs {
+  CondRepaintArgs rp;            // (noise1 / noise2 unused; zk_tmp, xh0_lig, com_pocket0, fixed may be null without repaint)
+  const float* eps;
+  float u_alpha_ts, u_c_eps, u_sigma;   // the reverse step's coefficients
+  int repaint;                   // 0: update only
+  uint64_t seed, draw; int64_t sample_offset; const int64_t* sample_ids;
+  float* t_word; float t_next;   // optional
+};
+
+__global__ __launch_bounds__(kThreads) void cond_step_keyed_kernel(CondStepArgs a) {
+  __shared__ float red[kThreads];
+  const int b = blockIdx.x;
+  const CondRepaintArgs& p = a.rp;
+  const SampleRows r = sample_rows(p.mask_lig, p.n_lig, p.mask_poc, p.n_poc, b);
+  const uint64_t gs = (uint64_t)(a.sample_ids ? a.sample_ids[b] : b + a.sample_offset);
+  cond_update_body(p.z_lig, p.xh_poc, a.eps, NoiseKeyed{a.seed, a.draw, gs}, r.l0, r.l1, r.p0, r.p1, p.dl, p.dp, a.u_alpha_ts,
+                   a.u_c_eps, a.u_sigma, p.remove_com, red);
+  if (a.repaint) {
+    __threadfence_block();
+    __syncthreads();             // the sample's rows of z_lig / xh_poc written above are read by other threads below
+    cond_repaint_body(p, r, b, NoiseKeyed{a.seed, a.draw + 1, gs}, NoiseKeyed{a.seed, a.draw + 2, gs}, red);
+  }
+  if (a.t_word && b == 0 && threadIdx.x == 0) *a.t_word = a.t_next;
 }
 
 // One RePaint iteration of the joint model after the reverse step (en_diffusion.py:742-809):
@@ -383,26 +474,6 @@ __global__ __launch_bounds__(kThreads) void joint_repaint_kernel(JointRepaintArg
   for (int idx = t; idx < np * 3; idx += kThreads) p.z_poc[(size_t)(r.p0 + idx / 3) * dp + idx % 3] -= m[idx % 3];
 }
 
-// ---- Philox4x32-10 (Salmon et al. 2011) + Box-Muller -----------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  const uint32_t n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
-
 // out[i][c] ~ N(0,1), a pure function of (seed, draw_index, stream_id, global
 // sample id, row within sample, column).
 __global__ void randn_keyed_kernel(float* out, const int64_t* mask, int n_rows, int n_cols,
@@ -415,13 +486,7 @@ __global__ void randn_keyed_kernel(float* out, const int64_t* mask, int n_rows, 
   const int first = lower_bound_i64(mask, n_rows, b);
   // global sample id: an explicit table (batches packed from several pockets) or offset + local id
   const uint64_t gs = (uint64_t)(sample_ids ? sample_ids[b] : b + sample_offset);
-  uint32_t ctr[4] = {(uint32_t)gs, (uint32_t)((i - first) * n_cols + c), (uint32_t)draw_index,
-                     (uint32_t)(draw_index >> 32) ^ (stream_id * 0x9E3779B1u) ^ (uint32_t)(gs >> 32)};
-  philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-  // Box-Muller on two 32-bit uniforms; u1 in (0,1]
-  const float u1 = ((float)(ctr[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-  const float u2 = (float)(ctr[1] >> 8) * (1.0f / 16777216.0f);
-  out[idx] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+  out[idx] = randn_keyed_value(seed, draw_index, stream_id, gs, (uint32_t)((i - first) * n_cols + c));
 }
 
 }  // namespace dsbdd

@@ -1465,6 +1465,27 @@ int dsbdd_cond_repaint_update(void* stream, float* z_lig, float* xh_pocket, floa
   return DSBDD_OK;
 }
 
+int dsbdd_cond_step_keyed(void* stream, float* z_lig, float* xh_pocket, const float* eps_lig, float* scratch_lig,
+                          const float* xh0_lig, const float* com_pocket0, const float* fixed, const int64_t* mask_lig,
+                          const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
+                          int32_t residue_nf, float alpha_ts, float c_eps, float sigma, int32_t repaint, float alpha_s,
+                          float sigma_s, float sigma_ts, int32_t remove_com, uint64_t seed, uint64_t draw_index,
+                          int64_t sample_offset, const int64_t* sample_ids, float* t_word, float t_next) {
+  if (!z_lig || !xh_pocket || !eps_lig || !mask_lig || !mask_pocket || batch < 1 || repaint < 0 || repaint > 2 ||
+      (repaint && (!scratch_lig || !xh0_lig || !com_pocket0 || !fixed)))
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  CondStepArgs a{};
+  a.rp = CondRepaintArgs{z_lig, xh_pocket, scratch_lig, xh0_lig, com_pocket0, fixed, nullptr, nullptr, mask_lig, mask_pocket,
+                         (int)n_lig, (int)n_pocket, 3 + atom_nf, 3 + residue_nf, alpha_s, sigma_s, alpha_ts, sigma_ts,
+                         repaint == 2, remove_com};
+  a.eps = eps_lig; a.u_alpha_ts = alpha_ts; a.u_c_eps = c_eps; a.u_sigma = sigma; a.repaint = repaint;
+  a.seed = seed; a.draw = draw_index; a.sample_offset = sample_offset; a.sample_ids = sample_ids;
+  a.t_word = t_word; a.t_next = t_next;
+  hipLaunchKernelGGL(cond_step_keyed_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
 int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, float* scratch_lig,
                                float* scratch_pocket, const float* xh0_lig, const float* xh0_pocket,
                                const float* fixed_lig, const float* fixed_pocket, const float* noise_known_lig,

@@ -740,7 +740,11 @@ class EnVariationalDiffusion(nn.Module):
                    torch.empty_like(z_lig), torch.empty_like(z_pocket) if want_pocket else None)
             self._dyn_bufs[key] = buf
         t, eps_l, eps_p = buf
-        t.fill_(float(t_value))
+        pre = getattr(self, "_t_prefilled", None)
+        if pre != (t.data_ptr(), float(t_value)):        # (the previous step's fused kernel may have written it already)
+            t.fill_(float(t_value))
+        self._t_prefilled = None
+        self._last_t = t
         return self.dynamics.forward_async(z_lig, z_pocket, t, lig_mask, pocket_mask, status=status,
                                            want_pocket=want_pocket, batch=batch, eps_lig=eps_l,
                                            eps_pocket=eps_p,

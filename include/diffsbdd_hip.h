@@ -311,6 +311,20 @@ int dsbdd_cond_repaint_update(void* stream, float* z_lig, float* xh_pocket, floa
                               int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
                               float alpha_ts, float sigma_ts, int32_t resample, int32_t remove_com);
 
+/* One launch per reverse step of a pocket-conditioned chain drawn from the keyed generator (round 5; replaces
+ * dsbdd_randn_keyed x 1-3 + dsbdd_cond_reverse_update [+ dsbdd_cond_repaint_update] + the fill of the denoiser's time
+ * word): the posterior update of conditional_model.py:448-464 with the noise of draw `draw_index` evaluated in place;
+ * repaint = 1: followed by the RePaint iteration of :600-660 (known part noised with draw + 1), 2: and the q(z_t | z_s)
+ * jump (draw + 2).  alpha_ts / sigma_ts are shared by the update and the jump (the same step); alpha_s / sigma_s noise
+ * the known part.  t_word (optional): device float that receives t_next at the end -- the `t` of the NEXT
+ * dsbdd_dynamics_forward call.  Results are bitwise those of the separate entry points on dsbdd_randn_keyed's output. */
+int dsbdd_cond_step_keyed(void* stream, float* z_lig, float* xh_pocket, const float* eps_lig, float* scratch_lig,
+                          const float* xh0_lig, const float* com_pocket0, const float* fixed, const int64_t* mask_lig,
+                          const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
+                          int32_t residue_nf, float alpha_ts, float c_eps, float sigma, int32_t repaint, float alpha_s,
+                          float sigma_s, float sigma_ts, int32_t remove_com, uint64_t seed, uint64_t draw_index,
+                          int64_t sample_offset, const int64_t* sample_ids, float* t_word, float t_next);
+
 /* One RePaint iteration of EnVariationalDiffusion.inpaint after the reverse step
  * (en_diffusion.py:742-809): known part q(z_s | x) with COM-centred noise, COM alignment over the
  * fixed ligand + pocket nodes, blend, optional jump back q(z_t | z_s) + joint COM removal. */

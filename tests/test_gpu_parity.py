@@ -346,6 +346,45 @@ def test_cond_inpaint_and_diversify_vs_golden():
     assert torch.equal(d_l.cpu()[:, 3:].long(), c.t("div_lig")[:, 3:].long())
 
 
+def test_fused_keyed_step_is_bitwise_the_separate_launches():
+    """csrc/ddpm.h cond_step_keyed_kernel (one launch per reverse step: keyed noise evaluated in place + posterior update
+    [+ RePaint iteration + q(z_t | z_s) jump] + the next call's time word) against the separate launches it replaces
+    (dsbdd_randn_keyed x 1-3, dsbdd_cond_reverse_update, dsbdd_cond_repaint_update, fill): the same chains, the same
+    seed -- torch.equal on everything returned, for sample_given_pocket, inpaint (resamplings 1 and 3, some atoms fixed)
+    and diversify, with ragged ligand sizes; and the fused kernel against the ORACLE on its own draws."""
+    c = Case("ddpm_small_cond_inpaint")
+    outs = {}
+    for fused in (True, False):
+        model = make_ddpm(c)
+        model.fused_step = fused
+        res = []
+        model.seed(77)
+        res += list(model.sample_given_pocket(c.pocket(), c.pocket("ligand_")["size"], timesteps=12))
+        for r in (1, 3):
+            model.seed(78 + r)
+            res += list(model.inpaint(c.pocket("ligand_"), c.pocket(), c.t("lig_fixed"), resamplings=r, timesteps=8))
+        model.seed(90)
+        res += list(model.diversify(c.pocket("ligand_"), c.pocket(), 5))
+        torch.cuda.synchronize()
+        outs[fused] = [t.clone() for t in res]
+    assert len(outs[True]) == len(outs[False]) == 16
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    # the fused path against the oracle, the oracle drawing the same keyed noise (dsbdd_randn_keyed) draw by draw
+    from tests.test_testset import _KeyedNoise
+    model = make_ddpm(c)
+    model.seed(5)
+    sizes = c.pocket("ligand_")["size"]
+    n = len(sizes)
+    o_l, o_p, lm, pm = model.sample_given_pocket(c.pocket(), sizes, timesteps=6)
+    om = do.OracleModel(c.state_dict(), c.cfg, c.cfg["atom_nf"], c.cfg["residue_nf"], c.ddpm["timesteps"],
+                        c.ddpm["noise_schedule"], c.ddpm["noise_precision"], norm_values=c.ddpm["norm_values"], conditional=True)
+    noise = _KeyedNoise(5, torch.arange(n), torch.repeat_interleave(torch.arange(n), sizes), dev())
+    r_l, r_p, _, _ = do.cond_sample_given_pocket(om, c.pocket(), sizes, noise, timesteps=6)
+    assert (o_l.cpu()[:, :3] - r_l[:, :3]).abs().max().item() < 1e-3
+    assert torch.equal(o_l.cpu()[:, 3:].long(), r_l[:, 3:].long())
+
+
 def test_joint_step_sample_and_inpaint_vs_golden():
     c = Case("ddpm_small_joint")
     model = make_ddpm(c)

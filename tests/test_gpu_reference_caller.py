@@ -111,8 +111,13 @@ def test_reference_generate_ligands_runs_the_hip_samplers(lm, example, name, n, 
     worst = 0.0
     for k, (pos, types_) in enumerate(mols):                                       # what build_molecule was handed
         hi = lo + int(n_lig[k])
-        assert torch.equal(types_.cpu(), t_ref[lo:hi]), (name, k)
-        worst = max(worst, (pos.cpu() - x_ref[lo:hi]).abs().max().item())
+        # the reference's utils.batch_to_list (utils.py:131-143) orders the rows by an UNSTABLE argsort of the mask: the
+        # atoms of a molecule may come permuted (positions and types by the same permutation) -- match them by position
+        d = (pos.cpu()[:, None, :] - x_ref[lo:hi][None, :, :]).abs().amax(-1)          # [ours, oracle]
+        match = d.argmin(1)
+        assert sorted(match.tolist()) == list(range(hi - lo)), (name, k, match.tolist())   # a permutation
+        assert torch.equal(types_.cpu(), t_ref[lo:hi][match]), (name, k)
+        worst = max(worst, d.gather(1, match[:, None]).max().item())
         lo = hi
     print(f"[{name}] reference generate_ligands on the HIP samplers: {n} molecules, T = {T}, max |x - oracle| = {worst:.2e}")
     assert worst < 1e-3, worst
