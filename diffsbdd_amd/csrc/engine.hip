@@ -97,6 +97,8 @@ struct dsbdd_engine {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int level_rows = 0;  // DSBDD_LEVEL_ROWS=1: all-row stages of a pruned call walk the level list (measured slower, see rows_of)
+  int fold_scan = 1;   // DSBDD_FOLD_SCAN=0: the single-workgroup scan_kernel / level_scan_kernel launches between the passes of the
+                       // radius graph and of the level ordering (round 5: folded into the fill / place kernels, graph.h)
   int lig_head = 1;    // DSBDD_LIG_HEAD=0: embedding_out / decoder / finalize as three launches also for ligand-only calls
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
@@ -205,7 +207,7 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
                             int* act_flag = nullptr, int* scan_tmp = nullptr, int* seg_base = nullptr,
-                            const EdgeList2* list2 = nullptr, int id_offset = 0, int* lvl = nullptr);
+                            const EdgeList2* list2 = nullptr, int id_offset = 0, int* lvl = nullptr, bool fold = false);
 
 extern "C" {
 
@@ -240,6 +242,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
   if (const char* lh = getenv("DSBDD_LIG_HEAD")) e->lig_head = atoi(lh) != 0;
+  if (const char* fs = getenv("DSBDD_FOLD_SCAN")) e->fold_scan = atoi(fs) != 0;
   if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
   if (const char* fk = getenv("DSBDD_FORK")) e->fork_front = atoi(fk) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
@@ -644,7 +647,7 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
                             int* act_flag, int* scan_tmp, int* seg_base, const EdgeList2* list2, int id_offset,
-                            int* lvl) {
+                            int* lvl, bool fold) {
   const int waves_per_block = kThreads / 64;
   int blocks = (N + waves_per_block - 1) / waves_per_block;
   if (blocks > 4096) blocks = 4096;
@@ -653,16 +656,24 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   // with scan_tmp / seg_base: every (sample, node set) segment of the edge list starts at a wave-tile
   // boundary (graph.h scan_kernel); without: a compact list (the public dsbdd_build_edges)
   const int aligned = scan_tmp && seg_base;
-  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, aligned ? seg_base : nullptr};
+  // fold (aligned lists of a forward call): seg_base holds the segments' raw totals, zeroed by prep_assemble_kernel and
+  // accumulated by the count pass; the fill pass computes every row's position itself -- no scan_kernel launch
+  fold = fold && aligned;
+  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, (aligned && !fold) ? seg_base : nullptr, fold ? seg_base : nullptr};
   EdgeList2 l2{};
-  if (list2 && aligned) l2 = *list2;
+  if (list2 && aligned) {
+    l2 = *list2;
+    if (fold) { l2.seg.seg_tot = l2.seg.seg_base; l2.seg.seg_base = nullptr; }
+  }
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr, l2, 0, lvl);
+                     (float*)nullptr, 0, status, act_flag, fold ? sg : SegAlign{}, (int*)nullptr, l2, 0, lvl);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg,
-                     (const int*)l2.deg, l2.row_ptr, l2.seg);
-  HIP_TRY(hipGetLastError());
+  if (!fold) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg,
+                       (const int*)l2.deg, l2.row_ptr, l2.seg);
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
                      (int*)nullptr, sg, row_ptr, l2, id_offset, (int*)nullptr);
@@ -744,10 +755,13 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   }
   // ---- masks -> offsets, split inputs ---------------------------------------
   {
-    const int work = N > B + 1 ? N : B + 1;
+    int work = N > B + 1 ? N : B + 1;
+    if (work < 2 * B) work = 2 * B;
+    const bool fold = e->fold_scan && !ext;
     hipLaunchKernelGGL(prep_assemble_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
                        (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off, e->tile_ctr, xh_lig, dl, xh_pocket, dp,
-                       t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
+                       t, (int)t_count, e->x, e->x_in, e->h0, J, JP, fold ? e->seg_base : (int*)nullptr,
+                       fold ? e->seg_base2 : (int*)nullptr);
     HIP_TRY(hipGetLastError());
   }
   // ---- two independent chains at the head of a call: A = encoders -> embedding (-> ghost-row features), needs only the
@@ -826,7 +840,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
                               e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
                               subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base,
-                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr);
+                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr, e->fold_scan != 0);
     if (rc) return rc;
     if (prune) {
       LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
@@ -839,9 +853,11 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       }
       hipLaunchKernelGGL(levels_kernel, dim3(B), dim3(kThreads), 0, s, la);
       HIP_TRY(hipGetLastError());
-      hipLaunchKernelGGL(level_scan_kernel, dim3(1), dim3(1024), 0, s, la, N);
-      HIP_TRY(hipGetLastError());
-      hipLaunchKernelGGL(level_place_kernel, dim3(B), dim3(kThreads), 0, s, la);
+      if (!e->fold_scan) {
+        hipLaunchKernelGGL(level_scan_kernel, dim3(1), dim3(1024), 0, s, la, N);
+        HIP_TRY(hipGetLastError());
+      }
+      hipLaunchKernelGGL(level_place_kernel, dim3(B), dim3(kThreads), 0, s, la, e->fold_scan);
       HIP_TRY(hipGetLastError());
       int64_t cb = (e->cap_edges + 255) / 256;
       if (cb > 2048) cb = 2048;

@@ -49,7 +49,18 @@ struct SegAlign {
   int n_lig; int B;
   int* scan_tmp;   // [n + 1] plain exclusive scan
   int* seg_base;   // [2B + 1]
+  // round 5 ("folded scan", forward calls of the engine): raw edge totals of the 2B segments, accumulated by the count
+  // pass with integer atomics (order-free: exact) from zero; the fill pass then finds a row's position itself -- a wave
+  // sum over the earlier segments' padded totals + a wave sum over the earlier rows of its own segment -- and no
+  // scan_kernel launch (one workgroup, 15.6 us per call) sits between the two passes.  nullptr: the scan_kernel path.
+  int* seg_tot;    // [2B]
 };
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 
 // Optional second output of the radius graph: the edges that have a LIGAND endpoint (all edges of
 // ligand rows + the ligand columns of pocket rows), in the same aligned layout with its own
@@ -83,6 +94,38 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     // aligned layout: first edge of row i = base of its (sample, node set) segment + the edges of the
     // segment's earlier rows (plain scan differences); compact layout: the plain scan itself
     int base = 0;
+    int base2 = 0;
+    if (FILL && seg.seg_tot) {
+      // folded scan: this row's position from the segment totals of the count pass and the degrees of the earlier rows
+      // of its own segment (wave sums of integers)
+      const int k = il ? b : seg.B + b;
+      const int first = il ? lig_off[b] : n_lig + poc_off[b];
+      const bool two = l2.deg != nullptr;
+      int sb = 0, sb2 = 0, pre = 0, pre2 = 0;
+      for (int k0 = 0; k0 < k; k0 += 64) {
+        const int kk = k0 + lane;
+        if (kk < k) {
+          sb += (seg.seg_tot[kk] + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
+          if (two) sb2 += (l2.seg.seg_tot[kk] + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
+        }
+      }
+      for (int r0 = first; r0 < i; r0 += 64) {
+        const int r = r0 + lane;
+        if (r < i) { pre += deg[r]; if (two) pre2 += l2.deg[r]; }
+      }
+      sb = wave_sum_i(sb); pre = wave_sum_i(pre);
+      base = sb + pre;
+      if (lane == 0) row_ptr_out[i] = base;
+      if (two) {
+        sb2 = wave_sum_i(sb2); pre2 = wave_sum_i(pre2);
+        base2 = sb2 + pre2;
+        if (lane == 0) l2.row_ptr[i] = base2;
+      }
+      if (i == n_nodes - 1 && lane == 0) {   // the last node closes the list: padded total (every later segment is empty)
+        row_ptr_out[n_nodes] = sb + ((seg.seg_tot[k] + kEdgeAlign - 1) & ~(kEdgeAlign - 1));
+        if (two) l2.row_ptr[n_nodes] = sb2 + ((l2.seg.seg_tot[k] + kEdgeAlign - 1) & ~(kEdgeAlign - 1));
+      }
+    } else {
     if (FILL) {
       if (seg.seg_base) {
         const int k = il ? b : seg.B + b;
@@ -93,12 +136,12 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
         base = row_ptr[i];
       }
     }
-    int base2 = 0;
     if (FILL && l2.deg) {
       const int k = il ? b : l2.seg.B + b;
       const int first = il ? lig_off[b] : n_lig + poc_off[b];
       base2 = l2.seg.seg_base[k] + l2.seg.scan_tmp[i] - l2.seg.scan_tmp[first];
       if (lane == 0) l2.row_ptr[i] = base2;
+    }
     }
     int cnt = 0, cnt_lig = 0;
 #pragma unroll 1
@@ -136,6 +179,11 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     if (!FILL && lane == 0) {
       deg[i] = cnt;
       if (l2.deg) l2.deg[i] = il ? cnt : cnt_lig;
+      if (seg.seg_tot) {
+        const int k = il ? b : seg.B + b;
+        atomicAdd(&seg.seg_tot[k], cnt);
+        if (l2.deg) atomicAdd(&l2.seg.seg_tot[k], il ? cnt : cnt_lig);
+      }
       // "active" for the coordinate MLPs in pocket-conditioning mode: ligand nodes and
       // pocket nodes that are a column of some ligand-row edge (graph is symmetric)
       if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
@@ -143,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       if (lvl) lvl[i] = il ? 0 : (cnt_lig > 0 ? 1 : kLevels - 1);
     }
     if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
-    if (FILL && seg.seg_base) {
+    if (FILL && (seg.seg_base || seg.seg_tot)) {
       // the last row of a (sample, node set) segment fills the segment up to the next wave-tile
       // boundary with inactive entries (row = -1), see scan_kernel
       const int seg_last = (il ? lig_off[b + 1] : n_lig + poc_off[b + 1]) - 1;
@@ -390,16 +438,52 @@ __global__ __launch_bounds__(1024) void level_scan_kernel(LevelArgs a, int n_nod
   }
 }
 
-__global__ __launch_bounds__(kThreads) void level_place_kernel(LevelArgs a) {
+// exclusive position of segment k = (L, b) among the kLevels * B segments: nodes, padded edges (wave sums)
+__device__ __forceinline__ void level_bases(const LevelArgs& a, int k, int lane, int& nb, int& eb) {
+  int sn = 0, se = 0;
+  for (int k0 = 0; k0 < k; k0 += 64) {
+    const int kk = k0 + lane;
+    if (kk < k) { sn += a.seg_rows[kk]; se += (a.seg_edges[kk] + kEdgeAlign - 1) & ~(kEdgeAlign - 1); }
+  }
+  nb = a.node_off + wave_sum_i(sn);
+  eb = a.edge_off + wave_sum_i(se);
+}
+
+// fold_scan != 0 (round 5): no level_scan_kernel launch in front -- every wave finds the bases of its own segment with
+// two wave sums over the (level, sample) table, and workgroup 0 writes the per-level ends / counts / statistics
+__global__ __launch_bounds__(kThreads) void level_place_kernel(LevelArgs a, int fold_scan = 0) {
   static_assert(kThreads / 64 >= kLevels - 1, "one wave per pocket level");
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (fold_scan && b == 0 && w == kThreads / 64 - 1) {
+    // cumulative ends of the levels (what level_scan_kernel wrote): level t ends where segment (t + 1, 0) begins
+    unsigned long long ed_run = 0;
+    for (int t = 0; t < kLevels; ++t) {
+      int cn, ce;
+      level_bases(a, (t + 1) * a.B, lane, cn, ce);
+      int own = 0;
+      for (int k0 = t * a.B; k0 < (t + 1) * a.B; k0 += 64) { const int kk = k0 + lane; if (kk < (t + 1) * a.B) own += a.seg_edges[kk]; }
+      ed_run += (unsigned long long)wave_sum_i(own);
+      if (lane == 0) {
+        a.lvl_cnt[t] = cn; a.lvl_cnt[kLevels + t] = cn - a.node_off;
+        a.lvl_end[t] = ce; a.lvl_end[kLevels + t] = ce - a.edge_off;
+        if (a.stats) {
+          a.stats[t] += (unsigned long long)(cn - a.node_off);
+          a.stats[kLevels + t] += (unsigned long long)(ce - a.edge_off);
+          a.stats[2 * kLevels + t] += ed_run;
+          if (t == 0) a.stats[3 * kLevels] += 1ull;
+        }
+      }
+    }
+  }
   auto pads = [&](int from) {               // fill the segment up to the next wave-tile boundary
     const int to = (from + kEdgeAlign - 1) & ~(kEdgeAlign - 1), pos = from + lane;
     if (pos < to && pos < a.e_cap) { a.erow[pos] = -1; a.ecol[pos] = 0; a.ed0[pos] = 0.f; }
   };
   if (w == 0) {                             // ligand rows keep their natural order
     const int l0 = a.lig_off[b], l1 = a.lig_off[b + 1];
-    const int nb = a.node_base[b], eb = a.edge_base[b], s0 = l0 < l1 ? a.row_ptr_nat[l0] : 0;
+    int nb, eb;
+    if (fold_scan) level_bases(a, b, lane, nb, eb); else { nb = a.node_base[b]; eb = a.edge_base[b]; }
+    const int s0 = l0 < l1 ? a.row_ptr_nat[l0] : 0;
     for (int i = l0 + lane; i < l1; i += 64) {
       a.lvl_list[nb + (i - l0)] = i;
       a.row_ptr[i] = eb + (a.row_ptr_nat[i] - s0);
@@ -409,7 +493,9 @@ __global__ __launch_bounds__(kThreads) void level_place_kernel(LevelArgs a) {
   const int L = w + 1;                      // pocket level of this wave
   if (L >= kLevels) return;
   const int p0 = a.n_lig + a.poc_off[b], p1 = a.n_lig + a.poc_off[b + 1];
-  int n_run = a.node_base[L * a.B + b], e_run = a.edge_base[L * a.B + b];
+  int n_run, e_run;
+  if (fold_scan) level_bases(a, L * a.B + b, lane, n_run, e_run);
+  else { n_run = a.node_base[L * a.B + b]; e_run = a.edge_base[L * a.B + b]; }
   for (int i0 = p0; i0 < p1; i0 += 64) {
     const int i = i0 + lane;
     const bool mine = i < p1 && a.lvl[i] == L;
@@ -579,9 +665,14 @@ __global__ void assemble_kernel(const float* xh_lig, int dl, const float* xh_poc
 __global__ void prep_assemble_kernel(const int64_t* mask_lig, int n_lig, const int64_t* mask_poc, int n_poc, int B,
                                      int* node_batch, int* lig_off, int* poc_off, int* tile_ctr, const float* xh_lig,
                                      int dl, const float* xh_poc, int dp, const float* t, int t_count, float* x,
-                                     float* x_in, float* h0, int J, int JP) {
+                                     float* x_in, float* h0, int J, int JP, int* seg_tot_a = nullptr,
+                                     int* seg_tot_b = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (tile_ctr && i < kTileCtrInts) tile_ctr[i] = 0;
+  if (i < 2 * B) {                     // segment totals of the radius graph's count pass (folded scan)
+    if (seg_tot_a) seg_tot_a[i] = 0;
+    if (seg_tot_b) seg_tot_b[i] = 0;
+  }
   if (i <= B) {
     lig_off[i] = lower_bound_i64(mask_lig, n_lig, i);
     poc_off[i] = lower_bound_i64(mask_poc, n_poc, i);

@@ -78,18 +78,32 @@ class LigandGenerator:
             raise ValueError(f"mode must be one of {sorted(_DDPM_BY_MODE)}")
         if pocket_representation not in ("CA", "full-atom"):
             raise ValueError("pocket_representation must be 'CA' or 'full-atom'")
-        if virtual_nodes:
-            raise NotImplementedError("virtual_nodes checkpoints are not supported by the sampling path")
         self.mode = mode
         self.pocket_representation = pocket_representation
         self.dataset_name = dataset
-        self.dataset_info = dataset_info(dataset)
+        self.dataset_info = dict(dataset_info(dataset))
         self.device = torch.device(device)
         info = self.dataset_info
-        self.lig_type_encoder, self.lig_type_decoder = info["atom_encoder"], info["atom_decoder"]
+        self.lig_type_encoder, self.lig_type_decoder = dict(info["atom_encoder"]), list(info["atom_decoder"])
+        # virtual nodes (lightning_modules.py:116-135,161-173): one more ligand atom class ('Ne'), every ligand padded to
+        # the largest size of the histogram during training; the class index reaches the DDPM as virtual_node_idx
+        # (its losses ignore the coordinates of virtual atoms).  Sampling (lightning_modules.py:519-535): every
+        # ligand gets max_num_nodes nodes and the atoms that come out as virtual are dropped before molecule building.
+        self.virtual_nodes = bool(virtual_nodes)
+        self.max_num_nodes = len(node_histogram) - 1
+        self.virtual_atom = None
+        if self.virtual_nodes:
+            self.virtual_atom = len(self.lig_type_encoder)
+            self.lig_type_encoder["Ne"] = self.virtual_atom
+            self.lig_type_decoder.append("Ne")
         ca = pocket_representation == "CA"
-        self.pocket_type_encoder = info["aa_encoder"] if ca else info["atom_encoder"]
-        self.pocket_type_decoder = info["aa_decoder"] if ca else info["atom_decoder"]
+        # (full-atom pockets share the ligand's encoder / decoder OBJECTS in the reference, lightning_modules.py:91-98:
+        #  with virtual nodes the extra class therefore widens the pocket features as well -- mirrored, or the
+        #  checkpoint's residue encoder would not load)
+        self.pocket_type_encoder = info["aa_encoder"] if ca else self.lig_type_encoder
+        self.pocket_type_decoder = info["aa_decoder"] if ca else self.lig_type_decoder
+        if self.virtual_nodes:
+            self.dataset_info["atom_encoder"], self.dataset_info["atom_decoder"] = self.lig_type_encoder, self.lig_type_decoder
         self.atom_nf, self.aa_nf, self.x_dims = len(self.lig_type_decoder), len(self.pocket_type_decoder), 3
         self.T = _get(diffusion_params, "diffusion_steps")
         # same keyword arguments as lightning_modules.py:137-159
@@ -116,7 +130,7 @@ class LigandGenerator:
             noise_precision=_get(diffusion_params, "diffusion_noise_precision"),
             loss_type=_get(diffusion_params, "diffusion_loss_type"),
             norm_values=_get(diffusion_params, "normalize_factors"),
-            size_histogram=np.asarray(node_histogram), virtual_node_idx=None).to(self.device)
+            size_histogram=np.asarray(node_histogram), virtual_node_idx=self.virtual_atom).to(self.device)
         self.ddpm.eval()
 
     # -- construction from a reference checkpoint ---------------------------------------
@@ -181,9 +195,18 @@ class LigandGenerator:
         pocket = self.prepare_pocket(residues, repeats=n_samples)
         xh_lig, lig_mask = self.sample_for_pocket(pocket, n_samples, num_nodes_lig, timesteps,
                                                   n_nodes_bias, n_nodes_min, **kwargs)
+        x, atom_type, lig_mask = self._drop_virtual(xh_lig, lig_mask)
+        return build_molecules(x, atom_type, lig_mask, self.dataset_info, largest_frag=largest_frag, batch=n_samples)
+
+    def _drop_virtual(self, xh_lig, lig_mask):
+        """(x, atom_type, lig_mask) of the generated atoms; with virtual nodes the atoms of the virtual class are
+        removed first (lightning_modules.py:531-537)."""
         x = xh_lig[:, :self.x_dims]
         atom_type = xh_lig[:, self.x_dims:].argmax(1)
-        return build_molecules(x, atom_type, lig_mask, self.dataset_info, largest_frag=largest_frag)
+        if self.virtual_nodes:
+            keep = atom_type != self.virtual_atom
+            x, atom_type, lig_mask = x[keep], atom_type[keep], lig_mask[keep]
+        return x, atom_type, lig_mask
 
     @torch.no_grad()
     def sample_for_pocket(self, pocket, n_samples, num_nodes_lig=None, timesteps=None,
@@ -192,7 +215,10 @@ class LigandGenerator:
         returns (xh_lig in the pocket's original frame, lig_mask)."""
         pocket_com_before = self.ddpm._seg_mean3(pocket["x"].float(), pocket["mask"], n_samples)
         if num_nodes_lig is None:
-            num_nodes_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket["size"])
+            if self.virtual_nodes:                          # lightning_modules.py:519-520
+                num_nodes_lig = torch.full((n_samples,), self.max_num_nodes, dtype=torch.int64)
+            else:
+                num_nodes_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket["size"])
         num_nodes_lig = torch.as_tensor(num_nodes_lig, dtype=torch.int64)
         num_nodes_lig = torch.clamp(num_nodes_lig + n_nodes_bias, min=n_nodes_min)
         if type(self.ddpm) == EnVariationalDiffusion:
@@ -236,7 +262,8 @@ class LigandGenerator:
             pk["mask"] = pk["mask"] + base
             parts.append(pk)
             if n_lig is None:
-                n_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pk["size"])
+                n_lig = torch.full((n,), self.max_num_nodes, dtype=torch.int64) if self.virtual_nodes else \
+                    self.ddpm.size_distribution.sample_conditional(n1=None, n2=pk["size"])
             n_lig = torch.as_tensor(n_lig, dtype=torch.int64).cpu()
             assert n_lig.numel() == n
             sizes.append(n_lig)
@@ -247,8 +274,8 @@ class LigandGenerator:
             self.ddpm.seed(seed, sample_ids=sample_ids)
         xh_lig, lig_mask = self.sample_for_pocket(pocket, base, torch.cat(sizes), timesteps,
                                                   n_nodes_bias, n_nodes_min, **kwargs)
-        mols = build_molecules(xh_lig[:, :self.x_dims], xh_lig[:, self.x_dims:].argmax(1), lig_mask,
-                               self.dataset_info, largest_frag=largest_frag)
+        x, atom_type, lig_mask = self._drop_virtual(xh_lig, lig_mask)
+        mols = build_molecules(x, atom_type, lig_mask, self.dataset_info, largest_frag=largest_frag, batch=base)
         out, o = [], 0
         for n in counts:
             out.append(mols[o:o + n])

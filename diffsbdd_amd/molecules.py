@@ -139,7 +139,7 @@ def _tables_on(device, info):
 _tables_on.cache = {}
 
 
-def bond_orders(x, atom_type, lig_mask, info, n_max=None):
+def bond_orders(x, atom_type, lig_mask, info, n_max=None, batch=None):
     """Bond-order matrices of a batch on the GPU.
 
     x [N,3] float32 (Angstrom), atom_type [N] integer class ids, lig_mask [N]
@@ -152,12 +152,12 @@ def bond_orders(x, atom_type, lig_mask, info, n_max=None):
     dev = x.device
     x = x.contiguous().float()
     at = atom_type.to(device=dev, dtype=torch.int32).contiguous()
-    B = int(lig_mask.max().item()) + 1 if lig_mask.numel() else 0
-    sizes = torch.bincount(lig_mask.to(dev), minlength=B)
+    B = int(batch) if batch is not None else (int(lig_mask.max().item()) + 1 if lig_mask.numel() else 0)
+    sizes = torch.bincount(lig_mask.to(dev), minlength=B)      # (`batch`: samples that lost every atom stay in the list)
     off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
     off[1:] = torch.cumsum(sizes, 0).to(torch.int32)
     if n_max is None:
-        n_max = int(sizes.max().item())
+        n_max = max(int(sizes.max().item()) if B else 0, 1)
     b1, b2, b3 = _tables_on(dev, info)
     m1, m2, m3 = info["margins"]
     out = torch.empty((B, n_max, n_max), dtype=torch.int8, device=dev)
@@ -169,13 +169,13 @@ def bond_orders(x, atom_type, lig_mask, info, n_max=None):
     return out, sizes
 
 
-def build_molecules(x, atom_type, lig_mask, info, largest_frag=False):
+def build_molecules(x, atom_type, lig_mask, info, largest_frag=False, batch=None):
     """Batch version of `build_molecule(..., use_openbabel=False)` +
     `process_molecule(largest_frag=...)` (molecule_builder.py:140-160, 162-214):
     list of `Molecule`, one per sample, in sample order."""
     if isinstance(info, str):
         info = dataset_info(info)
-    orders, sizes = bond_orders(x, atom_type, lig_mask, info)
+    orders, sizes = bond_orders(x, atom_type, lig_mask, info, batch=batch)
     orders = orders.cpu().numpy()
     sizes = sizes.cpu().numpy()
     xs = x.detach().float().cpu().numpy()

@@ -108,6 +108,28 @@ def test_molecule_fragments_and_sdf(tmp_path):
     assert np.allclose(read_sdf_coords(p), pos, atol=5e-5)
 
 
+def test_virtual_nodes_checkpoints_build_like_the_reference():
+    """lightning_modules.py:116-135,161-173: `virtual_nodes=True` adds the class 'Ne' to the ligand vocabulary (atom_nf
+    11), hands its index to the DDPM as virtual_node_idx, and -- the encoder / decoder objects being shared -- widens a
+    full-atom pocket's features too; C-alpha pockets keep their 20 classes.  Sampling drops the virtual atoms."""
+    from diffsbdd_amd.generate import LigandGenerator
+    keys = ("dataset", "egnn_params", "diffusion_params", "mode", "node_histogram", "pocket_representation", "virtual_nodes")
+    for rep, arch, want_r in (("full-atom", "small_cond", 11), ("CA", "small_variant", 20)):
+        hp = _hp(arch, "pocket_conditioning", rep)
+        hp["virtual_nodes"] = True
+        gen = LigandGenerator(**{k: hp[k] for k in keys}, device="cpu")
+        assert gen.atom_nf == 11 and gen.aa_nf == want_r and gen.virtual_atom == 10 and gen.lig_type_decoder[-1] == "Ne"
+        assert gen.ddpm.vnode_idx == 10 and gen.max_num_nodes == 39
+        sd = gen.ddpm.dynamics.state_dict()
+        assert sd["atom_encoder.0.weight"].shape[1] == 11 and sd["residue_encoder.0.weight"].shape[1] == want_r
+        xh = torch.zeros(5, 3 + 11)
+        xh[torch.arange(5), 3 + torch.tensor([0, 10, 2, 10, 10])] = 1.0
+        x, at, m = gen._drop_virtual(xh, torch.tensor([0, 0, 0, 1, 1]))
+        assert at.tolist() == [0, 2] and m.tolist() == [0, 0] and x.shape == (2, 3)
+    plain = LigandGenerator(**{k: _hp("small_cond", "pocket_conditioning", "full-atom")[k] for k in keys}, device="cpu")
+    assert plain.atom_nf == 10 and plain.virtual_atom is None and len(plain.dataset_info["atom_decoder"]) == 10
+
+
 def test_pocket_selection_like_generate_ligands(tmp_path):
     from diffsbdd_amd.generate import LigandGenerator
     pdb = tmp_path / "c.pdb"

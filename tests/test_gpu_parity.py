@@ -385,6 +385,43 @@ def test_fused_keyed_step_is_bitwise_the_separate_launches():
     assert torch.equal(o_l.cpu()[:, 3:].long(), r_l[:, 3:].long())
 
 
+def test_folded_scans_are_bitwise_the_scan_kernels(monkeypatch):
+    """Round 5: the exclusive scans between the two passes of the radius graph and of the level ordering are computed by
+    the fill / place kernels themselves (integer wave sums over segment totals; csrc/graph.h "folded scan") instead of
+    two single-workgroup launches.  DSBDD_FOLD_SCAN=0 selects the old launches: the edge lists, the level structures and
+    every output must be IDENTICAL -- ragged batch with a sample without ligand atoms and one without pocket atoms,
+    calls that return the pocket part (natural-order list) and ligand-only calls (level-ordered list), and a chain with
+    a pocket frame (second list of block 0)."""
+    cfg, _ = W.arch_cfg("small_cond")
+    sd = W.random_state_dict(cfg, 4)
+    xl, xp, t, ml, mp = _random_problem(cfg, [23, 0, 9, 40, 1], [36, 50, 0, 20, 44], seed=17)
+    N = len(ml) + len(mp)
+    c = Case("ddpm_small_cond")
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("DSBDD_FOLD_SCAN", fold)
+        m = make_dynamics(cfg, sd)
+        f_l, f_p = m(*[v.to(dev()) for v in (xl, xp, t, ml, mp)])
+        er, ec = m.engine().last_edges(N)
+        slots = m.engine().edge_slots(N)
+        tt = torch.full((1,), 0.4)
+        e_l, _, st = m.forward_async(xl, xp, tt, ml, mp, want_pocket=False, batch=5)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 0
+        lv = m.engine().last_levels(N)
+        model = make_ddpm(c)
+        model.frame_min_pocket_nodes = 1            # small pockets take the frame too: block 0's second list
+        model.seed(3)
+        chain = model.sample_given_pocket(c.pocket(), c.t("num_nodes_lig"), timesteps=5)
+        res[fold] = ([f_l, f_p, er, ec, e_l, chain[0], chain[1]], slots, lv)
+    a, b = res["1"], res["0"]
+    assert a[1] == b[1]
+    for u, v in zip(a[0], b[0]):
+        assert torch.equal(u, v)
+    for k in a[2]:
+        assert np.array_equal(np.asarray(a[2][k]), np.asarray(b[2][k])), k
+
+
 def test_joint_step_sample_and_inpaint_vs_golden():
     c = Case("ddpm_small_joint")
     model = make_ddpm(c)

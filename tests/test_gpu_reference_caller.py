@@ -118,9 +118,13 @@ def test_reference_generate_ligands_runs_the_hip_samplers(lm, example, name, n, 
         assert sorted(match.tolist()) == list(range(hi - lo)), (name, k, match.tolist())   # a permutation
         assert torch.equal(types_.cpu(), t_ref[lo:hi][match]), (name, k)
         worst = max(worst, d.gather(1, match[:, None]).max().item())
+        # free-running over the chain: 1e-3 absolute + 1e-4 relative (the untrained joint model drives |x| to several
+        # hundred Angstrom, where one fp32 ulp is already 3e-5; same criterion as tests/test_gpu_parity.py's joint chains)
+        ref_k = x_ref[lo:hi][match]
+        assert ((pos.cpu() - ref_k).abs() - (1e-3 + 1e-4 * ref_k.abs())).max().item() <= 0, (name, k, worst, ref_k.abs().max().item())
         lo = hi
-    print(f"[{name}] reference generate_ligands on the HIP samplers: {n} molecules, T = {T}, max |x - oracle| = {worst:.2e}")
-    assert worst < 1e-3, worst
+    print(f"[{name}] reference generate_ligands on the HIP samplers: {n} molecules, T = {T}, max |x - oracle| = {worst:.2e} "
+          f"(max |x| = {x_ref.abs().max().item():.1f})")
 
 
 def _batch(cfg, dd, rep, n=3, seed=0):

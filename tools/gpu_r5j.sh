@@ -1,7 +1,7 @@
 #!/bin/bash
 TAG=${1:-r5j}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_reference_caller.py tests/test_gpu_parity.py tests/test_testset.py -m gpu -q -x -k "reference or fused or golden or free_running or bitwise or chain or driver or variants or eight or two_ranks" > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -8 gpurun_out/${TAG}_pytest.log
+timeout 900 python -m pytest tests/test_gpu_reference_caller.py tests/test_gpu_parity.py tests/test_testset.py tests/test_gpu_fullsize.py -m gpu -q -k "reference or fused or folded or ragged or golden or free_running or bitwise or chain or driver or variants or eight or two_ranks" > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -8 gpurun_out/${TAG}_pytest.log
 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-workloads --no-emulated-leg > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 python - <<PY
 import json
