@@ -97,8 +97,11 @@ struct dsbdd_engine {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int level_rows = 0;  // DSBDD_LEVEL_ROWS=1: all-row stages of a pruned call walk the level list (measured slower, see rows_of)
-  int fold_scan = 1;   // DSBDD_FOLD_SCAN=0: the single-workgroup scan_kernel / level_scan_kernel launches between the passes of the
-                       // radius graph and of the level ordering (round 5: folded into the fill / place kernels, graph.h)
+  int fold_scan = 1;   // DSBDD_FOLD_SCAN: 1 (default) = the level ordering's exclusive scans are computed by level_place_kernel
+                       // itself (no single-workgroup level_scan_kernel launch) and the block-0 sample mean rides in levels_kernel;
+                       // 0 = the separate launches; 2 = ALSO the radius graph's scan folded into its fill pass (segment totals
+                       // by integer atomics in the count pass) -- measured SLOWER: 19.8 k atomics on 128 counters take 129 us
+                       // (edges_kernel<false> 12 -> 129 us, profiles/r5k_*), kept for the record only
   int lig_head = 1;    // DSBDD_LIG_HEAD=0: embedding_out / decoder / finalize as three launches also for ligand-only calls
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
@@ -242,7 +245,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
   if (const char* lh = getenv("DSBDD_LIG_HEAD")) e->lig_head = atoi(lh) != 0;
-  if (const char* fs = getenv("DSBDD_FOLD_SCAN")) e->fold_scan = atoi(fs) != 0;
+  if (const char* fs = getenv("DSBDD_FOLD_SCAN")) e->fold_scan = atoi(fs) < 0 ? 0 : (atoi(fs) > 2 ? 2 : atoi(fs));
   if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
   if (const char* fk = getenv("DSBDD_FORK")) e->fork_front = atoi(fk) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
@@ -757,7 +760,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   {
     int work = N > B + 1 ? N : B + 1;
     if (work < 2 * B) work = 2 * B;
-    const bool fold = e->fold_scan && !ext;
+    const bool fold = e->fold_scan >= 2 && !ext;
     hipLaunchKernelGGL(prep_assemble_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
                        (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off, e->tile_ctr, xh_lig, dl, xh_pocket, dp,
                        t, (int)t_count, e->x, e->x_in, e->h0, J, JP, fold ? e->seg_base : (int*)nullptr,
@@ -814,6 +817,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   if (fork) HIP_TRY(hipEventRecord(e->ev_join, sa));
   // ---- edges (dynamics.py:114, 169-187) ---------------------------------------
   int64_t edge_bound = e->cap_edges;
+  bool mean_in_levels = false;
   if (ext) {
     HIP_TRY(zero_async(e->deg, (size_t)N * 4, s));
     if (ext_n_edges > 0) {
@@ -840,13 +844,16 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
                               e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
                               subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base,
-                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr, e->fold_scan != 0);
+                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr, e->fold_scan >= 2);
     if (rc) return rc;
     if (prune) {
       LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
                    e->ed0, e->seg_rows, e->seg_edges, e->node_base, e->edge_base, e->lvl_cnt, e->lvl_end,
                    e->lvl_list, e->row_ptrL, e->erowL, e->ecolL, e->ed0L, (int)e->cap_edgesL, e->lvl_stats,
-                   n_ghost, (int)ghost_slots, (int)e->cap_edges};
+                   n_ghost, (int)ghost_slots, (int)e->cap_edges, nullptr, nullptr};
+      // block 0's per-sample mean (coord2cross) rides in the levels launch: one launch less per pruned call
+      mean_in_levels = e->fold_scan && n_mlp == 2;
+      if (mean_in_levels) { la.mean_x = e->x; la.mean_out = e->mean; }
       if (!e->lvl_stats_zeroed) {
         HIP_TRY(zero_async(e->lvl_stats, 128, s));
         e->lvl_stats_zeroed = true;
@@ -857,7 +864,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         hipLaunchKernelGGL(level_scan_kernel, dim3(1), dim3(1024), 0, s, la, N);
         HIP_TRY(hipGetLastError());
       }
-      hipLaunchKernelGGL(level_place_kernel, dim3(B), dim3(kThreads), 0, s, la, e->fold_scan);
+      hipLaunchKernelGGL(level_place_kernel, dim3(B), dim3(kThreads), 0, s, la, e->fold_scan ? 1 : 0);
       HIP_TRY(hipGetLastError());
       int64_t cb = (e->cap_edges + 255) / 256;
       if (cb > 2048) cb = 2048;
@@ -988,7 +995,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   };
   bool pqg_ready = false, chained_pq = false, chained_coord = false;
   for (int blk = 0; blk < c.n_layers; ++blk) {
-    if (n_mlp == 2 && (blk == 0 || !subset)) {   // coord2cross needs the per-sample mean of the block's input x
+    if (n_mlp == 2 && (blk == 0 || !subset) && !(blk == 0 && mean_in_levels)) {   // coord2cross needs the per-sample mean of the block's input x
                                                  // (pocket-conditioning mode, later blocks: computed by the
                                                  // previous block's coordinate update)
       hipLaunchKernelGGL(sample_mean_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)e->x,

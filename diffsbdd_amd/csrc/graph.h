@@ -339,6 +339,29 @@ __device__ void scan_one(const int* deg, int* row_ptr, int n, SegAlign seg, int*
 //   level_scan_kernel   one workgroup: exclusive scans over the kLevels * B segments
 //   level_place_kernel  one workgroup per sample, wave L places level L: new row_ptr, lvl_list, pads
 //   level_copy_kernel   one thread per natural-list slot: move the edge to its new position
+// mean[b] = mean of x over ALL nodes of sample b = blockIdx.x (egnn_new.py:307-310); one fixed reduction tree, shared
+// by sample_mean_kernel and levels_kernel (round 5: block 0's mean of a pruned call rides in the levels launch)
+__device__ __forceinline__ void sample_mean_body(const float* x, const int* lig_off, const int* poc_off, int n_lig,
+                                                 float* mean, float (*red)[kThreads]) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = l0 + t; i < l1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+  for (int i = p0 + t; i < p1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+  red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
+    __syncthreads();
+  }
+  if (t < 3) {
+    int cnt = (l1 - l0) + (p1 - p0);
+    if (cnt == 0) cnt = 1;
+    mean[3 * b + t] = red[t][0] / (float)cnt;
+  }
+  __syncthreads();
+}
+
 struct LevelArgs {
   const int* node_batch; const int* lig_off; const int* poc_off; int n_lig; int B;
   int* lvl;                 // [N]
@@ -361,10 +384,13 @@ struct LevelArgs {
   int node_off; int edge_off;
   int e_cap_nat;            // capacity of the natural-order list: never indexed past it, even when the radius graph
                             // overflowed (status bit 1 is then set by edges_kernel and the call's result is discarded)
+  const float* mean_x; float* mean_out;   // optional: levels_kernel also writes the per-sample mean of mean_x (sample_mean_body)
 };
 
 __global__ __launch_bounds__(kThreads) void levels_kernel(LevelArgs a) {
   __shared__ int s_rows[kLevels], s_edges[kLevels];
+  __shared__ float s_red[3][kThreads];
+  if (a.mean_out) sample_mean_body(a.mean_x, a.lig_off, a.poc_off, a.n_lig, a.mean_out, s_red);
   const int b = blockIdx.x, t = threadIdx.x;
   const int p0 = a.n_lig + a.poc_off[b], p1 = a.n_lig + a.poc_off[b + 1];
   const int l0 = a.lig_off[b], l1 = a.lig_off[b + 1];
@@ -694,22 +720,7 @@ __global__ __launch_bounds__(kThreads) void sample_mean_kernel(const float* x, c
                                                                const int* poc_off, int n_lig,
                                                                float* mean) {
   __shared__ float red[3][kThreads];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const int l0 = lig_off[b], l1 = lig_off[b + 1], p0 = n_lig + poc_off[b], p1 = n_lig + poc_off[b + 1];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int i = l0 + t; i < l1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
-  for (int i = p0 + t; i < p1; i += kThreads) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
-  red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
-  __syncthreads();
-  for (int o = kThreads / 2; o > 0; o >>= 1) {
-    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
-    __syncthreads();
-  }
-  if (t < 3) {
-    int cnt = (l1 - l0) + (p1 - p0);
-    if (cnt == 0) cnt = 1;
-    mean[3 * b + t] = red[t][0] / (float)cnt;
-  }
+  sample_mean_body(x, lig_off, poc_off, n_lig, mean, red);
 }
 
 // x[i] += (sum over the row's edges of trans) for the nodes whose coordinates are updated
