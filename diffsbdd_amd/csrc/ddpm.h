@@ -84,7 +84,9 @@ __device__ __forceinline__ void cond_update_body(float* z_lig, float* xh_poc, co
     const int i = l0 + idx / dl, c = idx % dl;
     const size_t o = (size_t)i * dl + c;
     // mu = zt / alpha_{t|s} - (sigma^2_{t|s} / alpha_{t|s} / sigma_t) * eps ; zs = mu + sigma * noise
-    const float v = (z_lig[o] / alpha_ts - c_eps * eps[o]) + sigma * noise(o, idx / dl, idx);
+    // (explicit fma: the SAME two roundings whether the noise is a load or evaluated in place -- left to the compiler,
+    //  the two instantiations contracted this expression differently: 1 ulp apart)
+    const float v = __builtin_fmaf(sigma, noise(o, idx / dl, idx), __builtin_fmaf(-c_eps, eps[o], z_lig[o] / alpha_ts));
     z_lig[o] = v;
     if (c < 3) s[c] += v;
   }
@@ -298,7 +300,7 @@ __device__ __forceinline__ void cond_repaint_body(const CondRepaintArgs& p, cons
     const int c = idx % dl;
     const size_t o = (size_t)(r.l0 + idx / dl) * dl + c;
     const float base = c < 3 ? p.xh0_lig[o] + shift[c] : p.xh0_lig[o];
-    const float v = p.alpha_s * base + p.sigma_s * noise1(o, idx / dl, idx);
+    const float v = __builtin_fmaf(p.sigma_s, noise1(o, idx / dl, idx), p.alpha_s * base);
     p.zk_tmp[o] = v;
     if (c < 3) s[c] += v;
   }
@@ -328,7 +330,7 @@ __device__ __forceinline__ void cond_repaint_body(const CondRepaintArgs& p, cons
     if (c < 3) zk += dx[c];
     float v = zk * f + p.z_lig[o] * (1.f - f);
     if (p.renoise) {
-      v = p.alpha_ts * v + p.sigma_ts * noise2(o, idx / dl, idx);
+      v = __builtin_fmaf(p.sigma_ts, noise2(o, idx / dl, idx), p.alpha_ts * v);
       if (c < 3) s2[c] += v;
     }
     p.z_lig[o] = v;

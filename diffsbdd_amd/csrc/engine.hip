@@ -1683,8 +1683,12 @@ struct TrainScratch {
   size_t bytes, wg_floats;
 };
 static int train_grid(int64_t E) {
+  // persistent workgroups of the backward edge kernels per CU (DSBDD_TRAIN_WG_PER_CU, default 1; the kernels fit two:
+  // 256 VGPRs, 74 KB of LDS)
+  static const int per_cu = [] { const char* v = getenv("DSBDD_TRAIN_WG_PER_CU"); return v && atoi(v) >= 1 && atoi(v) <= 4 ? atoi(v) : 1; }();
   int64_t tiles = (E + 127) / 128;
-  int64_t g = tiles < device_cus() ? tiles : device_cus();
+  int64_t cap = (int64_t)per_cu * device_cus();
+  int64_t g = tiles < cap ? tiles : cap;
   return g < 1 ? 1 : (int)g;
 }
 static TrainScratch carve_train(char* base, int H, int64_t N, int64_t E) {
