@@ -72,6 +72,32 @@ def test_wgrad_and_colsum_vs_torch(K, M, N):
     assert rel_err(out, A.double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("H,E,e_upd", [(256, 160000, 30000), (192, 30857, 17228), (256, 91152, 11000), (128, 50000, 49000)])
+def test_wgrad_on_an_edge_prefix_fits_the_scratch_of_the_full_list(H, E, e_upd):
+    """the coordinate stage's backward runs the weight-gradient GEMM on the ligand-row PREFIX
+    (K = e_upd < E) with a scratch sized for E.  The split-K plan is not monotonic in K (K = 30 000 needs 188 chunks,
+    K = 160 000 only 186 at 256 x 256), so the bound must cover every prefix: `dsbdd_train_wgrad_scratch_bytes(E)` does,
+    a call whose plan would not fit returns DSBDD_ERR_CAPACITY instead of writing past the end, and guard words behind
+    the scratch stay untouched."""
+    from diffsbdd_amd import _lib
+    lib = _lib.load()
+    nb = lib.dsbdd_train_wgrad_scratch_bytes(E, H, H)
+    assert lib.dsbdd_train_wgrad_plan_bytes(e_upd, H, H) <= nb
+    g = torch.Generator().manual_seed(E + e_upd)
+    A = torch.randn(e_upd, H, generator=g).to(dev())
+    B = torch.randn(e_upd, H, generator=g).to(dev())
+    guard = 4096
+    scr = torch.full((nb + guard,), 0xA5, dtype=torch.uint8, device=dev())
+    C_ = torch.empty(H, H, device=dev())
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.dsbdd_train_wgrad(s, A.data_ptr(), H, B.data_ptr(), H, e_upd, H, H, C_.data_ptr(), scr.data_ptr(), nb))
+    torch.cuda.synchronize()
+    assert bool((scr[nb:] == 0xA5).all())                      # nothing written behind the bound
+    assert rel_err(C_, A.double().t() @ B.double()) < 2e-6
+    small = lib.dsbdd_train_wgrad_plan_bytes(e_upd, H, H) - 4
+    assert lib.dsbdd_train_wgrad(s, A.data_ptr(), H, B.data_ptr(), H, e_upd, H, H, C_.data_ptr(), scr.data_ptr(), small) == _lib.ERR_CAPACITY
+
+
 @pytest.mark.parametrize("M,K,N,bias", [(777, 256, 256, True), (300, 10, 20, True), (1500, 512, 256, True),
                                          (64, 129, 256, True), (900, 256, 129, False), (500, 256, 1024, False)])
 def test_hip_linear_forward_backward(M, K, N, bias):
