@@ -43,15 +43,21 @@
 
 namespace dsbdd {
 
-// scheduling fence between the MFMA groups and the B-operand reads of the emulated path (the compiler otherwise sinks the
-// reads to just in front of their first use and waits for each); -DDSBDD_EMU_NOFENCE: leave the order to the compiler
+// Emulated path, A/B switches (profiles/r5_emu_microbench.md: every combination lands within 4 % of the others):
+//   -DDSBDD_EMU_FENCE   scheduling fences between the MFMA groups and the B-operand reads, which then stay one pair of column
+//                       tiles ahead of their use (default: the compiler's order -- it sinks the reads to just in front of
+//                       their first MFMA);  377 us (default) vs 386 - 395 us on the micro-benchmark list
+//   -DDSBDD_EMU_PIPE_A  the next k step's activations computed one step ahead (default: in front of the step's own MFMAs)
 #ifndef DSBDD_EMU_FENCE_MASK
 #define DSBDD_EMU_FENCE_MASK 0
 #endif
-#ifdef DSBDD_EMU_NOFENCE
-#define EMU_FENCE() do { } while (0)
-#else
+#ifdef DSBDD_EMU_FENCE
 #define EMU_FENCE() __builtin_amdgcn_sched_barrier(DSBDD_EMU_FENCE_MASK)
+#else
+#define EMU_FENCE() do { } while (0)
+#endif
+#ifndef DSBDD_EMU_PIPE_A
+#define DSBDD_EMU_NOPIPE_A 1
 #endif
 
 // EMU = 0: exact fp32 (v_mfma_f32_32x32x2_f32).  EMU = 6 / 9: fp32 EMULATED on the bf16 matrix cores -- both operands of
@@ -474,13 +480,10 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
       if constexpr (EMU != 0) {
         // ---- emulated path: one 16-k step = 8 activations per lane, split into three bf16x8, 6 (9) MFMAs per column tile.
-        // Software pipeline of a step (the bf16 MFMAs do not use the vector ALUs, so everything else can hide behind them
-        // -- but only inside ONE wave: the two waves of a SIMD drift into phase, tools/microbench_emu.hip):
-        //   * the B operands of a pair of column tiles are read one pair ahead, plane by plane, into the registers the
-        //     MFMAs just released (lo plane: 1 product, mid: 2, hi: 3 -> the order lo, mid, hi frees them early);
-        //   * the activations of the NEXT step are computed between this step's MFMAs (n_*), from the P / Q chunk that
-        //     was requested one step earlier; the chunk after that is requested as soon as its registers are free;
-        //   * the next W2E slice travels through staging registers in two halves, as before.
+        // Order of a step: the step's activations, the next P / Q chunk requested, then per pair of column tiles the three
+        // B planes (lo: 1 product, mid: 2, hi: 3) and their MFMAs; the next W2E slice travels through staging registers in
+        // two halves.  (-DDSBDD_EMU_FENCE / -DDSBDD_EMU_PIPE_A: B reads one pair ahead behind scheduling fences / the next
+        // step's activations one step ahead -- measured neutral to slower, see the top of the file.)
         constexpr int NG1 = (NG + 1) / 2;
         auto act8 = [&](int ks, bf16x8& o_h, bf16x8& o_m, bf16x8& o_l) {       // activations of k step ks from pc / qc
           const float* vk = vq + ks * 16 + 8 * half;       // this lane's k = 16 ks + 8 half + i

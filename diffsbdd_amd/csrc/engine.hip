@@ -34,6 +34,25 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
       return fail(DSBDD_ERR_LAUNCH, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// Every entry point launches on the caller's stream: make that stream's device the current one for the duration of the
+// call (a module living on a GPU that is not torch's current device must not launch through another device's
+// context), and restore it afterwards.  The NULL stream belongs to the current device by definition.
+struct StreamDevice {
+  int prev = -1;
+  bool switched = false;
+  explicit StreamDevice(void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!s) return;
+    hipDevice_t d = 0;
+    int cur = 0;
+    if (hipStreamGetDevice(s, &d) != hipSuccess || hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+    if ((int)d != cur) { prev = cur; switched = hipSetDevice((int)d) == hipSuccess; }
+  }
+  ~StreamDevice() { if (switched) (void)hipSetDevice(prev); }
+  StreamDevice(const StreamDevice&) = delete;
+  StreamDevice& operator=(const StreamDevice&) = delete;
+};
+
 static inline int pad4(int v) { return (v + 3) & ~3; }
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -389,6 +408,7 @@ int dsbdd_engine_set_pocket_frame(dsbdd_engine* e, void* stream, const float* x_
                                   const int32_t* frame_rows, const int32_t* twin_local, int64_t n_lig,
                                   int64_t n_pocket, int64_t batch, int64_t n_frame, int64_t batch_frame,
                                   int64_t edge_bound_frame) {
+  StreamDevice stream_device_(stream);
   if (!e || !x_frame || !mask_frame || !frame_rows || !twin_local) return fail(DSBDD_ERR_ARG, "null argument");
   if (!e->ws) return fail(DSBDD_ERR_STATE, "workspace not bound");
   if (e->cfg.update_pocket_coords) return fail(DSBDD_ERR_STATE, "a pocket frame needs rigid pocket coordinates");
@@ -1289,6 +1309,7 @@ int dsbdd_dynamics_forward(dsbdd_engine* e, void* stream, const float* xh_lig, c
                            const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
                            const int32_t* ext_row, const int32_t* ext_col, int64_t ext_n_edges,
                            float* eps_lig, float* eps_pocket, int32_t* status) {
+  StreamDevice stream_device_(stream);
   if (!e || !xh_lig || !xh_pocket || !t || !mask_lig || !mask_pocket || !eps_lig || !status)
     return fail(DSBDD_ERR_ARG, "null argument");
   if (!e->has_weights) return fail(DSBDD_ERR_STATE, "weights not set");
@@ -1410,6 +1431,7 @@ int dsbdd_cond_reverse_update(void* stream, float* z_lig, float* xh_pocket, cons
                               const float* noise, const int64_t* mask_lig, const int64_t* mask_pocket,
                               int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
                               int32_t residue_nf, float alpha_ts, float c_eps, float sigma, int32_t remove_com) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !xh_pocket || !eps_lig || !noise || !mask_lig || !mask_pocket || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
   hipLaunchKernelGGL(cond_update_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
@@ -1424,6 +1446,7 @@ int dsbdd_joint_reverse_update(void* stream, float* z_lig, float* z_pocket, cons
                                const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
                                int64_t n_pocket, int64_t batch, int32_t atom_nf, int32_t residue_nf,
                                float alpha_ts, float c_eps, float sigma, int32_t center_noise) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !z_pocket || !eps_lig || !eps_pocket || !noise_lig || !noise_pocket || !mask_lig ||
       !mask_pocket || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1436,6 +1459,7 @@ int dsbdd_joint_reverse_update(void* stream, float* z_lig, float* z_pocket, cons
 
 int dsbdd_segment_mean3(void* stream, const float* x, int32_t ld, const int64_t* mask, int64_t n_rows,
                         int64_t batch, float* out) {
+  StreamDevice stream_device_(stream);
   if (!x || !mask || !out || batch < 1 || ld < 3 || n_rows < 0) return fail(DSBDD_ERR_ARG, "bad argument");
   hipLaunchKernelGGL(segment_mean3_kernel, dim3((int)batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      x, ld, mask, (int)n_rows, out);
@@ -1447,6 +1471,7 @@ int dsbdd_cond_affine_noise(void* stream, float* z_lig, float* xh_pocket, const 
                             const int64_t* mask_lig, const int64_t* mask_pocket, int64_t n_lig,
                             int64_t n_pocket, int64_t batch, int32_t atom_nf, int32_t residue_nf, float a,
                             float sigma, int32_t remove_com) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !xh_pocket || !noise || !mask_lig || !mask_pocket || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
   hipLaunchKernelGGL(cond_affine_noise_kernel, dim3((int)batch), dim3(kThreads), 0,
@@ -1461,6 +1486,7 @@ int dsbdd_joint_affine_noise(void* stream, float* z_lig, float* z_pocket, const 
                              int64_t n_lig, int64_t n_pocket, int64_t batch, int32_t atom_nf,
                              int32_t residue_nf, float a, float sigma, int32_t center_noise,
                              int32_t remove_com) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !z_pocket || !noise_lig || !noise_pocket || !mask_lig || !mask_pocket || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
   hipLaunchKernelGGL(joint_affine_noise_kernel, dim3((int)batch), dim3(kThreads), 0,
@@ -1477,6 +1503,7 @@ int dsbdd_cond_repaint_update(void* stream, float* z_lig, float* xh_pocket, floa
                               const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
                               int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
                               float alpha_ts, float sigma_ts, int32_t resample, int32_t remove_com) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !xh_pocket || !scratch_lig || !xh0_lig || !com_pocket0 || !fixed || !noise_known ||
       (resample && !noise_resample) || !mask_lig || !mask_pocket || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1494,6 +1521,7 @@ int dsbdd_cond_step_keyed(void* stream, float* z_lig, float* xh_pocket, const fl
                           int32_t residue_nf, float alpha_ts, float c_eps, float sigma, int32_t repaint, float alpha_s,
                           float sigma_s, float sigma_ts, int32_t remove_com, uint64_t seed, uint64_t draw_index,
                           int64_t sample_offset, const int64_t* sample_ids, float* t_word, float t_next) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !xh_pocket || !eps_lig || !mask_lig || !mask_pocket || batch < 1 || repaint < 0 || repaint > 2 ||
       (repaint && (!scratch_lig || !xh0_lig || !com_pocket0 || !fixed)))
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1517,6 +1545,7 @@ int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, floa
                                const int64_t* mask_pocket, int64_t n_lig, int64_t n_pocket, int64_t batch,
                                int32_t atom_nf, int32_t residue_nf, float alpha_s, float sigma_s,
                                float alpha_ts, float sigma_ts, int32_t jump) {
+  StreamDevice stream_device_(stream);
   if (!z_lig || !z_pocket || !scratch_lig || !scratch_pocket || !xh0_lig || !xh0_pocket || !fixed_lig ||
       !fixed_pocket || !noise_known_lig || !noise_known_pocket || (jump && (!noise_jump_lig || !noise_jump_pocket)) ||
       !mask_lig || !mask_pocket || batch < 1)
@@ -1533,6 +1562,7 @@ int dsbdd_joint_repaint_update(void* stream, float* z_lig, float* z_pocket, floa
 int dsbdd_randn_keyed(void* stream, float* out, const int64_t* mask, int64_t n_rows, int32_t n_cols,
                       int64_t batch, int64_t sample_offset, const int64_t* sample_ids, uint64_t seed,
                       uint64_t draw_index, uint32_t stream_id) {
+  StreamDevice stream_device_(stream);
   (void)batch;
   if (!out || !mask || n_rows < 0 || n_cols < 1) return fail(DSBDD_ERR_ARG, "bad argument");
   const int64_t n = n_rows * n_cols;
@@ -1547,6 +1577,7 @@ int dsbdd_randn_keyed(void* stream, float* out, const int64_t* mask, int64_t n_r
 int dsbdd_node_linear(void* stream, const float* A1, int32_t lda1, int32_t K1, const float* A2, int32_t lda2,
                       int32_t K2, const float* WT, int32_t ldw, const float* bias, const float* R, int32_t ldr,
                       float* C, int32_t ldc, int64_t M, int32_t N, int32_t act) {
+  StreamDevice stream_device_(stream);
   if (!A1 || !WT || !C || K1 < 1 || K2 < 0 || (K2 > 0 && !A2) || (ldw & 3) || N > ldw ||
       (reinterpret_cast<uintptr_t>(WT) & 15))
     return fail(DSBDD_ERR_ARG, "bad argument (WT must be 16-byte aligned with ldw % 4 == 0)");
@@ -1558,6 +1589,7 @@ int dsbdd_bond_orders(void* stream, const float* x, const int32_t* atom_type, co
                       int64_t batch, int32_t n_types, const float* bonds1, const float* bonds2,
                       const float* bonds3, float margin1, float margin2, float margin3, int32_t n_max,
                       int8_t* order) {
+  StreamDevice stream_device_(stream);
   if (!x || !atom_type || !mol_off || !bonds1 || !bonds2 || !bonds3 || !order || batch < 1 || n_types < 1 ||
       n_max < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1575,6 +1607,7 @@ int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig, con
                       int32_t* node_batch, int32_t* lig_off, int32_t* poc_off, int32_t* deg, int32_t* row_ptr,
                       int32_t* edge_row, int32_t* edge_col, float* edge_d0, int64_t edge_capacity,
                       int32_t* status) {
+  StreamDevice stream_device_(stream);
   if (!x || !mask_lig || !mask_pocket || !cfg || !node_batch || !lig_off || !poc_off || !deg || !row_ptr ||
       !edge_row || !edge_col || !edge_d0 || !status || batch < 1)
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1591,15 +1624,17 @@ int dsbdd_build_edges(void* stream, const float* x, const int64_t* mask_lig, con
 }  // extern "C"
 
 // ---- training-step building blocks (csrc/train.h) ---------------------------------------------------------------
-static int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+static int device_cus() {      // CU count of the CURRENT device (cached per device id)
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] == 0) {
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-    if (n <= 0) n = 256;
+    int n = 0;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    cache[dev] = n > 0 ? n : 256;
   }
-  return n;
+  return cache[dev];
 }
 
 static hipError_t launch_edge_plain(int H, hipStream_t s, int mode, const EdgeArgs& a, int64_t edge_bound) {
@@ -1791,6 +1826,7 @@ size_t dsbdd_train_wgrad_plan_bytes(int64_t K, int64_t M, int64_t N) {
 }
 
 int dsbdd_train_edge_rev(void* stream, const dsbdd_train_graph* g, int32_t* rev) {
+  StreamDevice stream_device_(stream);
   if (!graph_ok(g) || !rev) return fail(DSBDD_ERR_ARG, "bad argument");
   if (g->n_edges == 0) return DSBDD_OK;
   hipLaunchKernelGGL(edge_rev_kernel, dim3((unsigned)((g->n_edges + 255) / 256)), dim3(256), 0,
@@ -1801,6 +1837,7 @@ int dsbdd_train_edge_rev(void* stream, const dsbdd_train_graph* g, int32_t* rev)
 }
 
 int dsbdd_train_sample_mean(void* stream, const float* x, const dsbdd_train_graph* g, float* mean) {
+  StreamDevice stream_device_(stream);
   if (!graph_ok(g) || !x || !mean) return fail(DSBDD_ERR_ARG, "bad argument");
   hipLaunchKernelGGL(sample_mean_kernel, dim3((unsigned)g->batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x,
                      g->lig_off, g->poc_off, (int)g->n_lig, mean);
@@ -1810,6 +1847,7 @@ int dsbdd_train_sample_mean(void* stream, const float* x, const dsbdd_train_grap
 
 int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                             float norm_factor, float* agg, void* scratch, size_t scratch_bytes) {
+  StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !mlp_ok(m) || !x || !agg || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
   const TrainScratch ts = carve_train(static_cast<char*>(scratch), H, g->n_nodes, g->n_edges);
   if (ts.bytes > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small (dsbdd_train_scratch_bytes)");
@@ -1832,6 +1870,7 @@ int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g,
 int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                              float norm_factor, const float* d_agg, const dsbdd_train_mlp_grad* out, float* d_x,
                              void* scratch, size_t scratch_bytes) {
+  StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !g->rev || !mlp_ok(m) || !x || !d_agg || !out || !out->dP || !out->dQ ||
       !out->d_vec || !out->d_W2 || !out->gd0 || (out->ldo & 3) || !d_x || !scratch)
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1852,6 +1891,7 @@ int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g
 int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
                               const float* x, const float* mean, int64_t n_upd, float norm_constant, float coords_range,
                               int32_t use_tanh, float norm_factor, float* x_out, void* scratch, size_t scratch_bytes) {
+  StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) || (n_mlp == 2 && (!mlp_ok(m + 1) || !mean)) ||
       !m->head || !x || !x_out || n_upd < 0 || n_upd > g->n_nodes || !scratch)
     return fail(DSBDD_ERR_ARG, "bad argument");
@@ -1884,6 +1924,7 @@ int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph*
                                float coords_range, int32_t use_tanh, float norm_factor, const float* d_xout,
                                const dsbdd_train_mlp_grad* out, float* d_x, float* d_mean, void* scratch,
                                size_t scratch_bytes) {
+  StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !g->rev || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) ||
       (n_mlp == 2 && (!mlp_ok(m + 1) || !mean || !d_mean)) || !m->head || !x || !d_xout || !out || !d_x || n_upd < 0 ||
       n_upd > g->n_nodes || e_upd < 0 || e_upd > g->n_edges || !scratch)
@@ -1917,6 +1958,7 @@ int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph*
 }
 
 int dsbdd_train_radial_backward(void* stream, const dsbdd_train_graph* g, const float* x, const float* gd, float* d_x) {
+  StreamDevice stream_device_(stream);
   if (!graph_ok(g) || !g->rev || !x || !gd || !d_x) return fail(DSBDD_ERR_ARG, "bad argument");
   const int N = (int)g->n_nodes;
   hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, static_cast<hipStream_t>(stream), gd,
@@ -1928,6 +1970,7 @@ int dsbdd_train_radial_backward(void* stream, const dsbdd_train_graph* g, const 
 
 int dsbdd_train_wgrad(void* stream, const float* A, int32_t lda, const float* B, int32_t ldb, int64_t K, int32_t M,
                       int32_t N, float* C, void* scratch, size_t scratch_bytes) {
+  StreamDevice stream_device_(stream);
   if (!A || !B || !C || K < 1 || M < 1 || N < 1 || lda < M || ldb < N || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
   if (wgrad_plan(K, M, N).floats * 4 > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small");
   return wgrad_impl(static_cast<hipStream_t>(stream), A, lda, B, ldb, K, M, N, C, static_cast<float*>(scratch), scratch_bytes / 4);
@@ -1935,6 +1978,7 @@ int dsbdd_train_wgrad(void* stream, const float* A, int32_t lda, const float* B,
 
 int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int32_t N, float* out, void* scratch,
                        size_t scratch_bytes) {
+  StreamDevice stream_device_(stream);
   if (!A || !out || M < 1 || N < 1 || lda < N || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
   if ((size_t)((M + 31) / 32) * N * 4 > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small");
   HIP_TRY(reduce_parts(static_cast<hipStream_t>(stream), A, (int)M, (size_t)lda, N, out, static_cast<float*>(scratch)));
