@@ -254,6 +254,15 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #define DSBDD_TS() do { } while (0)
 #endif
   DSBDD_TS();                                            // mark 0: kernel entry (after the vector loads were issued)
+#ifdef DSBDD_DIAG_PHASES
+  // DIAGNOSTIC ONLY (tools/microbench_emu.hip "phases"): shader cycles of every wave by phase of the emulated K step --
+  // 0 outside the K loop (prologue, epilogue), 1 activations + first B reads, 2 MFMA phase, 3 trailing staging stores,
+  // 4 barrier.  s_memtime waits for the wave's LDS operations; at these boundaries they are awaited anyway.
+  unsigned long long ph_t = __builtin_readcyclecounter(), ph[5] = {0, 0, 0, 0, 0};
+#define DSBDD_PH(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define DSBDD_PH(i) do { } while (0)
+#endif
   const int E = min(*p.e_count, p.e_cap);
   const int nt_a = (E + BMB - 1) / BMB;
   const int E_b = (MODE == MODE_GCL && p.e_count_b) ? min(*p.e_count_b, p.e_cap_b) : 0;   // second list of the stage
@@ -478,6 +487,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       if (more || !last_unit_k) streamB(sq, sks, (bslice + 1) & 1);
 #endif
       const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
+      if constexpr (EMU != 0) DSBDD_PH(0);
       if constexpr (EMU != 0) {
         // ---- emulated path: one 16-k step = 8 activations per lane, split into three bf16x8, 6 (9) MFMAs per column tile.
         // Order of a step: the step's activations, the next P / Q chunk requested, then per pair of column tiles the three
@@ -556,6 +566,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #endif
 #define EMU_MM(a, b) do { _Pragma("unroll") for (int u = 0; u < 2; ++u) \
           acc[2 * cp + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[2 * cp + u], 0, 0, 0); } while (0)
+        DSBDD_PH(1);
         if (SETPRIO_EMU) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int cp = 0; cp < CT / 2; ++cp) {
@@ -583,8 +594,10 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         }
 #undef EMU_MM
         if (SETPRIO_EMU) __builtin_amdgcn_s_setprio(0);
+        DSBDD_PH(2);
 #pragma unroll
         for (int g = (NG > 1 ? NG1 : 0); g < NG; ++g) stage_store((bslice + 1) & 1, g);
+        DSBDD_PH(3);
 #ifndef DSBDD_EMU_NOPIPE_A
         a_h = n_h; a_m = n_m; a_l = n_l;
 #endif
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #else
       __syncthreads();
 #endif
+      if constexpr (EMU != 0) DSBDD_PH(4);
       DSBDD_TS();           // marks 2 .. NK+1: end of every K step
     }
 
@@ -865,6 +879,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       ++q;
     }
   }  // units
+#ifdef DSBDD_DIAG_PHASES
+  DSBDD_PH(0);
+  if (p.ts && lane == 0)
+    for (int i = 0; i < 5; ++i) p.ts[(blockIdx.x * 4 + (t >> 6)) * 8 + i] = ph[i];
+#endif
   check_out();
 }
 

@@ -259,6 +259,29 @@ int main(int argc, char** argv) {
     printf("\nwhole batch (%d rows): max |emulated - exact| / max |agg| = %.3e (6 products), %.3e (9 products)\n", N, d6 / am, d9 / am);
   }
 
+#ifdef DSBDD_DIAG_PHASES
+  {   // in-situ phase clocks of the emulated GCL kernel over the whole list (hipcc -DDSBDD_DIAG_PHASES)
+    EdgeArgs a = edge_args(MODE_GCL, 0);
+    const int grid = grid_of(MODE_GCL, counts[0]);
+    unsigned long long* d_ts = dev_zero<unsigned long long>((size_t)grid * 4 * 8);
+    a.ts = d_ts;
+    launch(6, MODE_GCL, a, grid);
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(d_ts, 0, (size_t)grid * 4 * 8 * 8));
+    const float us = time_us([&] { launch(6, MODE_GCL, a, grid); }, 1);
+    std::vector<unsigned long long> ts((size_t)grid * 4 * 8);
+    CK(hipMemcpy(ts.data(), d_ts, ts.size() * 8, hipMemcpyDeviceToHost));
+    const char* pn[5] = {"outside the K loop (prologue, accumulator init, epilogue)", "activations, P / Q request, first staging loads, first B reads",
+                         "MFMA phase (48 MFMAs, B reads, staging in the middle)", "trailing staging stores", "barrier"};
+    double tot[5] = {0, 0, 0, 0, 0}, all = 0;
+    for (size_t wv = 0; wv < (size_t)grid * 4; ++wv) for (int i = 0; i < 5; ++i) { tot[i] += (double)ts[wv * 8 + i] / 4.0; all += (double)ts[wv * 8 + i] / 4.0; }
+    const double ksteps = (double)((counts[0] + 127) / 128) * (H / 16);          // (every launch overwrites its clocks)
+    printf("\n## phase clocks, emulated GCL kernel, whole list, grid %d (%.1f us with the clocks in)\n\n| phase | share of the wave's time | shader cycles per K step |\n|---|---|---|\n", grid, us);
+    for (int i = 0; i < 5; ++i) printf("| %s | %.3f | %.0f |\n", pn[i], tot[i] / all, tot[i] / ksteps);
+    printf("| all | 1 | %.0f |\n", all / ksteps);
+  }
+#endif
+
   // ---- timing -----------------------------------------------------------------------------------------------------
   printf("\n## timing (B = %d)\n\n| kernel | edges | us / launch | TFLOP/s (algorithmic fp32 FLOPs) | frac of 157.3 | speed-up vs exact |\n|---|---|---|---|---|---|\n", B);
   const char* names[4] = {"GCL whole list", "GCL ligand-row prefix", "GCL 28 % prefix", "GCL 69 % prefix"};
