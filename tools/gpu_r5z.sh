@@ -30,5 +30,9 @@ timeout 300 python tools/train_step_bench.py --workload crossdock_fullatom_cond 
 timeout 300 python tools/train_step_bench.py --workload crossdock_ca_cond --steps 8 --paths hip 2>/dev/null | tail -1 >> gpurun_out/${TAG}_train_step.md
 cat gpurun_out/${TAG}_train_step.md
 [ -x tools/bin/mb_emu ] && timeout 120 tools/bin/mb_emu 64 20 > gpurun_out/${TAG}_mb_emu.md 2>&1
+[ -x tools/bin/mb_emu_ph ] && { timeout 120 tools/bin/mb_emu_ph 64 5 0 | grep -A9 "phase clocks"; timeout 120 tools/bin/mb_emu_ph 64 5 0 256 | grep -A9 "phase clocks"; } > gpurun_out/${TAG}_emu_phase_clocks.md 2>&1
+[ -x tools/bin/emu_phase_probe ] && timeout 120 tools/bin/emu_phase_probe > gpurun_out/${TAG}_emu_phase_probe.md 2>&1
+# matrix-pipe / instruction counters of the exact and the emulated edge kernels side by side (micro-benchmark launches)
+[ -x tools/bin/mb_emu ] && bash tools/pmc_micro.sh ${TAG}_emu edge_wave tools/bin/mb_emu "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC" > /dev/null 2>&1
 DSBDD_EMU=6 timeout 1200 python -m pytest tests -m gpu -q --deselect tests/test_gpu_emu.py > gpurun_out/${TAG}_emu_gate_pytest.log 2>&1; echo "gate rc=$?" >> gpurun_out/${TAG}_emu_gate_pytest.log; tail -4 gpurun_out/${TAG}_emu_gate_pytest.log
 ls gpurun_out | grep "^${TAG}" | tr '\n' ' '
