@@ -629,3 +629,21 @@ def test_edge_first_layer_relayout_on_cpu(H, emb):
     w.grad = None
     outs[0].sum().backward()
     assert torch.equal(w.grad[:, :2 * H], torch.ones(H, 2 * H, dtype=torch.float64)) and (w.grad[:, 2 * H:] == 0).all()
+
+
+def test_committed_pmc_traffic_was_measured_on_the_committed_kernel_sources():
+    """`roofline.traffic` of the benchmark line is read from a committed PMC measurement (counters cannot be collected from
+    inside the process); `bench.py` reports it only when the file's `kernel_source_sha16` equals the hash of the edge
+    kernel's sources in this tree.  This test keeps the committed pair consistent: editing `csrc/edge_wave.h`,
+    `edge_mlp.h` or `common.h` without re-running `tools/pmc_traffic.sh` fails HERE instead of silently turning the
+    driver's `traffic` into null."""
+    import bench
+    from diffsbdd_amd.build import kernel_source_hash
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", bench.PMC_TRAFFIC_FILE)
+    assert os.path.isfile(path), path
+    rec = json.load(open(path))
+    assert rec["kernel_source_sha16"] == kernel_source_hash(), \
+        "profiles/%s is stale: re-run tools/pmc_traffic.sh on the GPU box and commit its json" % bench.PMC_TRAFFIC_FILE
+    # the figure itself: between the algorithmic bytes of the launch (65.5 MB) and a small multiple of them
+    assert 60e6 < rec["traffic_bytes_per_launch"] < 200e6
+    assert abs(rec["traffic_bytes_per_launch"] - (2 * rec["FETCH_SIZE_kb"] + rec["WRITE_SIZE_kb"]) * 1024) < 1.0
