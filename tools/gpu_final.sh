@@ -1,14 +1,6 @@
 #!/bin/bash
-# The round's closing GPU session: suite + benches (tools/gpu_round.sh), call sequence and kernel stats of a short run,
-# kernel stats of the full-length benchmark command under rocprofv3, HBM traffic by PMC, the micro-benchmarks.
-# Usage: tools/gpu_final.sh TAG
-TAG=${1:-final}
-mkdir -p gpurun_out
-bash tools/gpu_round.sh $TAG
-bash tools/prof_short.sh ${TAG}_T50
-bash tools/prof_full.sh ${TAG}_T500 --steps 2 --warmup 1
-bash tools/pmc_traffic.sh $TAG
-bash tools/prof_short.sh ${TAG}_ca --workload crossdock_ca_cond
-[ -x tools/bin/mfma_shadow ] && timeout 60 tools/bin/mfma_shadow > gpurun_out/${TAG}_mfma_shadow.md 2>&1
-[ -x tools/bin/mb_final ] && timeout 120 tools/bin/mb_final 64 40 > gpurun_out/${TAG}_microbench.md 2>&1
-ls gpurun_out | grep "^${TAG}" | tr '\n' ' '
+# The closing GPU session of a round.  Round 5: tools/gpu_r5z.sh -- PMC traffic first (so that the bench line of the same
+# session finds a record stamped with this build's kernel-source hash; tests/test_host_logic.py checks the committed pair),
+# the whole GPU suite, the default bench line, rocprofv3 kernel stats of the full-length command (exact and emulated), call
+# sequences, training step, micro-benchmarks, the DSBDD_EMU=6 gate run of the suite.  Usage: tools/gpu_final.sh TAG
+exec bash "$(dirname "$0")/gpu_r5z.sh" "${1:-final}"
