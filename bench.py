@@ -186,10 +186,15 @@ def cpu_reference(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
             "torch_threads": torch.get_num_threads()}
 
 
-def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32):
-    """kind "reference" when oracle/_ref was shipped with the push (then the port's figure rides along as `port`),
-    else the port."""
-    port = cpu_port(arch, key, b_cpu, n_lig, n_calls, steps=steps, max_threads=max_threads)
+def cpu_baseline(arch, key, b_cpu, n_lig, n_calls, steps=2, max_threads=32, port_batch=16, port_steps=2):
+    """kind "reference" when oracle/_ref was shipped with the push: the reference itself at batch `b_cpu` x `steps` reverse
+    steps (SURVEY.md 8d's protocol: the benchmark batch, k = 5 steps after one warm-up); the port's figure then rides along
+    as `port`, from a shorter sample (batch `port_batch` x `port_steps`), as a cross-check.  Without the archive: the port at
+    the full sample."""
+    from oracle import make_ref
+    have_ref = make_ref.available()
+    port = cpu_port(arch, key, port_batch if have_ref else b_cpu, n_lig, n_calls,
+                    steps=port_steps if have_ref else steps, max_threads=max_threads)
     try:
         ref = cpu_reference(arch, key, b_cpu, n_lig, n_calls, steps=steps, max_threads=max_threads)
     except Exception as exc:      # a broken archive must not cost the benchmark line
@@ -250,8 +255,21 @@ def call_flops(cfg, lv, plan, N, E, joint):
     return 2.0 * mac
 
 
-def secondary_workloads(device, n_lig_atoms):
-    """One timed chain (after one warm-up chain) of the other single-GPU configurations, so that the driver's record of
+def ref_flops(cfg, N, E, n_lig_nodes):
+    """FLOP of one EGNNDynamics.forward as the REFERENCE evaluates it (the literal graph, SURVEY.md 8d F_ref: every edge
+    MLP on every edge with its full first layer, every row in every stage) -- what the CPU baseline executes per call;
+    BASELINE.md 3.5 asks for 2 F_ref / t beside the F_min-based figure."""
+    H, L, S, J = cfg["hidden_nf"], cfg["n_layers"], cfg["inv_sublayers"], cfg["joint_nf"]
+    A = 2 + (cfg.get("edge_embedding_dim") or 0)
+    n_mlp = 1 if cfg["reflection_equivariant"] else 2
+    a, r = cfg["atom_nf"], cfg["residue_nf"]
+    mac = L * (E * (S + n_mlp) * ((2 * H + A) * H + H * H + H) + S * N * 3 * H * H) + 2 * N * (J + 1) * H + \
+        n_lig_nodes * 2 * (2 * a * a + 2 * a * J) + (N - n_lig_nodes) * 2 * (2 * r * r + 2 * r * J)
+    return 2.0 * mac
+
+
+def secondary_workloads(device, n_lig_atoms, steps=3):
+    """`steps` timed chains (after one warm-up chain) of the other single-GPU configurations, so that the driver's record of
     the default run holds them: BASELINE.json configs[1] (crossdock_ca_cond x 32), configs[4] on ONE GPU
     (moad_fullatom_joint x 64, RePaint resamplings = 2: 1000 EGNN calls) and the heterogeneous-pocket variant of
     configs[2] (3rfm / 5ndu alternating, every sample under its own rotation)."""
@@ -290,17 +308,20 @@ def secondary_workloads(device, n_lig_atoms):
         eng = model.dynamics.engine()
         lv0 = eng.level_stats(raw=True)
         t0 = time.perf_counter()
-        out_l = chain(200)[0]
+        for k in range(steps):
+            out_l = chain(200 + k)[0]
         torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+        dt = (time.perf_counter() - t0) / steps
         assert torch.isfinite(out_l).all()
         N = B * n_lig_atoms + pocket0["x"].shape[0]
         lv, plan = eng.level_stats(since=lv0), eng.last_plan()
-        call = call_flops(cfg, lv, plan, N, eng.edge_count(N), joint)
+        e_last = eng.edge_count(N)
+        call = call_flops(cfg, lv, plan, N, e_last, joint)
         whole = call * n_calls / dt / 1e12 if call else None
         out.append({"workload": workload, "pockets": pockets, "batch": B, "states": None if joint else "anchored",
                     "egnn_calls_per_chain": n_calls, "value": B / dt, "unit": "ligands/s", "ms_per_step": dt * 1e3,
-                    "steps": 1, "warmup": 1, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
+                    "steps": steps, "warmup": 1, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
+                    "reference_graph_tflops": ref_flops(cfg, N, e_last, B * n_lig_atoms) * n_calls / dt / 1e12,
                     "stage_radii": plan[0], "stage_ghost": plan[1],
                     "edge_granule16": "auto (EnVariationalDiffusion.granule16_auto): mask 0x%08x" %
                                       (eng._options.get(2, 0) & 0xFFFFFFFF)})
@@ -404,8 +425,8 @@ def main():
     ap.add_argument("--timesteps", type=int, default=None, help="DDPM steps (default: the config's 500)")
     ap.add_argument("--n-lig", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed reverse steps of the CPU baseline")
+    ap.add_argument("--cpu-batch", type=int, default=None, help="batch of the CPU baseline (default: the benchmark batch)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed reverse steps of the CPU baseline (SURVEY.md 8d: k = 5)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP-event timing of the dominant kernel on every k-th EGNN call (1 = every call)")
@@ -429,6 +450,7 @@ def main():
                          "as a secondary figure.")
     ap.add_argument("--no-other-leg", action="store_true", help="skip the secondary figure (the other state model)")
     ap.add_argument("--other-steps", type=int, default=5, help="timed chains of the secondary figure")
+    ap.add_argument("--secondary-steps", type=int, default=3, help="timed chains of every `other_workloads` leg")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the one-chain legs of the other single-GPU configurations (configs[1], configs[4] on one "
                          "GPU, heterogeneous pockets) that ride along with the default run")
@@ -450,6 +472,9 @@ def main():
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    if args.granule16 is not None and args.emulation:
+        raise SystemExit("--granule16 and --emulation exclude each other: the 16-edge-granule kernels have no emulated form, a chain "
+                         "would mix exact and emulated stages under one `dtype` label")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start one rank per GPU ourselves (the same launch the
         # driver uses) and hand the result through; rank 0 of the child job prints the JSON line
@@ -668,6 +693,10 @@ def main():
                 "kernel_share_of_wall": (kern_ms * args.time_every / (elapsed_s * 1e3)) if kern_n else None,
                 # the same roofline over the WHOLE call: algorithmic FLOP of everything a call evaluates / wall time
                 "whole_call_tflops": whole, "whole_call_frac": (whole / FP32_MATRIX_PEAK_TFLOPS) if whole else None,
+                # the same wall time priced with the work of the REFERENCE's literal graph (what the CPU
+                # baseline executes per call) -- not a hardware rate, may exceed the peak: the exact algebraic savings
+                "reference_graph_flops_per_call": ref_flops(cfg, N, e_last, B * args.n_lig),
+                "reference_graph_tflops": ref_flops(cfg, N, e_last, B * args.n_lig) * n_calls * n_chains / elapsed_s / 1e12,
                 "algorithmic_flops_per_call": call, "stage_radii": plan[0], "stage_ghost": plan[1],
                 # mean over the calls of the chain: nodes / edge-list slots with hop level <= r (r = 0: ligand rows,
                 # r = 4: everything); message stage g of G evaluates level <= G - g
@@ -689,7 +718,7 @@ def main():
         other_workloads = None
         if world == 1 and not args.no_other_workloads and args.workload == "crossdock_fullatom_cond" and \
                 args.pockets == "same" and args.timesteps is None and args.batch is None:
-            other_workloads = secondary_workloads(device, args.n_lig)
+            other_workloads = secondary_workloads(device, args.n_lig, steps=args.secondary_steps)
             try:
                 other_workloads.append(training_leg(device, args.n_lig))
             except Exception as exc:      # the training leg must not cost the benchmark line
@@ -697,7 +726,7 @@ def main():
                                         "error": repr(exc)[:300]})
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not joint:
-            cpu = cpu_baseline(arch, key, args.cpu_batch, args.n_lig, n_calls, steps=args.cpu_steps,
+            cpu = cpu_baseline(arch, key, args.cpu_batch or B, args.n_lig, n_calls, steps=args.cpu_steps,
                                max_threads=args.cpu_threads)
             if not args.no_config0:
                 cpu["config0"] = cpu_config0(max_threads=args.cpu_threads)
@@ -733,6 +762,35 @@ def main():
             "backend": torch.distributed.get_backend() if world > 1 else None,
             "host_cores": os.cpu_count(),
         }
+
+        def r3(v):
+            return None if v is None else float(f"{v:.4g}")
+
+        def wl(name, pockets=None):
+            for w_ in other_workloads or []:
+                if w_.get("workload") == name and (pockets is None or w_.get("pockets") == pockets):
+                    return w_
+            return None
+        # LAST key, compact (< 1200 characters): the line's secondary figures where the driver's record (which keeps the
+        # tail of the output) can see them
+        ca, mixed_w, joint_w = wl("crossdock_ca_cond"), wl("crossdock_fullatom_cond", "mixed"), wl("moad_fullatom_joint")
+        train_w = wl("training step: crossdock_fullatom_cond")
+        summ = {"value": r3(value), "dom_frac": r3(roofline["frac"]), "whole_frac": r3(roofline["whole_call_frac"]),
+                "x_cpu": r3(line["speedup_vs_cpu_baseline"])}
+        if other is not None:
+            summ[other["states"]] = {"value": r3(other["value"]), "dom_frac": r3(other["roofline"]["frac"]),
+                                     "whole_frac": r3(other["roofline"]["whole_call_frac"])}
+        if emulated is not None:
+            summ["emulated"] = {"value": r3(emulated["value"]), "bf16_frac": r3(emulated["roofline"]["frac"]), "dtype": "f32-emulated(bf16x3,6)"}
+        for k_, w_ in (("ca32", ca), ("mixed", mixed_w), ("joint", joint_w)):
+            if w_ is not None:
+                summ[k_] = {"value": r3(w_.get("value")), "whole_frac": r3(w_.get("whole_call_frac"))}
+                if w_.get("emulated"):
+                    summ[k_]["emulated"] = r3(w_["emulated"].get("value"))
+        if train_w is not None and train_w.get("value") is not None:
+            summ["train"] = {"ms": r3(train_w["ms_per_step"]), "frac": r3(train_w["roofline"]["frac"])}
+        line["summary"] = summ
+        assert len(json.dumps(summ)) < 1200
         print(json.dumps(line), flush=True)
     if world > 1:
         barrier()

@@ -17,22 +17,9 @@ import ctypes as C
 import torch.nn.functional as F
 
 from . import _lib
-from .en_diffusion import EnVariationalDiffusion, num_nodes_to_batch_mask, seg_mean, seg_sum
+from .en_diffusion import EnVariationalDiffusion, _chain, num_nodes_to_batch_mask, seg_mean, seg_sum
 
 __all__ = ["ConditionalDDPM", "SimpleConditionalDDPM"]
-
-
-def _chain(fn):
-    """Sampling entry point: whatever happens, the engine's pocket frame of this chain is released."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapped(self, *args, **kwargs):
-        try:
-            return fn(self, *args, **kwargs)
-        finally:
-            self._end_chain()
-    return wrapped
 
 
 class ConditionalDDPM(EnVariationalDiffusion):
@@ -169,9 +156,13 @@ class ConditionalDDPM(EnVariationalDiffusion):
         gamma_0 = self.gamma(t0)
         sigma_x = self.SNR(-0.5 * gamma_0)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        net, _, _ = self._dyn(z0_lig.contiguous(), xh0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
-                              batch_size, status, False)
-        self._check_status(status)
+        try:
+            net, _, _ = self._dyn(z0_lig.contiguous(), xh0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
+                                  batch_size, status, False)
+            self._check_status(status)
+        finally:
+            if not _in_chain:
+                self._end_chain()
         if fix_noise:
             raise NotImplementedError("fix_noise option isn't implemented yet")
         xh_lig = self.compute_x_pred(net, z0_lig, gamma_0, lig_mask).contiguous()

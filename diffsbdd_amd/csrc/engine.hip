@@ -118,9 +118,9 @@ struct dsbdd_engine {
   int level_rows = 0;  // DSBDD_LEVEL_ROWS=1: all-row stages of a pruned call walk the level list (measured slower, see rows_of)
   int fold_scan = 1;   // DSBDD_FOLD_SCAN: 1 (default) = the level ordering's exclusive scans are computed by level_place_kernel
                        // itself (no single-workgroup level_scan_kernel launch) and the block-0 sample mean rides in levels_kernel;
-                       // 0 = the separate launches; 2 = ALSO the radius graph's scan folded into its fill pass (segment totals
-                       // by integer atomics in the count pass) -- measured SLOWER: 19.8 k atomics on 128 counters take 129 us
-                       // (edges_kernel<false> 12 -> 129 us, profiles/r5k_*), kept for the record only
+                       // 0 = the separate launches.  (The same fold for the radius graph's own scan -- segment totals by
+                       // integer atomics in the count pass -- was measured SLOWER in round 5, 19.8 k atomics on 128 counters:
+                       // edges_kernel<false> 12 -> 129 us, profiles/r5k_*; its code was removed in round 6.)
   int lig_head = 1;    // DSBDD_LIG_HEAD=0: embedding_out / decoder / finalize as three launches also for ligand-only calls
   int edge_bperm = 1;  // edge_wave.h reads the B operand with 16-byte LDS loads from those copies (DSBDD_EDGE_BPERM=0: off)
   // optional timing of the dominant kernel (GCL edge stage) with HIP events
@@ -229,7 +229,7 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
                             int* act_flag = nullptr, int* scan_tmp = nullptr, int* seg_base = nullptr,
-                            const EdgeList2* list2 = nullptr, int id_offset = 0, int* lvl = nullptr, bool fold = false);
+                            const EdgeList2* list2 = nullptr, int id_offset = 0, int* lvl = nullptr);
 
 extern "C" {
 
@@ -264,7 +264,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   const char* prn = getenv("DSBDD_PRUNE");
   if (prn && atoi(prn) == 0) e->prune = 0;
   if (const char* lh = getenv("DSBDD_LIG_HEAD")) e->lig_head = atoi(lh) != 0;
-  if (const char* fs = getenv("DSBDD_FOLD_SCAN")) e->fold_scan = atoi(fs) < 0 ? 0 : (atoi(fs) > 2 ? 2 : atoi(fs));
+  if (const char* fs = getenv("DSBDD_FOLD_SCAN")) e->fold_scan = atoi(fs) > 0 ? 1 : 0;
   if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
   if (const char* fk = getenv("DSBDD_FORK")) e->fork_front = atoi(fk) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
@@ -670,7 +670,7 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
                             const int* node_batch, const int* lig_off, const int* poc_off, int* deg,
                             int* row_ptr, int* erow, int* ecol, float* ed0, int64_t cap, int* status,
                             int* act_flag, int* scan_tmp, int* seg_base, const EdgeList2* list2, int id_offset,
-                            int* lvl, bool fold) {
+                            int* lvl) {
   const int waves_per_block = kThreads / 64;
   int blocks = (N + waves_per_block - 1) / waves_per_block;
   if (blocks > 4096) blocks = 4096;
@@ -679,24 +679,16 @@ static int build_edges_impl(hipStream_t s, const float* x, int n_lig, int N, int
   // with scan_tmp / seg_base: every (sample, node set) segment of the edge list starts at a wave-tile
   // boundary (graph.h scan_kernel); without: a compact list (the public dsbdd_build_edges)
   const int aligned = scan_tmp && seg_base;
-  // fold (aligned lists of a forward call): seg_base holds the segments' raw totals, zeroed by prep_assemble_kernel and
-  // accumulated by the count pass; the fill pass computes every row's position itself -- no scan_kernel launch
-  fold = fold && aligned;
-  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, (aligned && !fold) ? seg_base : nullptr, fold ? seg_base : nullptr};
+  SegAlign sg{node_batch, lig_off, poc_off, n_lig, B, scan_tmp, aligned ? seg_base : nullptr};
   EdgeList2 l2{};
-  if (list2 && aligned) {
-    l2 = *list2;
-    if (fold) { l2.seg.seg_tot = l2.seg.seg_base; l2.seg.seg_base = nullptr; }
-  }
+  if (list2 && aligned) l2 = *list2;
   hipLaunchKernelGGL((edges_kernel<false>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     (float*)nullptr, 0, status, act_flag, fold ? sg : SegAlign{}, (int*)nullptr, l2, 0, lvl);
+                     (float*)nullptr, 0, status, act_flag, SegAlign{}, (int*)nullptr, l2, 0, lvl);
   HIP_TRY(hipGetLastError());
-  if (!fold) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg,
-                       (const int*)l2.deg, l2.row_ptr, l2.seg);
-    HIP_TRY(hipGetLastError());
-  }
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)deg, row_ptr, N, sg,
+                     (const int*)l2.deg, l2.row_ptr, l2.seg);
+  HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL((edges_kernel<true>), dim3(blocks), dim3(kThreads), 0, s, x, node_batch, lig_off,
                      poc_off, n_lig, N, cut, deg, (const int*)row_ptr, erow, ecol, ed0, (int)cap, status,
                      (int*)nullptr, sg, row_ptr, l2, id_offset, (int*)nullptr);
@@ -780,11 +772,9 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
   {
     int work = N > B + 1 ? N : B + 1;
     if (work < 2 * B) work = 2 * B;
-    const bool fold = e->fold_scan >= 2 && !ext;
     hipLaunchKernelGGL(prep_assemble_kernel, dim3((work + 255) / 256), dim3(256), 0, s, mask_lig, nlig, mask_pocket,
                        (int)n_pocket, B, e->node_batch, e->lig_off, e->poc_off, e->tile_ctr, xh_lig, dl, xh_pocket, dp,
-                       t, (int)t_count, e->x, e->x_in, e->h0, J, JP, fold ? e->seg_base : (int*)nullptr,
-                       fold ? e->seg_base2 : (int*)nullptr);
+                       t, (int)t_count, e->x, e->x_in, e->h0, J, JP);
     HIP_TRY(hipGetLastError());
   }
   // ---- two independent chains at the head of a call: A = encoders -> embedding (-> ghost-row features), needs only the
@@ -864,7 +854,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     int rc = build_edges_impl(s, e->x, nlig, N, B, c, e->node_batch, e->lig_off, e->poc_off, e->deg,
                               e->row_ptr, e->erow, e->ecol, e->ed0, e->cap_edges, status,
                               subset ? e->act_flag : nullptr, e->scan_tmp, e->seg_base,
-                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr, e->fold_scan >= 2);
+                              split0 ? &l2 : nullptr, 0, prune ? e->lvl : nullptr);
     if (rc) return rc;
     if (prune) {
       LevelArgs la{e->node_batch, e->lig_off, e->poc_off, nlig, B, e->lvl, e->deg, e->row_ptr, e->erow, e->ecol,
@@ -1061,7 +1051,8 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
                            G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub), w2tp16_of(blk, sub), w2e_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
       // 16-edge-granule variant of this stage (engine option; never for block 0's two-list launch of a framed call)
-      const bool g16 = ((e->granule16 >> (g & 15)) & 1u) && !(split0 && blk == 0 && sub == 0);
+      // (no emulated 16-edge kernel: with DSBDD_OPT_EMU the mask is ignored, a chain never mixes exact and emulated stages)
+      const bool g16 = ((e->granule16 >> (g & 15)) & 1u) && !(split0 && blk == 0 && sub == 0) && !e->emu;
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
       ea.agg = e->agg; ea.agg_head = e->agg_head; ea.tile_ctr = e->tile_ctr;
       ea.norm_factor = c.normalization_factor;
@@ -1224,7 +1215,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
       ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
       ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.xagg_head = e->xagg_head;
-      const bool c16 = (e->granule16 >> (16 + (blk & 15))) & 1u;          // 16-edge-granule variant of this stage
+      const bool c16 = ((e->granule16 >> (16 + (blk & 15))) & 1u) && !e->emu;   // 16-edge-granule variant of this stage
       ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = (size_t)(c16 ? e->cap_tiles16 : e->cap_tiles) * 4;
       ea.tile_ctr = e->tile_ctr; ea.norm_factor = c.normalization_factor;
       ea.pass_split = c16 ? 1 : e->coord_split;

@@ -49,11 +49,6 @@ struct SegAlign {
   int n_lig; int B;
   int* scan_tmp;   // [n + 1] plain exclusive scan
   int* seg_base;   // [2B + 1]
-  // round 5 ("folded scan", forward calls of the engine): raw edge totals of the 2B segments, accumulated by the count
-  // pass with integer atomics (order-free: exact) from zero; the fill pass then finds a row's position itself -- a wave
-  // sum over the earlier segments' padded totals + a wave sum over the earlier rows of its own segment -- and no
-  // scan_kernel launch (one workgroup, 15.6 us per call) sits between the two passes.  nullptr: the scan_kernel path.
-  int* seg_tot;    // [2B]
 };
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -95,37 +90,6 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     // segment's earlier rows (plain scan differences); compact layout: the plain scan itself
     int base = 0;
     int base2 = 0;
-    if (FILL && seg.seg_tot) {
-      // folded scan: this row's position from the segment totals of the count pass and the degrees of the earlier rows
-      // of its own segment (wave sums of integers)
-      const int k = il ? b : seg.B + b;
-      const int first = il ? lig_off[b] : n_lig + poc_off[b];
-      const bool two = l2.deg != nullptr;
-      int sb = 0, sb2 = 0, pre = 0, pre2 = 0;
-      for (int k0 = 0; k0 < k; k0 += 64) {
-        const int kk = k0 + lane;
-        if (kk < k) {
-          sb += (seg.seg_tot[kk] + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
-          if (two) sb2 += (l2.seg.seg_tot[kk] + kEdgeAlign - 1) & ~(kEdgeAlign - 1);
-        }
-      }
-      for (int r0 = first; r0 < i; r0 += 64) {
-        const int r = r0 + lane;
-        if (r < i) { pre += deg[r]; if (two) pre2 += l2.deg[r]; }
-      }
-      sb = wave_sum_i(sb); pre = wave_sum_i(pre);
-      base = sb + pre;
-      if (lane == 0) row_ptr_out[i] = base;
-      if (two) {
-        sb2 = wave_sum_i(sb2); pre2 = wave_sum_i(pre2);
-        base2 = sb2 + pre2;
-        if (lane == 0) l2.row_ptr[i] = base2;
-      }
-      if (i == n_nodes - 1 && lane == 0) {   // the last node closes the list: padded total (every later segment is empty)
-        row_ptr_out[n_nodes] = sb + ((seg.seg_tot[k] + kEdgeAlign - 1) & ~(kEdgeAlign - 1));
-        if (two) l2.row_ptr[n_nodes] = sb2 + ((l2.seg.seg_tot[k] + kEdgeAlign - 1) & ~(kEdgeAlign - 1));
-      }
-    } else {
     if (FILL) {
       if (seg.seg_base) {
         const int k = il ? b : seg.B + b;
@@ -141,7 +105,6 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       const int first = il ? lig_off[b] : n_lig + poc_off[b];
       base2 = l2.seg.seg_base[k] + l2.seg.scan_tmp[i] - l2.seg.scan_tmp[first];
       if (lane == 0) l2.row_ptr[i] = base2;
-    }
     }
     int cnt = 0, cnt_lig = 0;
 #pragma unroll 1
@@ -179,11 +142,6 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
     if (!FILL && lane == 0) {
       deg[i] = cnt;
       if (l2.deg) l2.deg[i] = il ? cnt : cnt_lig;
-      if (seg.seg_tot) {
-        const int k = il ? b : seg.B + b;
-        atomicAdd(&seg.seg_tot[k], cnt);
-        if (l2.deg) atomicAdd(&l2.seg.seg_tot[k], il ? cnt : cnt_lig);
-      }
       // "active" for the coordinate MLPs in pocket-conditioning mode: ligand nodes and
       // pocket nodes that are a column of some ligand-row edge (graph is symmetric)
       if (act_flag) act_flag[i] = (il || cnt_lig > 0) ? 1 : 0;
@@ -191,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void edges_kernel(
       if (lvl) lvl[i] = il ? 0 : (cnt_lig > 0 ? 1 : kLevels - 1);
     }
     if (FILL && lane == 0 && base + cnt > e_cap) atomicOr(status, 2);
-    if (FILL && (seg.seg_base || seg.seg_tot)) {
+    if (FILL && seg.seg_base) {
       // the last row of a (sample, node set) segment fills the segment up to the next wave-tile
       // boundary with inactive entries (row = -1), see scan_kernel
       const int seg_last = (il ? lig_off[b + 1] : n_lig + poc_off[b + 1]) - 1;
@@ -691,14 +649,9 @@ __global__ void assemble_kernel(const float* xh_lig, int dl, const float* xh_poc
 __global__ void prep_assemble_kernel(const int64_t* mask_lig, int n_lig, const int64_t* mask_poc, int n_poc, int B,
                                      int* node_batch, int* lig_off, int* poc_off, int* tile_ctr, const float* xh_lig,
                                      int dl, const float* xh_poc, int dp, const float* t, int t_count, float* x,
-                                     float* x_in, float* h0, int J, int JP, int* seg_tot_a = nullptr,
-                                     int* seg_tot_b = nullptr) {
+                                     float* x_in, float* h0, int J, int JP) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (tile_ctr && i < kTileCtrInts) tile_ctr[i] = 0;
-  if (i < 2 * B) {                     // segment totals of the radius graph's count pass (folded scan)
-    if (seg_tot_a) seg_tot_a[i] = 0;
-    if (seg_tot_b) seg_tot_b[i] = 0;
-  }
   if (i <= B) {
     lig_off[i] = lower_bound_i64(mask_lig, n_lig, i);
     poc_off[i] = lower_bound_i64(mask_poc, n_poc, i);

@@ -249,6 +249,20 @@ class StepCoefficients:
         return float(alpha_ts), float(torch.sqrt(sigma2))
 
 
+def _chain(fn):
+    """Sampling entry point: whatever happens, the chain state (engine pocket frame, edge bound, prefilled time word) of
+    this call is released."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            self._end_chain()
+    return wrapped
+
+
 class EnVariationalDiffusion(nn.Module):
     """The E(n) diffusion module (joint ligand + pocket)."""
 
@@ -722,9 +736,14 @@ class EnVariationalDiffusion(nn.Module):
         return torch.tensor(rep, dtype=torch.int64)
 
     def _end_chain(self):
+        """End of a sampling call: the pocket frame is released and the module leaves the "in chain" state, so that a
+        denoiser call outside a chain validates the packed weights again (`_dyn`: in_chain) and no stale prefilled time
+        word survives."""
         if getattr(self, "_framed", False):
             self.dynamics.engine().clear_pocket_frame()
             self._framed = False
+        self._chain = None
+        self._t_prefilled = None
 
     def _dyn(self, z_lig, z_pocket, t_value, lig_mask, pocket_mask, batch, status, want_pocket):
         """One denoiser call.  t and the eps outputs live in persistent buffers keyed by the
@@ -780,6 +799,7 @@ class EnVariationalDiffusion(nn.Module):
             self.residue_nf, float(co.alpha_ts[s]), float(co.c_eps[s]), float(co.sigma[s]), 1),
             "dsbdd_joint_reverse_update")
 
+    @_chain
     def sample_p_zs_given_zt(self, s, t, zt_lig, zt_pocket, ligand_mask, pocket_mask, fix_noise=False):
         """Functional form with the reference's signature: s, t are [B,1]
         tensors (all entries equal, as every caller passes them)."""
@@ -849,9 +869,13 @@ class EnVariationalDiffusion(nn.Module):
         gamma_0 = self.gamma(t0)
         sigma_x = self.SNR(-0.5 * gamma_0)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        e_l, e_p, _ = self._dyn(z0_lig.contiguous(), z0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
-                                batch_size, status, True)
-        self._check_status(status)
+        try:
+            e_l, e_p, _ = self._dyn(z0_lig.contiguous(), z0_pocket.contiguous(), 0.0, lig_mask, pocket_mask,
+                                    batch_size, status, True)
+            self._check_status(status)
+        finally:
+            if not _in_chain:
+                self._end_chain()
         xh_l = self.compute_x_pred(e_l, z0_lig, gamma_0, lig_mask).contiguous()
         xh_p = self.compute_x_pred(e_p, z0_pocket, gamma_0, pocket_mask).contiguous()
         # xh = mu + sigma_x * eps, eps COM-free (en_diffusion.py:263-288); one t for the whole batch
@@ -880,6 +904,7 @@ class EnVariationalDiffusion(nn.Module):
 
     # ---- sampling (en_diffusion.py:580-651) --------------------------------------------------------
     @torch.no_grad()
+    @_chain
     def sample(self, n_samples, num_nodes_lig, num_nodes_pocket, return_frames=1, timesteps=None,
                device='cpu'):
         timesteps = self.T if timesteps is None else timesteps
@@ -930,7 +955,41 @@ class EnVariationalDiffusion(nn.Module):
             cur += step
         return sched[::-1]
 
+    def _joint_inpaint_iteration(self, s, co, z_l, z_p, zk_l, zk_p, xh0_l, xh0_p, lfix, pfix, lm, pm, n, status,
+                                 jump_to=None, frame_out=None):
+        """One iteration of the RePaint loop body (en_diffusion.py:742-809), in place on the state buffers z_l / z_p
+        (stable pointers: the engine replays its captured graph): noise draws for the known part q(z_s | x) (:742-746),
+        one reverse step of the whole state (one EGNN call), then ONE kernel for COM alignment over the fixed nodes,
+        the blend and -- at the end of a resampling segment (`jump_to` = s + jump_length) -- the jump back
+        q(z_t | z_s) (:793-809).  `frame_out` = (out_lig, out_pocket, idx): the blended state is a frame of the
+        chain visualisation; the jump then runs as its own launch behind the copy."""
+        lib = _lib.load()
+
+        def repaint(n1, n2, a_ts, s_ts):
+            _lib.check(lib.dsbdd_joint_repaint_update(
+                self._cs(z_l), z_l.data_ptr(), z_p.data_ptr(), zk_l.data_ptr(), zk_p.data_ptr(),
+                xh0_l.data_ptr(), xh0_p.data_ptr(), lfix.data_ptr(), pfix.data_ptr(), n1[0].data_ptr(),
+                n1[1].data_ptr(), n2[0].data_ptr() if n2 else None, n2[1].data_ptr() if n2 else None,
+                lm.data_ptr(), pm.data_ptr(), lm.numel(), pm.numel(), n, self.atom_nf, self.residue_nf,
+                float(co.alpha[s]), float(co.sigma_t[s]), a_ts, s_ts, 1 if n2 else 0),
+                "dsbdd_joint_repaint_update")
+
+        n1 = self._joint_noise_raw(lm, pm, n)                   # known part: q(z_s | x)
+        self._joint_step(s, co, z_l, z_p, lm, pm, n, status)    # unknown part: one reverse step
+        jump = jump_to is not None
+        a_ts, s_ts = co.pair(s, jump_to) if jump else (1.0, 0.0)
+        if jump and frame_out is None:
+            repaint(n1, self._joint_noise_raw(lm, pm, n), a_ts, s_ts)
+        else:
+            repaint(n1, None, 1.0, 0.0)
+            if frame_out is not None:
+                out_lig, out_pocket, idx = frame_out
+                out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_l, z_p)
+            if jump:
+                self._joint_gauss_(z_l, z_p, lm, pm, n, a_ts, s_ts, True)
+
     @torch.no_grad()
+    @_chain
     def inpaint(self, ligand, pocket, lig_fixed, pocket_fixed, resamplings=1, jump_length=1,
                 return_frames=1, timesteps=None):
         timesteps = self.T if timesteps is None else timesteps
@@ -968,39 +1027,20 @@ class EnVariationalDiffusion(nn.Module):
         out_lig = torch.zeros((return_frames,) + z_l.size(), device=dev)
         out_pocket = torch.zeros((return_frames,) + z_p.size(), device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        lib = _lib.load()
-
-        def repaint(s, n1, n2, a_ts, s_ts):
-            _lib.check(lib.dsbdd_joint_repaint_update(
-                self._cs(z_l), z_l.data_ptr(), z_p.data_ptr(), zk_l.data_ptr(), zk_p.data_ptr(),
-                xh0_l.data_ptr(), xh0_p.data_ptr(), lfix.data_ptr(), pfix.data_ptr(), n1[0].data_ptr(),
-                n1[1].data_ptr(), n2[0].data_ptr() if n2 else None, n2[1].data_ptr() if n2 else None,
-                lm.data_ptr(), pm.data_ptr(), lm.numel(), pm.numel(), n, self.atom_nf, self.residue_nf,
-                float(co.alpha[s]), float(co.sigma_t[s]), a_ts, s_ts, 1 if n2 else 0),
-                "dsbdd_joint_repaint_update")
 
         schedule = self.get_repaint_schedule(resamplings, jump_length, timesteps)
         s = timesteps - 1
         for i, n_denoise_steps in enumerate(schedule):
             for j in range(n_denoise_steps):
-                # the state buffers z_l / z_p are updated in place (stable pointers: the engine replays
-                # its captured graph); per iteration: noise draws, one EGNN call, two small kernels
-                n1 = self._joint_noise_raw(lm, pm, n)           # known part: q(z_s | x), en_diffusion.py:742-746
-                self._joint_step(s, co, z_l, z_p, lm, pm, n, status)    # unknown part: one reverse step
                 jump = j == n_denoise_steps - 1 and i < len(schedule) - 1
                 frame = (n_denoise_steps > jump_length or i == len(schedule) - 1) and \
                     (s * return_frames) % timesteps == 0
-                a_ts, s_ts = co.pair(s, s + jump_length) if jump else (1.0, 0.0)
-                if jump and not frame:
-                    # COM alignment, blend and the jump back q(z_t | z_s) (en_diffusion.py:752-809) in one kernel
-                    repaint(s, n1, self._joint_noise_raw(lm, pm, n), a_ts, s_ts)
-                else:
-                    repaint(s, n1, None, 1.0, 0.0)
-                    if frame:
-                        idx = (s * return_frames) // timesteps
-                        out_lig[idx], out_pocket[idx] = self.unnormalize_z(z_l, z_p)
-                    if jump:
-                        self._joint_gauss_(z_l, z_p, lm, pm, n, a_ts, s_ts, True)
+                frame_out = None
+                if frame:
+                    idx = (s * return_frames) // timesteps
+                    frame_out = (out_lig, out_pocket, idx)
+                self._joint_inpaint_iteration(s, co, z_l, z_p, zk_l, zk_p, xh0_l, xh0_p, lfix, pfix, lm, pm, n, status,
+                                              jump_to=s + jump_length if jump else None, frame_out=frame_out)
                 if jump:
                     s = s + jump_length
                 s -= 1

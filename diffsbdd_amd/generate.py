@@ -208,6 +208,16 @@ class LigandGenerator:
             x, atom_type, lig_mask = x[keep], atom_type[keep], lig_mask[keep]
         return x, atom_type, lig_mask
 
+    def _ligand_sizes(self, num_nodes_lig, n_nodes_bias=0, n_nodes_min=0):
+        """Bias and minimum of generate_ligands (lightning_modules.py:806-811).  With virtual nodes every ligand already
+        has `max_num_nodes` slots (the validation-time rule, :519-520, which this package uses for generation too --
+        INTEGRATION.md "virtual nodes"); a positive bias must not ask for more nodes than any training sample had, so the
+        sizes stay <= max_num_nodes."""
+        n = torch.clamp(torch.as_tensor(num_nodes_lig, dtype=torch.int64) + n_nodes_bias, min=n_nodes_min)
+        if self.virtual_nodes:
+            n = torch.clamp(n, max=self.max_num_nodes)
+        return n
+
     @torch.no_grad()
     def sample_for_pocket(self, pocket, n_samples, num_nodes_lig=None, timesteps=None,
                           n_nodes_bias=0, n_nodes_min=0, **kwargs):
@@ -219,8 +229,7 @@ class LigandGenerator:
                 num_nodes_lig = torch.full((n_samples,), self.max_num_nodes, dtype=torch.int64)
             else:
                 num_nodes_lig = self.ddpm.size_distribution.sample_conditional(n1=None, n2=pocket["size"])
-        num_nodes_lig = torch.as_tensor(num_nodes_lig, dtype=torch.int64)
-        num_nodes_lig = torch.clamp(num_nodes_lig + n_nodes_bias, min=n_nodes_min)
+        num_nodes_lig = self._ligand_sizes(num_nodes_lig, n_nodes_bias, n_nodes_min)
         if type(self.ddpm) == EnVariationalDiffusion:
             lig_mask = num_nodes_to_batch_mask(len(num_nodes_lig), num_nodes_lig, self.device)
             ligand = {"x": torch.zeros((len(lig_mask), self.x_dims), device=self.device),

@@ -225,9 +225,14 @@ int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghos
  * exact fp32 on v_mfma_f32_32x32x2_f32.  6 / 9 = fp32 EMULATED on the bf16 matrix cores: both operands split exactly into
  * three bf16 terms, the 6 largest (or all 9) partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16
  * (csrc/edge_wave.h, "emulated path").  Same inputs, same edge order, same aggregation protocol; the results differ from
- * the exact path in rounding only (error vs a float64 evaluation not larger than the exact path's own:
- * profiles/r5_emu_error.md) and every parity test of the exact path holds at the same tolerance
- * (tests/test_gpu_emu.py).  Part of a chain's definition like the granule mask: never changed by the engine. */
+ * the exact path in rounding only (error vs a float64 evaluation <= 2 x the exact path's own -- the tested bound,
+ * tests/test_gpu_emu.py; measured <= 1.1 x: profiles/r5_emu_error.md) and every parity test of the exact path holds at
+ * the same tolerance.  Part of a chain's definition like the granule mask: never changed by the engine.  The
+ * 16-edge-granule kernels and the training kernels have no emulated form: with DSBDD_OPT_EMU != 0 the DSBDD_OPT_GRANULE16
+ * mask is IGNORED (every edge stage of a forward call runs the emulated 32-edge kernel, so a chain never mixes exact and
+ * emulated stages); the training step (dsbdd_train_*) always computes in exact fp32.
+ * (Round 5 also made the fma of cond_update_kernel / cond_repaint_kernel explicit: the un-fused reverse-step path
+ * differs from earlier rounds' results by up to 1 ulp.) */
 enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1, DSBDD_OPT_GRANULE16 = 2, DSBDD_OPT_EMU = 3 };
 int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value);
 /* current value of an option (what the environment / set_option left); DSBDD_ERR_ARG (< 0) for an unknown id */

@@ -454,6 +454,35 @@ def joint_sample_p_zt_given_zs(m, zs_lig, zs_pocket, lig_mask, pocket_mask, g_t,
     return _joint_remove_mean(m, zt_l, zt_p, lig_mask, pocket_mask)
 
 
+def joint_inpaint_iteration(m, s, timesteps, z_l, z_p, xh0_l, xh0_p, lig_fixed, pocket_fixed, lm, pm, noise,
+                            jump_to=None):
+    """One iteration of EnVariationalDiffusion.inpaint's loop body, en_diffusion.py:742-809: the known part noised
+    to level s (:745), one reverse step of the whole state (:749), COM alignment over the fixed nodes (:752-772),
+    blend (:775-778) and -- at the end of a resampling segment (`jump_to` = s + jump_length) -- the jump back
+    q(z_t | z_s) (:793-809).  xh0_*: the normalised input centred at the COM of the known nodes."""
+    nd = m.n_dims
+    n = int(max(lm.max(), pm.max())) + 1
+    lfb, pfb = lig_fixed.bool().view(-1), pocket_fixed.bool().view(-1)
+    lf, pf = lig_fixed.view(-1, 1).to(z_l.dtype), pocket_fixed.view(-1, 1).to(z_l.dtype)
+    s_arr = torch.full((n, 1), float(s)) / timesteps
+    t_arr = torch.full((n, 1), float(s + 1)) / timesteps
+    g_s = m.g(s_arr)
+    zk_l, zk_p = joint_noised_representation(m, xh0_l, xh0_p, lm, pm, g_s, noise)  # :745
+    zu_l, zu_p = joint_sample_p_zs_given_zt(m, s_arr, t_arr, z_l, z_p, lm, pm, noise)  # :749
+    idx = torch.cat((lm[lfb], pm[pfb]))
+    com_n = _seg_mean(torch.cat((zk_l[:, :nd][lfb], zk_p[:, :nd][pfb])), idx, n)
+    com_d = _seg_mean(torch.cat((zu_l[:, :nd][lfb], zu_p[:, :nd][pfb])), idx, n)
+    dx = com_d - com_n
+    zk_l = torch.cat([zk_l[:, :nd] + dx[lm], zk_l[:, nd:]], 1)
+    zk_p = torch.cat([zk_p[:, :nd] + dx[pm], zk_p[:, nd:]], 1)
+    z_l = zk_l * lf + zu_l * (1 - lf)                            # :775-778
+    z_p = zk_p * pf + zu_p * (1 - pf)
+    if jump_to is not None:                                      # :793-809
+        t_arr2 = torch.full((n, 1), float(jump_to)) / timesteps
+        z_l, z_p = joint_sample_p_zt_given_zs(m, z_l, z_p, lm, pm, m.g(t_arr2), g_s, noise)
+    return z_l, z_p
+
+
 def joint_inpaint(m, ligand, pocket, lig_fixed, pocket_fixed, noise, resamplings=1,
                   jump_length=1, timesteps=None):
     """EnVariationalDiffusion.inpaint, en_diffusion.py:676-837 (return_frames=1)."""
@@ -474,30 +503,15 @@ def joint_inpaint(m, ligand, pocket, lig_fixed, pocket_fixed, noise, resamplings
     xh0_l = torch.cat([xh0_l[:, :nd] - mean_known[lm], xh0_l[:, nd:]], 1)
     xh0_p = torch.cat([xh0_p[:, :nd] - mean_known[pm], xh0_p[:, nd:]], 1)
     z_l, z_p = joint_noise(m, lm, pm, noise)                             # :719
-    lf, pf = lig_fixed.to(z_l.dtype), pocket_fixed.to(z_l.dtype)
     sched = repaint_schedule(resamplings, jump_length, timesteps)
     s = timesteps - 1
     for i, n_steps in enumerate(sched):
         for j in range(n_steps):
-            s_arr = torch.full((n, 1), float(s)) / timesteps
-            t_arr = torch.full((n, 1), float(s + 1)) / timesteps
-            g_s = m.g(s_arr)
-            zk_l, zk_p = joint_noised_representation(m, xh0_l, xh0_p, lm, pm, g_s, noise)  # :745
-            zu_l, zu_p = joint_sample_p_zs_given_zt(m, s_arr, t_arr, z_l, z_p, lm, pm, noise)  # :749
-            idx = torch.cat((lm[lfb], pm[pfb]))
-            com_n = _seg_mean(torch.cat((zk_l[:, :nd][lfb], zk_p[:, :nd][pfb])), idx, n)
-            com_d = _seg_mean(torch.cat((zu_l[:, :nd][lfb], zu_p[:, :nd][pfb])), idx, n)
-            dx = com_d - com_n
-            zk_l = torch.cat([zk_l[:, :nd] + dx[lm], zk_l[:, nd:]], 1)
-            zk_p = torch.cat([zk_p[:, :nd] + dx[pm], zk_p[:, nd:]], 1)
-            z_l = zk_l * lf + zu_l * (1 - lf)                            # :775-778
-            z_p = zk_p * pf + zu_p * (1 - pf)
-            if j == n_steps - 1 and i < len(sched) - 1:                  # :793-809
-                t = s + jump_length
-                t_arr2 = torch.full((n, 1), float(t)) / timesteps
-                z_l, z_p = joint_sample_p_zt_given_zs(
-                    m, z_l, z_p, lm, pm, m.g(t_arr2), m.g(s_arr), noise)
-                s = t
+            jump = j == n_steps - 1 and i < len(sched) - 1
+            z_l, z_p = joint_inpaint_iteration(m, s, timesteps, z_l, z_p, xh0_l, xh0_p, lig_fixed, pocket_fixed,
+                                               lm, pm, noise, jump_to=s + jump_length if jump else None)
+            if jump:
+                s = s + jump_length
             s -= 1
     return _joint_final(m, z_l, z_p, lm, pm, n, noise)
 

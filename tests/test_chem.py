@@ -126,8 +126,12 @@ def test_virtual_nodes_checkpoints_build_like_the_reference():
         xh[torch.arange(5), 3 + torch.tensor([0, 10, 2, 10, 10])] = 1.0
         x, at, m = gen._drop_virtual(xh, torch.tensor([0, 0, 0, 1, 1]))
         assert at.tolist() == [0, 2] and m.tolist() == [0, 0] and x.shape == (2, 3)
+        # a positive size bias never asks for more nodes than max_num_nodes; the minimum still applies
+        assert gen._ligand_sizes(torch.tensor([39, 39, 20]), n_nodes_bias=5).tolist() == [39, 39, 25]
+        assert gen._ligand_sizes(torch.tensor([3]), n_nodes_bias=-2, n_nodes_min=4).tolist() == [4]
     plain = LigandGenerator(**{k: _hp("small_cond", "pocket_conditioning", "full-atom")[k] for k in keys}, device="cpu")
     assert plain.atom_nf == 10 and plain.virtual_atom is None and len(plain.dataset_info["atom_decoder"]) == 10
+    assert plain._ligand_sizes(torch.tensor([39]), n_nodes_bias=5).tolist() == [44]      # no virtual nodes: the reference's rule
 
 
 def test_pocket_selection_like_generate_ligands(tmp_path):
@@ -294,3 +298,24 @@ def test_generate_for_several_pockets_in_one_batch(tmp_path):
     for got, want in zip(packed[0] + packed[1], alone_a + alone_b):
         assert got.symbols == want.symbols
         assert np.allclose(got.positions, want.positions, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_sample_whose_atoms_are_all_virtual_is_an_empty_molecule_at_its_index():
+    """With virtual nodes the atoms of the class 'Ne' are dropped before molecule building (lightning_modules.py:531-537);
+    a sample that keeps no atom must still occupy its slot of the per-sample list (callers index molecules by sample)."""
+    from diffsbdd_amd.generate import LigandGenerator
+    from diffsbdd_amd.molecules import build_molecules
+    keys = ("dataset", "egnn_params", "diffusion_params", "mode", "node_histogram", "pocket_representation", "virtual_nodes")
+    hp = _hp("small_cond", "pocket_conditioning", "full-atom")
+    hp["virtual_nodes"] = True
+    gen = LigandGenerator(**{k: hp[k] for k in keys}, device="cuda")
+    types = torch.tensor([0, 1, 10, 10, 10, 10, 2, 0])          # sample 1: virtual atoms only
+    mask = torch.tensor([0, 0, 0, 1, 1, 1, 2, 2])
+    xh = torch.zeros(8, 3 + 11, device="cuda")
+    xh[:, :3] = torch.arange(8, dtype=torch.float32, device="cuda")[:, None] * 1.4
+    xh[torch.arange(8), 3 + types] = 1.0
+    x, at, m = gen._drop_virtual(xh, mask.cuda())
+    mols = build_molecules(x, at, m, gen.dataset_info, batch=3)
+    assert [mol.num_atoms for mol in mols] == [2, 0, 2]
+    assert mols[0].symbols == ["C", "N"] or len(mols[0].symbols) == 2
