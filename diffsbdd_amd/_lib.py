@@ -28,7 +28,7 @@ GCL_NAMES = ["E1_WT", "E1_WD", "E1_WD0", "E1_TAB", "E2_WT", "E2_B", "ATT_W", "AT
              "N1_WT", "N1_B", "N2_WT", "N2_B"]
 EQ_NAMES = ["C1_WT", "C_WD", "C_WD0", "C_TAB", "C_W2T", "C_B2",
             "X_WD", "X_WD0", "X_TAB", "X_W2T", "X_B2", "W3"]
-OPT_PRUNE, OPT_CONE, OPT_GRANULE16, OPT_EMU = 0, 1, 2, 3
+OPT_PRUNE, OPT_CONE, OPT_GRANULE16, OPT_EMU, OPT_SPLITK = 0, 1, 2, 3, 4
 (BUF_EDGE_ROW, BUF_EDGE_COL, BUF_EDGE_D0, BUF_ROW_PTR, BUF_H, BUF_X, BUF_NODE_BATCH, BUF_DEG,
  BUF_LEVEL, BUF_LEVEL_LIST, BUF_LEVEL_COUNT, BUF_LEVEL_END, BUF_LROW_PTR, BUF_LEDGE_ROW, BUF_LEDGE_COL,
  BUF_LEDGE_D0, BUF_LEVEL_STATS) = range(17)

@@ -61,6 +61,8 @@ struct EdgeMlpW {
   // optional: the three bf16 planes of W2T in the operand layout of v_mfma_f32_32x32x16_bf16 (edge_wave.h, emulated
   // path; pack_w2e_kernel): [H/16 k steps][H/32 column tiles][3 planes][64 lanes][8 bf16] = 6 H^2 bytes
   const void* W2E;
+  // optional: the per-wave rotated, lane-grouped copy of the split-K kernel (edge_splitk.h; pack_w2sk_kernel), H^2 floats
+  const float* W2SK;
 };
 
 struct EdgeArgs {

@@ -15,6 +15,7 @@
 #include "edge_mlp.h"
 #include "edge_wave.h"
 #include "edge_wave16.h"
+#include "edge_splitk.h"
 #include "graph.h"
 #include "lig_head.h"
 #include "molecule.h"
@@ -101,6 +102,9 @@ struct dsbdd_engine {
   unsigned granule16 = 0;               // DSBDD_OPT_GRANULE16: bit g = message stage g, bit 16 + b = coordinate stage of block b
                                         // run on the 16-edge-granule kernels (default: none; DSBDD_GRANULE16=<mask> in the environment)
   bool w2tp16_ready = false;            // their lane-grouped W2^T copies are current
+  unsigned splitk = 0;                  // DSBDD_OPT_SPLITK: the same bit layout -- stages that run on the split-K kernels (edge_splitk.h:
+                                        // a workgroup owns 32 edges, wave w a quarter of the reduction dimension; hidden_nf 256 only)
+  bool w2sk_ready = false;              // their per-wave rotated W2^T copies are current
   int emu = 0;                          // DSBDD_OPT_EMU: 0 = exact fp32 edge kernels (default), 6 / 9 = fp32 emulated on the bf16 matrix
                                         // cores with 6 / 9 partial products (edge_wave.h, "emulated path"); DSBDD_EMU=<k> in the environment
   bool w2e_ready = false;               // the bf16 planes of every W2^T are current
@@ -203,7 +207,7 @@ static WsLayout carve(const dsbdd_config& c, int64_t nl, int64_t np, int64_t B, 
       (size_t)N * JP * 4,                                                                           // 18 hout
       (size_t)N * 4, (size_t)(N + 1) * 4, (size_t)N * 4,                                            // 19-21 act flag/ptr/list
       (size_t)NG * 2 * H * 4,                                                                       // 22 pqg (GCL P|Q)
-      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 14 + 4096,                              // 23 lane-grouped W2^T copies (32- and 16-edge kernels: 2 x 4 B) + the bf16 planes of the emulated path (6 B)
+      (size_t)c.n_layers * (c.inv_sublayers + 2) * H * H * 18 + 4096,                              // 23 lane-grouped W2^T copies (32- and 16-edge kernels: 2 x 4 B) + the bf16 planes of the emulated path (6 B) + the split-K copies (4 B)
       (size_t)2 * T * H * 4, (size_t)2 * T * 2 * 16,                                                // 24 agg_head, 25 xagg_head[2][T][4] (16-edge tiles: 2 T slots)
       (size_t)(N + 1) * 4, (size_t)(2 * B + 1) * 4, (size_t)kTileCtrInts * 4,                       // 26 scan_tmp 27 seg_base 28 tile_ctr
       (size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)(N + 1) * 4, (size_t)N * 4,              // 29-33 list 2: erow ecol ed0 row_ptr deg
@@ -268,6 +272,7 @@ int dsbdd_engine_create(const dsbdd_config* cfg, dsbdd_engine** out) {
   if (const char* lr = getenv("DSBDD_LEVEL_ROWS")) e->level_rows = atoi(lr) != 0;
   if (const char* fk = getenv("DSBDD_FORK")) e->fork_front = atoi(fk) != 0;
   if (const char* g16 = getenv("DSBDD_GRANULE16")) e->granule16 = (unsigned)strtoul(g16, nullptr, 0);
+  if (const char* sk = getenv("DSBDD_SPLITK")) e->splitk = (unsigned)strtoul(sk, nullptr, 0);
   if (const char* em = getenv("DSBDD_EMU")) { const int v = atoi(em); e->emu = (v == 6 || v == 9) ? v : 0; }
   const char* cn = getenv("DSBDD_CONE");
   if (cn) e->cone = atoi(cn) <= 0 ? 0 : (atoi(cn) >= 2 ? 2 : 1);
@@ -312,6 +317,7 @@ int dsbdd_engine_set_weights(dsbdd_engine* e, const float* const* slots_host, in
   e->drop_graphs();
   e->w2tp_ready = false;
   e->w2tp16_ready = false;
+  e->w2sk_ready = false;
   e->w2e_ready = false;
   e->wchain_ready = false;
   e->h0_pocket_valid = false;
@@ -375,6 +381,7 @@ int dsbdd_engine_bind_workspace(dsbdd_engine* e, void* ws, size_t bytes, int64_t
   e->h0_pocket_valid = false;
   e->w2tp_ready = false;
   e->w2tp16_ready = false;
+  e->w2sk_ready = false;
   e->w2e_ready = false;
   return DSBDD_OK;
 }
@@ -472,6 +479,7 @@ int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value) {
     case DSBDD_OPT_PRUNE: e->prune = value ? 1 : 0; break;
     case DSBDD_OPT_CONE: e->cone = value <= 0 ? 0 : (value >= 2 ? 2 : 1); break;   // 0 off, 1 by the cost model, 2 always
     case DSBDD_OPT_GRANULE16: e->granule16 = (unsigned)value; break;               // bit g: message stage g, bit 16 + b: coordinate stage b
+    case DSBDD_OPT_SPLITK: e->splitk = (unsigned)value; break;                     // the same layout: stages on the split-K kernels
     case DSBDD_OPT_EMU:                                                            // 0 exact fp32; 6 / 9: emulated on the bf16 matrix cores
       if (value != 0 && value != 6 && value != 9) return fail(DSBDD_ERR_ARG, "DSBDD_OPT_EMU takes 0, 6 or 9");
       e->emu = value; break;
@@ -487,6 +495,7 @@ int dsbdd_engine_get_option(const dsbdd_engine* e, int which) {
     case DSBDD_OPT_PRUNE: return e->prune;
     case DSBDD_OPT_CONE: return e->cone;
     case DSBDD_OPT_GRANULE16: return (int)e->granule16;
+    case DSBDD_OPT_SPLITK: return (int)e->splitk;
     case DSBDD_OPT_EMU: return e->emu;
   }
   return fail(DSBDD_ERR_ARG, "unknown option");
@@ -630,8 +639,25 @@ static hipError_t launch_edge16(const dsbdd_engine* e, hipStream_t s, int mode, 
   return hipErrorInvalidValue;
 }
 
+// split-K variant (edge_splitk.h): one workgroup item per (32-edge tile, MLP), persistent over 2 workgroups per CU
+static hipError_t launch_edge_sk(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a, int64_t edge_bound) {
+  const bool two = mode == MODE_COORD && a.n_mlp == 2;
+  int64_t items = (edge_bound + 31) / 32 * (two ? 2 : 1);
+  int64_t resident = 2LL * e->n_cu;
+  if (e->edge_max_wg > 0 && e->edge_max_wg < resident) resident = e->edge_max_wg;
+  if (items > resident) items = resident;
+  const int q8 = two ? 16 : 8;                        // 8 XCDs (x 2 MLPs)
+  int grid = (int)((items + q8 - 1) / q8 * q8);
+  if (grid < q8) grid = q8;
+  if (e->cfg.hidden_nf != 256) return hipErrorInvalidValue;
+  if (mode == MODE_GCL) hipLaunchKernelGGL((edge_splitk_kernel<256, MODE_GCL>), dim3(grid), dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((edge_splitk_kernel<256, MODE_COORD>), dim3(grid), dim3(kThreads), 0, s, a);
+  return hipGetLastError();
+}
+
 static hipError_t launch_edge(const dsbdd_engine* e, hipStream_t s, int mode, const EdgeArgs& a,
-                              int64_t edge_bound, bool g16 = false) {
+                              int64_t edge_bound, bool g16 = false, bool sk = false) {
+  if (sk && a.mlp[0].W2SK) return launch_edge_sk(e, s, mode, a, edge_bound);
   if (g16) return launch_edge16(e, s, mode, a, edge_bound);
   const int H = e->cfg.hidden_nf;
   // 128-edge workgroup tiles (4 waves x 32 edges), 2 workgroups per CU, persistent over tiles
@@ -935,6 +961,24 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
     return e->emu ? reinterpret_cast<const char*>(e->w2tp + 2 * n_w2 * H * H) + ((size_t)blk * (c.inv_sublayers + 2) + which) * 6 * H * H
                   : nullptr;
   };
+  const bool can_sk = H == 256 && !e->emu;       // (edge_splitk.h: hidden_nf 256; no emulated form -- the mask is ignored with DSBDD_OPT_EMU)
+  auto w2sk_of = [&](int blk, int which) -> const float* {   // behind the bf16 planes: byte offset n_w2 H^2 14
+    return (e->splitk && can_sk) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(e->w2tp) + n_w2 * H * H * 14) +
+                                       ((size_t)blk * (c.inv_sublayers + 2) + which) * H * H
+                                 : nullptr;
+  };
+  if (e->splitk && can_sk && !e->w2sk_ready) {
+    for (int blk = 0; blk < c.n_layers; ++blk)
+      for (int which = 0; which < c.inv_sublayers + 2; ++which) {
+        const float* src = which < c.inv_sublayers ? W[gcl_slot(c, blk, which, DSBDD_GCL_E2_WT)]
+                         : W[eq_slot(c, blk, which == c.inv_sublayers ? DSBDD_EQ_C_W2T : DSBDD_EQ_X_W2T)];
+        if (!src) continue;
+        hipLaunchKernelGGL(pack_w2sk_kernel, dim3((H * H + 255) / 256), dim3(256), 0, s, src,
+                           const_cast<float*>(w2sk_of(blk, which)), H);
+        HIP_TRY(hipGetLastError());
+      }
+    e->w2sk_ready = true;
+  }
   if (e->emu && !e->w2e_ready) {
     for (int blk = 0; blk < c.n_layers; ++blk)
       for (int which = 0; which < c.inv_sublayers + 2; ++which) {
@@ -1048,11 +1092,14 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.e_cap = L_cap - (int)begin; ea.wt_base = (int)(begin / 32); ea.x = e->x;
       ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = 2 * H;
       ea.mlp[0] = EdgeMlpW{e->pqg, e->pqg + H, G(DSBDD_GCL_E1_WD), G(DSBDD_GCL_E1_WD0), G(DSBDD_GCL_E1_TAB),
-                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub), w2tp16_of(blk, sub), w2e_of(blk, sub)};
+                           G(DSBDD_GCL_E2_WT), G(DSBDD_GCL_E2_B), w2tp_of(blk, sub), w2tp16_of(blk, sub), w2e_of(blk, sub),
+                           w2sk_of(blk, sub)};
       ea.mlp[1] = ea.mlp[0];
       // 16-edge-granule variant of this stage (engine option; never for block 0's two-list launch of a framed call)
       // (no emulated 16-edge kernel: with DSBDD_OPT_EMU the mask is ignored, a chain never mixes exact and emulated stages)
       const bool g16 = ((e->granule16 >> (g & 15)) & 1u) && !(split0 && blk == 0 && sub == 0) && !e->emu;
+      // split-K variant of this stage (engine option; takes precedence over the 16-edge mask; block 0's two-list launch too)
+      const bool gsk = ((e->splitk >> (g & 15)) & 1u) && can_sk;
       ea.att_w = G(DSBDD_GCL_ATT_W); ea.att_b = G(DSBDD_GCL_ATT_B); ea.attention = c.attention;
       ea.agg = e->agg; ea.agg_head = e->agg_head; ea.tile_ctr = e->tile_ctr;
       ea.norm_factor = c.normalization_factor;
@@ -1071,7 +1118,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // single-occupancy tile latency of their own (45 us for 35 tiles)
         a2.erow_b = a3.erow; a2.ecol_b = a3.ecol; a2.ed0_b = a3.ed0; a2.e_count_b = a3.e_count; a2.e_cap_b = a3.e_cap;
         a2.wt_base_b = a3.wt_base; a2.agg_b = a3.agg; a2.agg_head_b = a3.agg_head;
-        HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound + ((e->frame_cap3 + 127) / 128) * 128));
+        HIP_TRY(launch_edge(e, s, MODE_GCL, a2, edge_bound + ((e->frame_cap3 + 127) / 128) * 128, false, gsk));
         hipLaunchKernelGGL(agg_complete2_kernel, dim3((N + n_ghost + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, (const int*)e->row_ptr2, (const int*)e->deg2,
                            (const float*)e->aggB, (const float*)e->agg_headB, (const int*)e->row_ptr3,
@@ -1081,7 +1128,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         // (timed: the launches over the whole list only, so that every timed launch is the same work)
         const bool timed = e->time_now && (all_rows || radius == e->plan_timed_level) && e->ev_used + 2 <= e->ev.size();
         if (timed) HIP_TRY(hipEventRecord(e->ev[e->ev_used], s));
-        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, L_bound, g16));
+        HIP_TRY(launch_edge(e, s, MODE_GCL, ea, L_bound, g16 && !gsk, gsk));
         if (timed) {
           HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], s));
           e->ev_used += 2;
@@ -1090,7 +1137,7 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
         const int n_rows = N + (ghost ? n_ghost : 0);
         hipLaunchKernelGGL(agg_complete_kernel, dim3((n_rows + 3) / 4), dim3(kThreads), 0, s, e->agg,
                            (const float*)e->agg_head, L_ptr, (const int*)e->deg, n_rows, H,
-                           (int)(g16 ? e->cap_tiles16 : e->cap_tiles) - 1, g16 ? 4 : 5);
+                           (int)((g16 && !gsk) ? e->cap_tiles16 : e->cap_tiles) - 1, (g16 && !gsk) ? 4 : 5);
         HIP_TRY(hipGetLastError());
       }
       // node MLP (egnn_new.py:21-24,56-57): h += W4 SiLU(W3 [h, agg] + b3) + b4
@@ -1205,25 +1252,26 @@ static int forward_impl(dsbdd_engine* e, hipStream_t s, const float* xh_lig, con
       ea.n_lig = nlig; ea.n_nodes = N + n_frame_rows; ea.ldpq = PQ;
       ea.mlp[0] = EdgeMlpW{e->pq + QW, e->pq, Q(DSBDD_EQ_C_WD), Q(DSBDD_EQ_C_WD0), Q(DSBDD_EQ_C_TAB),
                            Q(DSBDD_EQ_C_W2T), Q(DSBDD_EQ_C_B2), w2tp_of(blk, c.inv_sublayers), w2tp16_of(blk, c.inv_sublayers),
-                           w2e_of(blk, c.inv_sublayers)};
+                           w2e_of(blk, c.inv_sublayers), w2sk_of(blk, c.inv_sublayers)};
       if (n_mlp == 2)
         ea.mlp[1] = EdgeMlpW{e->pq + QW + H, e->pq + H, Q(DSBDD_EQ_X_WD), Q(DSBDD_EQ_X_WD0), Q(DSBDD_EQ_X_TAB),
                              Q(DSBDD_EQ_X_W2T), Q(DSBDD_EQ_X_B2), w2tp_of(blk, c.inv_sublayers + 1),
-                             w2tp16_of(blk, c.inv_sublayers + 1), w2e_of(blk, c.inv_sublayers + 1)};
+                             w2tp16_of(blk, c.inv_sublayers + 1), w2e_of(blk, c.inv_sublayers + 1), w2sk_of(blk, c.inv_sublayers + 1)};
       else
         ea.mlp[1] = ea.mlp[0];
       ea.w3 = Q(DSBDD_EQ_W3); ea.node_batch = e->node_batch; ea.mean = e->mean;
       ea.norm_constant = c.norm_constant; ea.coords_range = c.coords_range; ea.use_tanh = c.use_tanh;
       ea.n_mlp = n_mlp; ea.xagg = e->xagg; ea.xagg_head = e->xagg_head;
-      const bool c16 = ((e->granule16 >> (16 + (blk & 15))) & 1u) && !e->emu;   // 16-edge-granule variant of this stage
+      const bool csk = ((e->splitk >> (16 + (blk & 15))) & 1u) && can_sk;        // split-K variant of this stage (one sum per MLP)
+      const bool c16 = ((e->granule16 >> (16 + (blk & 15))) & 1u) && !e->emu && !csk;   // 16-edge-granule variant of this stage
       ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = (size_t)(c16 ? e->cap_tiles16 : e->cap_tiles) * 4;
       ea.tile_ctr = e->tile_ctr; ea.norm_factor = c.normalization_factor;
-      ea.pass_split = c16 ? 1 : e->coord_split;
+      ea.pass_split = (c16 || csk) ? 1 : e->coord_split;
       if (e->ts_buf && e->ts_next < e->ts_cap) ea.ts = e->ts_buf + (size_t)(e->ts_next++) * 1024;
      
-      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, L_bound, c16));
+      HIP_TRY(launch_edge(e, s, MODE_COORD, ea, L_bound, c16, csk));
       {
-        const int n_q = ((e->coord_split || c16) && n_mlp == 2) ? 2 : 1;   // (the 16-edge kernel keeps one sum per MLP)
+        const int n_q = ((e->coord_split || c16 || csk) && n_mlp == 2) ? 2 : 1;   // (the 16-edge / split-K kernels keep one sum per MLP)
         const int c_shift = c16 ? 4 : 5, c_max = (int)(c16 ? e->cap_tiles16 : e->cap_tiles) - 1;
         // few updated rows (the ligand's): one workgroup per sample updates them and reduces the next block's mean;
         // all rows updated (joint model): the wide per-component kernel, the mean stays a launch of its own

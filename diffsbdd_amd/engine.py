@@ -412,6 +412,10 @@ class HipEngine:
         _lib.check(self.lib.dsbdd_engine_set_option(self.handle, which, int(value)))
         self._options[which] = int(value)
 
+    def get_option(self, which):
+        """Current value of an engine switch (what the environment / set_option left)."""
+        return int(self.lib.dsbdd_engine_get_option(self.handle, which))
+
     def _read(self, ptr, count, dtype):
         import numpy as np
         itemsize = np.dtype(dtype).itemsize

@@ -221,6 +221,15 @@ int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghos
  * sublayer), bit 16 + b = the coordinate stage of block b.  Default 0 (environment: DSBDD_GRANULE16=<mask>).  The two
  * variants agree to rounding (< 1e-6 relative measured); each is bitwise reproducible; the mask is never changed by the
  * engine itself.
+ * DSBDD_OPT_SPLITK (round 6; environment DSBDD_SPLITK=<mask>): bit mask, same layout as DSBDD_OPT_GRANULE16, of the stages
+ * that run on the split-K variant of the fused edge kernels (csrc/edge_splitk.h: a WORKGROUP owns 32 edges, wave w a
+ * quarter of the reduction dimension of the H x H layer for all H columns, B operand straight from L2, the four partial
+ * accumulators reduce-scattered through LDS): a quarter of the default kernel's work unit (7 instead of 27 us of matrix
+ * time per wave) with the A operand still evaluated once per element -- for launches of fewer tiles than the chip has
+ * resident workgroups (crossdock_ca_cond, the free-running full-atom chain).  hidden_nf = 256 only; elsewhere, and with
+ * DSBDD_OPT_EMU != 0, the mask is ignored.  A stage named in both masks runs the split-K kernel.  Same aggregation
+ * protocol (head slots per 32-edge tile); results differ from the default kernel in the association of the K sum only
+ * (four partial sums); bitwise reproducible; the mask is never changed by the engine itself.
  * DSBDD_OPT_EMU (round 5; environment DSBDD_EMU): arithmetic of the H x H layer of the fused edge kernels.  0 (default) =
  * exact fp32 on v_mfma_f32_32x32x2_f32.  6 / 9 = fp32 EMULATED on the bf16 matrix cores: both operands split exactly into
  * three bf16 terms, the 6 largest (or all 9) partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16
@@ -233,7 +242,7 @@ int dsbdd_engine_last_plan(const dsbdd_engine* e, int32_t* radius, int32_t* ghos
  * emulated stages); the training step (dsbdd_train_*) always computes in exact fp32.
  * (Round 5 also made the fma of cond_update_kernel / cond_repaint_kernel explicit: the un-fused reverse-step path
  * differs from earlier rounds' results by up to 1 ulp.) */
-enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1, DSBDD_OPT_GRANULE16 = 2, DSBDD_OPT_EMU = 3 };
+enum { DSBDD_OPT_PRUNE = 0, DSBDD_OPT_CONE = 1, DSBDD_OPT_GRANULE16 = 2, DSBDD_OPT_EMU = 3, DSBDD_OPT_SPLITK = 4 };
 int dsbdd_engine_set_option(dsbdd_engine* e, int which, int value);
 /* current value of an option (what the environment / set_option left); DSBDD_ERR_ARG (< 0) for an unknown id */
 int dsbdd_engine_get_option(const dsbdd_engine* e, int which);

@@ -565,6 +565,9 @@ def test_frame_survives_unrelated_calls_on_the_same_engine():
     (3, 14, "inpaint2", 4, "32"),      # small batch, resamplings = 2: the q(z_t | z_s) jump inside the fused kernel
     (64, 23, "inpaint", 2, "16"),      # the headline plan with every eligible stage on the 16-edge-granule kernels
     (3, 14, "inpaint2", 4, "16"),
+    (64, 23, "inpaint", 2, "sk"),      # ... and with every stage (block 0's two-list launch included) on the split-K kernels
+    (64, 23, "sample", 2, "sk"),
+    (3, 14, "inpaint2", 4, "sk"),
 ])
 def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps, granule, monkeypatch):
     """The EXACT engine plan bench.py times, against the oracle at the size it is timed at: B identical 3rfm
@@ -579,6 +582,8 @@ def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps, gran
     from diffsbdd_amd import synthetic
     if granule == "16":
         monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")     # (block 0's two-list launch of a framed call stays on 32)
+    if granule == "sk":
+        monkeypatch.setenv("DSBDD_SPLITK", "0xFFFFFFFF")        # (csrc/edge_splitk.h)
     arch = "crossdock_fullatom_cond"
     cfg, dd = W.arch_cfg(arch)
     sd = W.random_state_dict(cfg, 0)
@@ -662,6 +667,8 @@ def test_bench_plan_steps_teacher_forced_vs_oracle(B, n_lig, mode, n_steps, gran
     ("small_variant", 6, False, "16"),               # the same calls with the edge stages on the 16-edge-granule kernels
     ("crossdock_fullatom_cond", 8, "shared", "16"),
     ("crossdock_ca_cond", 8, False, "16"),
+    ("crossdock_fullatom_cond", 8, "shared", "sk"),  # ... and on the split-K kernels
+    ("crossdock_ca_cond", 8, False, "sk"),
 ])
 @pytest.mark.parametrize("want_pocket", [False, True])
 def test_node_chain_kernel_vs_three_launches_and_oracle(arch, B, frame, granule, want_pocket, monkeypatch):
@@ -673,6 +680,8 @@ def test_node_chain_kernel_vs_three_launches_and_oracle(arch, B, frame, granule,
     from diffsbdd_amd.engine import edge_capacity
     if granule == "16":
         monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")
+    if granule == "sk":
+        monkeypatch.setenv("DSBDD_SPLITK", "0xFFFFFFFF")
     cfg, dd, xl, xp, t, ml, mp = bench_problem(arch, B)
     sd = W.random_state_dict(cfg, 0)
     d = dev()

@@ -244,18 +244,22 @@ def test_se3_equivariance_full_size(arch):
     assert (a_p[:, 3:] - b_p[:, 3:]).abs().max().item() < TOL
 
 
-def test_bitwise_reproducible_and_forced_multi_tile_loop():
-    """The edge aggregation has a fixed summation order (csrc/edge_mlp.h: plain stores + ordered
+@pytest.mark.parametrize("variant", ["32", "sk"])
+def test_bitwise_reproducible_and_forced_multi_tile_loop(variant, monkeypatch):
+    """(variant "sk": every stage on the split-K kernels, csrc/edge_splitk.h.)  The edge aggregation has a fixed summation order (csrc/edge_mlp.h: plain stores + ordered
     head partial sums, no atomics): repeated calls are bitwise equal, and so is a run whose tiles
     are distributed differently over the workgroups.  DSBDD_EDGE_MAX_WG caps the persistent grid at
     8 (GCL) / 16 (coordinate stage) workgroups, so every workgroup walks many tiles (work queue,
     next-tile prefetch, commit_edge, the continuous W2^T stream across units) -- the path large
     batches take -- and must reproduce the reference-generated eps."""
     import os
+    if variant == "sk":
+        monkeypatch.setenv("DSBDD_SPLITK", "0xFFFFFFFF")
     c = Case("dyn_fullatom_cond")
     sd = c.state_dict()
     args = (c.t("xh_lig"), c.t("xh_pocket"), c.t("t"), c.t("mask_lig"), c.t("mask_pocket"))
     m = make_dynamics(c.cfg, sd)
+    assert m.engine().get_option(4) == (-1 if variant == "sk" else 0)
     a, ap, _ = m.forward_async(*args)
     for _ in range(3):
         b, bp, _ = m.forward_async(*args)
@@ -273,12 +277,16 @@ def test_bitwise_reproducible_and_forced_multi_tile_loop():
     assert (p1.cpu() - c.t("eps_pocket")).abs().max().item() < TOL
 
 
-def test_batch_composition_invariance_bitwise():
+@pytest.mark.parametrize("variant", ["32", "sk"])
+def test_batch_composition_invariance_bitwise(variant, monkeypatch):
     """a sample's result must not depend on what else is in the batch.  Every
     (sample, node set) segment of the edge list starts at a wave-tile boundary and all per-row /
     per-sample sums have a fixed order, so eps of samples 0..1 evaluated alone equals, bit for bit,
-    their rows in the 3-sample batch (device-built edges, both model kinds)."""
-    for name in ("dyn_fullatom_cond", "dyn_fullatom_joint", "dyn_small_variant"):
+    their rows in the 3-sample batch (device-built edges, both model kinds).  variant "sk": every stage on the
+    split-K kernels (csrc/edge_splitk.h; H = 256 models -- the others ignore the mask)."""
+    if variant == "sk":
+        monkeypatch.setenv("DSBDD_SPLITK", "0xFFFFFFFF")
+    for name in ("dyn_fullatom_cond", "dyn_ca_cond") if variant == "sk" else ("dyn_fullatom_cond", "dyn_fullatom_joint", "dyn_small_variant"):
         c = Case(name)
         m = make_dynamics(c.cfg, c.state_dict())
         d = dev()
@@ -639,16 +647,25 @@ def _random_problem(cfg, n_lig, n_poc, seed, lig_shift=None, spread=3.0):
     return torch.cat([xl, hl], 1), torch.cat([xp, hp], 1), t, ml, mp
 
 
-@pytest.mark.parametrize("granule", ["32", "16"])
+@pytest.mark.parametrize("granule", ["32", "16", "sk"])
 @pytest.mark.parametrize("arch,max_wg", [("small_cond", 0), ("small_variant", 0), ("small_joint", 0),
-                                         ("small_cond", 8), ("small_variant", 8), ("small_joint", 8)])
+                                         ("small_cond", 8), ("small_variant", 8), ("small_joint", 8),
+                                         ("crossdock_ca_cond", 0), ("crossdock_ca_cond", 8), ("crossdock_fullatom_cond", 16)])
 def test_rows_spanning_many_tiles(arch, max_wg, granule, monkeypatch):
     """A 150-atom ligand: fully connected ligand rows have degree > 150, so one
     row's edge segment spans 5+ wave tiles / 2+ workgroup tiles.  granule "16": every stage on the 16-edge-granule
-    kernels (csrc/edge_wave16.h: a row then spans 10+ wave tiles; head slots per 16-edge tile)."""
+    kernels (csrc/edge_wave16.h: a row then spans 10+ wave tiles; head slots per 16-edge tile).  granule "sk": every
+    stage on the split-K kernels (csrc/edge_splitk.h, H = 256: a workgroup per 32-edge tile; with the grid capped at 8 / 16
+    workgroups every workgroup walks many items, both MLPs of the coordinate stage as separate populations)."""
     import os
+    if granule == "sk" and not arch.startswith("crossdock"):
+        pytest.skip("split-K kernels: hidden_nf 256 only")
+    if granule != "sk" and arch.startswith("crossdock") and max_wg != 8:
+        pytest.skip("the H = 256 cases of the other variants: one is enough")
     if granule == "16":
         monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")
+    if granule == "sk":
+        monkeypatch.setenv("DSBDD_SPLITK", "0xFFFFFFFF")
     cfg, _ = W.arch_cfg(arch)
     sd = W.random_state_dict(cfg, 3)
     xl, xp, t, ml, mp = _random_problem(cfg, [150, 3, 40], [40, 30, 5], seed=11,
@@ -670,30 +687,35 @@ def test_rows_spanning_many_tiles(arch, max_wg, granule, monkeypatch):
         assert excess(f_l, o_l) <= 0 and excess(f_p, o_p) <= 0
 
 
-@pytest.mark.parametrize("arch", ["small_cond", "small_joint", "crossdock_ca_cond"])
+@pytest.mark.parametrize("arch", ["small_cond", "small_joint", "crossdock_ca_cond", "crossdock_fullatom_cond"])
 def test_edge_granule_variants_agree(arch, monkeypatch):
-    """The 16-edge-granule kernels (csrc/edge_wave16.h) against the 32-edge ones on the same call: another k grouping
-    inside the fp32 MFMA chains and another summation tree of the row sums -- rounding only (2e-5 stated, ~1e-6
-    measured); the ligand-output-only call (level-ordered list, head slots at list offsets) included."""
+    """The 16-edge-granule kernels (csrc/edge_wave16.h) and -- H = 256 -- the split-K kernels (csrc/edge_splitk.h) against
+    the 32-edge ones on the same call: another k grouping inside the fp32 MFMA chains (split-K: four partial sums over a
+    quarter of k each) and another summation tree of the row sums -- rounding only (2e-5 stated, ~1e-6 measured); the
+    ligand-output-only call (level-ordered list, head slots at list offsets) included."""
     cfg, _ = W.arch_cfg(arch)
     sd = W.random_state_dict(cfg, 2)
     xl, xp, t, ml, mp = _random_problem(cfg, [23, 9, 40, 1], [36, 50, 20, 44], seed=17,
                                         spread=0.5 if arch == "small_joint" else 3.0)
     out = {}
-    for granule in ("32", "16"):
+    variants = ("32", "16", "sk") if cfg["hidden_nf"] == 256 else ("32", "16")
+    for granule in variants:
+        monkeypatch.delenv("DSBDD_GRANULE16", raising=False)
+        monkeypatch.delenv("DSBDD_SPLITK", raising=False)
         if granule == "16":
             monkeypatch.setenv("DSBDD_GRANULE16", "0xFFFFFFFF")
-        else:
-            monkeypatch.delenv("DSBDD_GRANULE16", raising=False)
+        elif granule == "sk":
+            monkeypatch.setenv("DSBDD_SPLITK", "0xFFFFFFFF")
         m = make_dynamics(cfg, sd)
         a = m.forward_async(xl, xp, t, ml, mp)
         b = m.forward_async(xl, xp, t[:1], ml, mp, want_pocket=False) if not cfg["update_pocket_coords"] else a
         torch.cuda.synchronize()
         assert int(a[2].item()) == 0 and int(b[2].item()) == 0
         out[granule] = (a[0].clone(), a[1].clone(), b[0].clone())
-    for u, v in zip(out["32"], out["16"]):
-        assert (u - v).abs().max().item() < 2e-5 * max(1.0, v.abs().max().item())
-    assert not torch.equal(out["32"][0], out["16"][0]) or arch == "small_joint"     # (the variant really switched)
+    for other in variants[1:]:
+        for u, v in zip(out["32"], out[other]):
+            assert (u - v).abs().max().item() < 2e-5 * max(1.0, v.abs().max().item()), other
+        assert not torch.equal(out["32"][0], out[other][0]) or arch == "small_joint"     # (the variant really switched)
 
 
 def test_ligand_without_pocket_neighbours_and_batch_of_one():
