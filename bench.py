@@ -279,6 +279,8 @@ def secondary_workloads(device, n_lig_atoms, steps=3):
         arch, key, B = WORKLOADS[workload]
         cfg, dd, model = build_model(arch, device)
         model.edge_granule16 = "auto"     # opt-in: coordinate stages on the 16-edge kernels where a round is saved (C-alpha)
+        model.edge_splitk = "auto"        # opt-in, per chain from host-side size bounds (EnVariationalDiffusion.splitk_auto): the
+                                          # split-K kernels for stages of at most 1.5 rounds of tiles; takes precedence over granule16
         T = dd["timesteps"]
         joint = not dd["conditional"]
         n_calls = (sum(model.get_repaint_schedule(2, 1, T)) + 1) if joint else T + 1
@@ -324,7 +326,8 @@ def secondary_workloads(device, n_lig_atoms, steps=3):
                     "reference_graph_tflops": ref_flops(cfg, N, e_last, B * n_lig_atoms) * n_calls / dt / 1e12,
                     "stage_radii": plan[0], "stage_ghost": plan[1],
                     "edge_granule16": "auto (EnVariationalDiffusion.granule16_auto): mask 0x%08x" %
-                                      (eng._options.get(2, 0) & 0xFFFFFFFF)})
+                                      (eng._options.get(2, 0) & 0xFFFFFFFF),
+                    "edge_splitk": "auto (EnVariationalDiffusion.splitk_auto): mask 0x%08x" % (eng._options.get(4, 0) & 0xFFFFFFFF)})
         del model, eng
         torch.cuda.empty_cache()
     return out
@@ -458,6 +461,9 @@ def main():
                     help="skip the end-to-end CPU run of BASELINE configs[0] (C-alpha, 4 samples, 50 steps)")
     ap.add_argument("--granule16", default=None,
                     help="16-edge-granule edge kernels: 'auto' or a stage bit mask (DSBDD_OPT_GRANULE16); default: off")
+    ap.add_argument("--splitk", default=None,
+                    help="split-K edge kernels (csrc/edge_splitk.h): 'auto' (per chain, host-side size bounds) or a stage bit "
+                         "mask (DSBDD_OPT_SPLITK); default: off")
     ap.add_argument("--emulation", type=int, default=0, choices=[0, 6, 9],
                     help="arithmetic of the main legs' H x H edge layers: 0 (default) exact fp32 MFMA; 6 / 9: fp32 emulated on "
                          "the bf16 matrix cores (DSBDD_OPT_EMU); `dtype` of the line then says so")
@@ -472,9 +478,9 @@ def main():
                     help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
-    if args.granule16 is not None and args.emulation:
-        raise SystemExit("--granule16 and --emulation exclude each other: the 16-edge-granule kernels have no emulated form, a chain "
-                         "would mix exact and emulated stages under one `dtype` label")
+    if (args.granule16 is not None or args.splitk is not None) and args.emulation:
+        raise SystemExit("--granule16 / --splitk and --emulation exclude each other: those kernels have no emulated form (the engine "
+                         "ignores their masks with DSBDD_OPT_EMU), the line would describe a configuration that did not run")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start one rank per GPU ourselves (the same launch the
         # driver uses) and hand the result through; rank 0 of the child job prints the JSON line
@@ -493,6 +499,8 @@ def main():
     cfg, dd, model = build_model(arch, device)
     if args.granule16 is not None:
         model.edge_granule16 = "auto" if args.granule16 == "auto" else int(args.granule16, 0)
+    if args.splitk is not None:
+        model.edge_splitk = "auto" if args.splitk == "auto" else int(args.splitk, 0)
     if args.emulation:
         model.edge_emulation = args.emulation
     T = args.timesteps or dd["timesteps"]
@@ -581,12 +589,29 @@ def main():
         el_o = time.perf_counter() - t1
         k_ms, k_n = (eng.profile_read() if not args.no_kernel_timing else (0.0, 0))
         eng.profile(False, 0)
-        other = {"states": o_states, "call": ("ConditionalDDPM.sample_given_pocket (conditional_model.py:478-555)"
+        raw_o = (k_ms, k_n, eng.level_stats(since=lv1), eng.last_plan(), el_o, eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]))
+        # the same leg once more with EVERY edge stage on the split-K kernels (explicit mask, a chain constant; the per-chain
+        # "auto" rule keeps full-atom x 64 on the default kernels because host-side bounds cannot tell this chain's short
+        # launches -- the ligand of a random-weight chain drifts out of the pocket -- from a trained model's long ones)
+        sk_var = None
+        if args.splitk is None and not args.emulation and cfg["hidden_nf"] == 256:
+            model.edge_splitk = -1
+            chain(320, o_states)
+            sync()
+            t1s = time.perf_counter()
+            for k in range(args.other_steps):
+                chain(321 + k, o_states)
+            sync()
+            el_s = time.perf_counter() - t1s
+            model.edge_splitk = None
+            sk_var = {"value": B * args.other_steps / el_s, "unit": "ligands/s", "ms_per_step": el_s / args.other_steps * 1e3,
+                      "steps": args.other_steps, "engine_option": "DSBDD_OPT_SPLITK = 0xFFFFFFFF (every edge stage on csrc/edge_splitk.h; "
+                      "explicit, not the default)"}
+        other = {"states": o_states, "splitk_all": sk_var,
+                 "call": ("ConditionalDDPM.sample_given_pocket (conditional_model.py:478-555)"
                                               if o_states == "free" else "ConditionalDDPM.inpaint, all atoms known"),
                  "value": B * args.other_steps / el_o, "unit": "ligands/s", "ms_per_step": el_o / args.other_steps * 1e3,
-                 "steps": args.other_steps, "live_levels": eng.level_stats(since=lv1),
-                 "_raw": (k_ms, k_n, eng.level_stats(since=lv1), eng.last_plan(), el_o,
-                          eng.edge_count(B * args.n_lig + pocket0["x"].shape[0]))}
+                 "steps": args.other_steps, "live_levels": raw_o[2], "_raw": raw_o}
     # separate leg: the headline chain with the edge kernels' H x H layer EMULATED on the bf16 matrix cores
     # (csrc/edge_wave.h "emulated path"; same inputs, same states, same seeds as the main leg's protocol)
     emulated = None
@@ -780,6 +805,8 @@ def main():
         if other is not None:
             summ[other["states"]] = {"value": r3(other["value"]), "dom_frac": r3(other["roofline"]["frac"]),
                                      "whole_frac": r3(other["roofline"]["whole_call_frac"])}
+            if other.get("splitk_all"):
+                summ[other["states"]]["splitk_all"] = r3(other["splitk_all"]["value"])
         if emulated is not None:
             summ["emulated"] = {"value": r3(emulated["value"]), "bf16_frac": r3(emulated["roofline"]["frac"]), "dtype": "f32-emulated(bf16x3,6)"}
         for k_, w_ in (("ca32", ca), ("mixed", mixed_w), ("joint", joint_w)):

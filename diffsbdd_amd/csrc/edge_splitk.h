@@ -187,10 +187,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_splitk_kernel(EdgeArgs p) {
 #pragma unroll 1
   for (;;) {
     // accumulators: the tiles this wave owns start from the second layer's bias, the partials handed away from zero
+    // (the handed-away tiles take a zero C operand in their first MFMA: no 96 register clears per item)
     f32x16 acc[CT];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int cl = 0; cl < CT; ++cl) {
-      const float bv = cl < OWN ? sV[5 * H + feat(cl)] : 0.f;
+    for (int cl = 0; cl < OWN; ++cl) {
+      const float bv = sV[5 * H + feat(cl)];
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[cl][r] = bv;
     }
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(kThreads, 2) void edge_splitk_kernel(EdgeArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int cl = 0; cl < CT; ++cl) acc[cl] = mfma32(a[i], bq[i][cl >> 2][cl & 3], acc[cl]);
+        for (int cl = 0; cl < CT; ++cl)
+          acc[cl] = mfma32(a[i], bq[i][cl >> 2][cl & 3], (g == 0 && i == 0 && cl >= OWN) ? zero16 : acc[cl]);
         load_b((g + 1) % NG, i);        // (the last group requests group 0 again: the next item's, same rows)
       }
       __builtin_amdgcn_s_setprio(0);

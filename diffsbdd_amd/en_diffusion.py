@@ -648,6 +648,49 @@ class EnVariationalDiffusion(nn.Module):
             return -(-items64 // n_cu) * 0.5 <= 0.8 * -(-items128 // n_cu)
         return (((1 << n_blocks) - 1) << 16) if (pays(lo) and pays(hi)) else 0
 
+    # Split-K edge kernels (csrc/edge_splitk.h, include/diffsbdd_hip.h DSBDD_OPT_SPLITK): bit mask of the stages that use them
+    # (same layout as the granule mask), "auto" (`splitk_auto`: decided once per chain from the batch's sizes), or None =
+    # leave the engine's setting (default 0, environment DSBDD_SPLITK) alone.  The variants agree to rounding, so the mask
+    # is part of a chain's definition like `cone_mode`: set once per chain, never changed by the engine.
+    edge_splitk = None
+
+    @staticmethod
+    def splitk_auto(lig_mask, pocket_mask, batch, n_stages, n_blocks, n_mlp, hidden_nf, pocket_x=None, cutoff_pocket=None,
+                    n_cu=256):
+        """`edge_splitk = "auto"`: the stages whose LARGEST possible launch is at most 1.5 rounds of the default kernel's
+        128-edge workgroup tiles on the chip's CUs go to the split-K kernels (a quarter of the work unit, the same vector
+        work per MFMA: csrc/edge_splitk.h).  Measured (profiles/r6b_mbsk.md): below that the default kernel pays a whole
+        27-us wave tile per CU whatever the launch holds (20.8 k edges: 43 -> 37 us, 11.6 k: 41 -> 25 us, 5 k: 41 -> 14 us;
+        coordinate stage of 16 full-atom samples 72 -> 55 us), above ~2 rounds it is 3 - 10 % ahead (0.65 - 0.74 of the
+        peak against 0.60 - 0.68).  Decided ONCE PER CHAIN from host-side bounds, never from a device-side count, so that
+        a sample's bits do not depend on the batch it is evaluated in:
+            E   <= sum_b  n_l^2 + 2 n_l c_b + PP_b      (message stages; PP_b = pocket-pocket edges of the chain's frame,
+                                                         counted exactly on the device when `pocket_x` is given -- the
+                                                         pocket is rigid during a chain --, else the complete graph)
+            E_u <= sum_b  n_l^2 + n_l c_b               (coordinate stages: ligand rows)
+        with c_b = min(ceil(n_p / 24), 12) pocket neighbours per ligand atom (the bracket of `granule16_auto`).
+        crossdock_ca_cond x 32: every stage (22 k / 18 k edges); full-atom x 16: the coordinate stages; full-atom x 64:
+        none.  hidden_nf 256 only (the kernels' constraint).  One host sync per chain."""
+        if hidden_nf != 256:
+            return 0
+        nl = torch.bincount(lig_mask, minlength=batch).to(torch.int64)
+        npk = torch.bincount(pocket_mask, minlength=batch).to(torch.int64)
+        c = torch.clamp((npk + 23) // 24, max=12)
+        ll, lp = (nl * nl).sum(), (nl * c).sum()
+        pp = (npk * npk).sum()
+        if pocket_x is not None and cutoff_pocket is not None and int(npk.min()) == int(npk.max()) and int(npk[0]) > 0:
+            xb = pocket_x.reshape(batch, int(npk[0]), -1)[:, :, :3].float()
+            pp = (torch.cdist(xb, xb, compute_mode="donot_use_mm_for_euclid_dist") <= float(cutoff_pocket)).sum()
+        e_hi, e_u_hi = (torch.stack([ll + 2 * lp + pp, ll + lp])).tolist()
+
+        def tiles(e):
+            return -(-int(e) // 128)
+        limit = 3 * n_cu // 2
+        mask = ((1 << n_stages) - 1) if tiles(e_hi) <= limit else 0
+        if n_mlp * tiles(e_u_hi) <= limit:
+            mask |= ((1 << n_blocks) - 1) << 16
+        return mask
+
     # Arithmetic of the H x H layer of the fused edge kernels (include/diffsbdd_hip.h DSBDD_OPT_EMU; csrc/edge_wave.h,
     # "emulated path"): None leaves the engine's setting alone (default 0 = exact fp32 MFMA; environment DSBDD_EMU),
     # 6 / 9 = fp32 emulated on the bf16 matrix cores (three-way bf16 split of both operands, 6 / 9 partial products, fp32
@@ -696,6 +739,18 @@ class EnVariationalDiffusion(nn.Module):
                 g16 = int(self.edge_granule16) & 0xFFFFFFFF
             g16 = g16 - (1 << 32) if g16 >= (1 << 31) else g16
         self._apply_engine_option(_lib.OPT_GRANULE16, g16, "DSBDD_GRANULE16")
+        sk = None
+        if self.edge_splitk is not None:
+            if self.edge_splitk == "auto":
+                hp = self.dynamics._hp
+                sk = 0 if self.dynamics.update_pocket_coords else self.splitk_auto(
+                    lm, pm, batch, hp["n_layers"] * hp["inv_sublayers"], hp["n_layers"],
+                    1 if hp["reflection_equivariant"] else 2, hp["hidden_nf"],
+                    pocket_x=pocket["x"].to(dev) if pocket is not None else None, cutoff_pocket=hp["edge_cutoff_pocket"])
+            else:
+                sk = int(self.edge_splitk) & 0xFFFFFFFF
+            sk = sk - (1 << 32) if sk >= (1 << 31) else sk
+        self._apply_engine_option(_lib.OPT_SPLITK, sk, "DSBDD_SPLITK")
         emu = None if self.edge_emulation is None else int(self.edge_emulation)
         if emu not in (None, 0, 6, 9):
             raise ValueError("edge_emulation must be None, 0, 6 or 9")

@@ -552,6 +552,17 @@ def test_per_chain_engine_choices_are_pure_functions_of_the_batch():
     assert D.granule16_auto(ca, 32, 6, pocket_mask=ca_p) == 0x003F0000
     assert D.granule16_auto(fa, 64, 6, pocket_mask=fa_p) == 0 and D.granule16_auto(fa, 64, 6) == 0
     assert D.granule16_auto(ca[:23 * 8], 8, 6) == 0x003F0000                        # 8 x 23: 68 -> 134 items, half the time
+    # round 6, split-K kernels: the stages whose largest possible launch is <= 1.5 rounds of 128-edge tiles; the frame's
+    # pocket-pocket edges are counted exactly when the pocket coordinates are known, else bounded by the complete graph
+    from diffsbdd_amd import synthetic
+    p_ca, p_fa = synthetic.load_pocket("ca", 32, "cpu"), synthetic.load_pocket("fa", 64, "cpu")
+    auto = lambda lm, pk, b, **kw: D.splitk_auto(lm, pk["mask"], b, 6, 6, 2, 256, **kw)
+    assert auto(ca, p_ca, 32, pocket_x=p_ca["x"], cutoff_pocket=5.0) == 0x003F003F     # C-alpha x 32: every stage
+    assert auto(ca, p_ca, 32) == 0x003F0000                                             # pocket unknown: the coordinate stages
+    assert auto(fa, p_fa, 64, pocket_x=p_fa["x"], cutoff_pocket=5.0) == 0 and auto(fa, p_fa, 64) == 0
+    p16 = synthetic.load_pocket("fa", 16, "cpu")
+    assert auto(fa[:23 * 16], p16, 16, pocket_x=p16["x"], cutoff_pocket=5.0) == 0x003F0000   # full-atom x 16: coordinate stages
+    assert D.splitk_auto(ca, p_ca["mask"], 32, 6, 6, 2, 192, pocket_x=p_ca["x"], cutoff_pocket=5.0) == 0   # hidden_nf 256 only
 
 
 def test_training_c_abi_argument_errors_and_sizes():
