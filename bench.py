@@ -56,7 +56,7 @@ from diffsbdd_amd.pocket import prepare_pocket  # noqa: E402
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / fp32 vector peak
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), no sparsity
 HBM_PEAK_GBPS = 8000.0
-PMC_TRAFFIC_FILE = "r5z_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r6_pmc_traffic.json"
 METRIC = "sampled ligands/sec (500-step DDPM, fullatom_cond) at 1/2/4/8 MI355X"
 
 WORKLOADS = {

@@ -1,3 +1,6 @@
+// EXPERIMENT COPY (round 6 housekeeping): csrc/edge_wave.h as of round 5 with every A/B switch and diagnostic build it carried
+// (-DDSBDD_EDGE_DMA, -DDSBDD_DYNAMIC_TILES, -DDSBDD_EMU_FENCE, -DDSBDD_EMU_PIPE_A, -DDSBDD_EMU_NOPRIO, -DDSBDD_TIMESTAMPS,
+// -DDSBDD_DIAG_*).  Used by tools/microbench.hip and tools/microbench_emu.hip only; the product builds csrc/edge_wave.h.
 // Third structure of the fused edge-MLP kernels (same math and arguments as
 // edge_mlp.h -- see there for the algorithm and the reference citations).
 //
@@ -31,21 +34,34 @@
 //     fp32 MFMA stream no vector instruction is free (tools/mfma_shadow.hip).
 //   * a stage that walks two edge lists (block 0 of a framed call) runs them in one
 //     launch: the second list's tiles follow the first's (EdgeArgs::*_b).
-//   * tiles are assigned round-robin inside each XCD's contiguous tile range.
-//
-// Structures that were built, measured and dropped -- a per-XCD work queue for the tiles, the W2^T stream by LDS-DMA
-// (global_load_lds), scheduling fences / a one-step-ahead activation pipeline in the emulated path, the in-kernel
-// timestamp / phase-clock / "no X" diagnostic builds -- live in tools/edge_wave_diag.h (the round-5 state of this file,
-// used by the micro-benchmarks' A/B builds); their numbers are in profiles/README.md and DESIGN.md.
+//   * tiles are assigned round-robin inside each XCD's contiguous tile range (a per-XCD work
+//     queue exists behind -DDSBDD_DYNAMIC_TILES; it measured slower).
 //
 // Workgroup = 4 waves = 128 edges; LDS = 2 x 32 x H x 4 B (64 KB at H = 256) +
 // vectors -> 2 workgroups per CU, which overlap each other's epilogues.
 #pragma once
-#include "common.h"
-#include "edge_mlp.h"
-#include "graph.h"
+#include "../diffsbdd_amd/csrc/common.h"
+#include "../diffsbdd_amd/csrc/edge_mlp.h"
+#include "../diffsbdd_amd/csrc/graph.h"
 
 namespace dsbdd {
+
+// Emulated path, A/B switches (profiles/r5_emu_microbench.md: every combination lands within 4 % of the others):
+//   -DDSBDD_EMU_FENCE   scheduling fences between the MFMA groups and the B-operand reads, which then stay one pair of column
+//                       tiles ahead of their use (default: the compiler's order -- it sinks the reads to just in front of
+//                       their first MFMA);  377 us (default) vs 386 - 395 us on the micro-benchmark list
+//   -DDSBDD_EMU_PIPE_A  the next k step's activations computed one step ahead (default: in front of the step's own MFMAs)
+#ifndef DSBDD_EMU_FENCE_MASK
+#define DSBDD_EMU_FENCE_MASK 0
+#endif
+#ifdef DSBDD_EMU_FENCE
+#define EMU_FENCE() __builtin_amdgcn_sched_barrier(DSBDD_EMU_FENCE_MASK)
+#else
+#define EMU_FENCE() do { } while (0)
+#endif
+#ifndef DSBDD_EMU_PIPE_A
+#define DSBDD_EMU_NOPIPE_A 1
+#endif
 
 // EMU = 0: exact fp32 (v_mfma_f32_32x32x2_f32).  EMU = 6 / 9: fp32 EMULATED on the bf16 matrix cores -- both operands of
 // the H x H layer split into three bf16 terms (x = hi + mid + lo exactly), 6 (or all 9) partial products per k step on
@@ -62,7 +78,8 @@ struct WaveLayout {
   static constexpr int VEC_OFF = 0;
   static constexpr int SCR_OFF = VEC_OFF + NV * VEC_PER;
   static constexpr int SCR_PER = 32 * 3;                   // per wave: trans[32][3]; phi[32] uses the same words earlier
-  static constexpr int B_OFF = (SCR_OFF + 4 * SCR_PER + 4 + 255) / 256 * 256;   // [2][BK][H], 1 KB aligned
+  static constexpr int NEXT_OFF = SCR_OFF + 4 * SCR_PER;   // next tile index from the work queue
+  static constexpr int B_OFF = (NEXT_OFF + 4 + 255) / 256 * 256;   // [2][BK][H], 1 KB aligned
   static constexpr int TOTAL = B_OFF + 2 * B_BUF;
 };
 
@@ -186,6 +203,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   // s_setprio 1 around every MFMA cluster: the two workgroups sharing a CU are in different
   // phases, so favouring the wave that has MFMAs ready keeps the matrix pipe fed (+2.7 %)
   constexpr bool SETPRIO = true;
+#ifdef DSBDD_EMU_NOPRIO
+  constexpr bool SETPRIO_EMU = false;
+#else
+  constexpr bool SETPRIO_EMU = true;
+#endif
+  (void)SETPRIO_EMU;
   // B operand from the lane-grouped W2^T copy (EdgeMlpW::W2TP): lane j finds the values of all its
   // column tiles in CT consecutive words -> one (CT = 4) or two (CT = 8) ds_read_b128 per k step
   // instead of CT/2 ds_read2_b32.  For CT = 8 the two 16-byte halves are read in swapped order by
@@ -227,6 +250,22 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int swb = (bperm && CT == 8) ? ((j >> 3) & 1) : 0;          // this lane reads its halves swapped
   auto feat = [&](int c) { return ((c ^ (4 * swb)) * 32) + j; };    // feature held by accumulator tile c
 
+#ifdef DSBDD_TIMESTAMPS
+  int ts_n = 0;
+#define DSBDD_TS() do { if (p.ts && t == 0 && blockIdx.x < 64 && ts_n < 16) p.ts[blockIdx.x * 16 + ts_n++] = wall_clock64(); } while (0)
+#else
+#define DSBDD_TS() do { } while (0)
+#endif
+  DSBDD_TS();                                            // mark 0: kernel entry (after the vector loads were issued)
+#ifdef DSBDD_DIAG_PHASES
+  // DIAGNOSTIC ONLY (tools/microbench_emu.hip "phases"): shader cycles of every wave by phase of the emulated K step --
+  // 0 outside the K loop (prologue, epilogue), 1 activations + first B reads, 2 MFMA phase, 3 trailing staging stores,
+  // 4 barrier.  s_memtime waits for the wave's LDS operations; at these boundaries they are awaited anyway.
+  unsigned long long ph_t = __builtin_readcyclecounter(), ph[5] = {0, 0, 0, 0, 0};
+#define DSBDD_PH(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define DSBDD_PH(i) do { } while (0)
+#endif
   const int E = min(*p.e_count, p.e_cap);
   const int nt_a = (E + BMB - 1) / BMB;
   const int E_b = (MODE == MODE_GCL && p.e_count_b) ? min(*p.e_count_b, p.e_cap_b) : 0;   // second list of the stage
@@ -237,10 +276,54 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   const int tq = ntiles / 8, tr = ntiles % 8;
   const int csize = tq + (xcd < tr ? 1 : 0);
   const int cbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  // Static round-robin over the XCD's tiles: local tiles kx, kx + gx, ... (with two resident workgroups per CU the static
-  // order keeps the (kx, kx + n_CU) pairs of a CU balanced; a work queue measured 3 % slower, see the top of the file)
-  if (kx >= csize) return;
+  // Work queue: the workgroups of XCD x (and MLP population qsel) start with local tiles
+  // 0 .. gx-1 and then pull further local tile indices gx + atomicAdd(counter, 1).  Every
+  // workgroup counts itself out on the completion counter; the last one clears the counters
+  // for the next launch.  DYN needs four K steps per tile to hide the atomic (H >= 128).
+  // (Measured: the queue LOSES 3 % against the static round-robin assignment at the benchmark size --
+  // message stage 0.432 vs 0.427 ms, coordinate stage 127 vs 114 us, profiles/README.md: with two
+  // resident workgroups per CU the static order keeps the (kx, kx + n_CU) pairs of a CU balanced and
+  // costs nothing.  Static is the default; -DDSBDD_DYNAMIC_TILES builds the queue.)
+#ifdef DSBDD_DYNAMIC_TILES
+  constexpr bool DYN = NK >= 4;
+#else
+  constexpr bool DYN = false;
+#endif
+  int* q_head = p.tile_ctr + xcd + 8 * qsel;
+  int* q_done = p.tile_ctr + 16;
+  volatile int* s_next = reinterpret_cast<volatile int*>(smem + L::NEXT_OFF);
+  auto check_out = [&]() {
+    if (DYN && t == 0) {
+      __threadfence();
+      if (atomicAdd(q_done, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) p.tile_ctr[i] = 0;
+      }
+    }
+  };
+  if (kx >= csize) { check_out(); return; }
 
+#ifdef DSBDD_EDGE_DMA   // (the round-1/2 stream, kept for A/B timing)
+  // ---- W2^T slice streaming: direct global -> LDS DMA (global_load_lds, 16 B per lane,
+  // LDS destination = wave-uniform base + lane*16), no staging registers.  The DMA is
+  // tracked by vmcnt; the __syncthreads() that ends a K step drains it (vmcnt(0)) and
+  // publishes the slice to the other waves.
+  auto streamB = [&](int q, int ks, int buf) {
+#ifdef DSBDD_DIAG_NODMA
+    return;   // DIAGNOSTIC ONLY: W2^T is never streamed
+#endif
+    // uniform slice base (SGPR pair) + this thread's 32-bit byte offset: the saddr form of global_load_lds, no
+    // per-lane 64-bit address arithmetic
+    const char* src = reinterpret_cast<const char*>((bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H);
+    const unsigned toff = (unsigned)t * 16u;
+    float* dst = sB + buf * L::B_BUF + w * 256;          // wave-uniform
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (size_t)(kThreads * 16 * i) + toff),
+          (__attribute__((address_space(3))) void*)(dst + kThreads * 4 * i), 16, 0, 0);
+  };
+#endif
 
   // ---- W2^T slice stream through staging registers --------------------------------------------------------
   // The compiler orders every LDS read behind ALL pending global_load_lds (it cannot tell the slice being filled
@@ -252,6 +335,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   stg_t stg[SG];
   auto stage_lo = [](int g) { return BI * g / NG; };
   auto stage_load = [&](int q, int ks, int g) {
+#ifdef DSBDD_DIAG_NODMA
+    return;
+#endif
     const char* src = EMU ? reinterpret_cast<const char*>(p.mlp[qsel + q].W2E) + (size_t)ks * (96 * H)
                           : reinterpret_cast<const char*>((bperm ? p.mlp[qsel + q].W2TP : p.mlp[qsel + q].W2T) + (size_t)ks * BK * H);
     const unsigned toff = (unsigned)t * (4u * UNIT);
@@ -260,6 +346,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       stg[EMU ? i : i - stage_lo(g)] = *reinterpret_cast<const stg_t*>(src + (size_t)(kThreads * 4 * UNIT * i) + toff);
   };
   auto stage_store = [&](int buf, int g) {
+#ifdef DSBDD_DIAG_NODMA
+    return;
+#endif
     float* dst = sB + buf * L::B_BUF + t * UNIT;
 #pragma unroll
     for (int i = stage_lo(g); i < stage_lo(g + 1); ++i)
@@ -327,12 +416,17 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   };
 
   // prologue: first W2^T slice, first edge, first P/Q chunk
+#ifdef DSBDD_EDGE_DMA
+  streamB(0, 0, 0);
+#else
 #pragma unroll
   for (int g = 0; g < NG; ++g) { stage_load(0, 0, g); stage_store(0, g); }
+#endif
   fetch_idx(cbase + kx);
   fetch_x();
   commit_edge();
   __syncthreads();          // sV + slice 0 visible
+  DSBDD_TS();               // mark 1: prologue done (vectors, first W2^T slice, first edge)
   int bslice = 0;           // running slice counter (buffer = bslice & 1)
 
   // this lane's k of a step: exact path 8 g + 4 half + i (float4 chunks), emulated path 16 kt + 8 half + i (two float4)
@@ -346,7 +440,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 
   bf16x8 a_h = {}, a_m = {}, a_l = {};                     // emulated path: the current k step's activations (three bf16 planes)
   (void)a_h; (void)a_m; (void)a_l;
-  int li = kx, q = 0, next_li = 0;
+  int li = kx, q = 0, next_li = 0, ticket = 0;
   bool has_next = false;
 #pragma unroll 1
   for (;;) {
@@ -367,29 +461,56 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll 1
     for (int kt = 0; kt < NK; ++kt) {
       const bool more = kt + 1 < NK;
-      // next tile of this workgroup: its edge with two dependent loads, all behind the MFMAs of the current tile
+      // next tile of this workgroup: queue ticket (two K steps of latency budget), then the
+      // tile's edge with two dependent loads, all behind the MFMAs of the current tile
       const int st = q * NK + kt;
-      if (st == 0) {
-        next_li = li + gx;
-        has_next = next_li < csize;
-        if (has_next) fetch_idx(cbase + next_li);
+      if (DYN) {
+        if (st == 0) { has_next = false; if (t == 0) ticket = atomicAdd(q_head, 1); }
+        if (st == 1 && t == 0) *s_next = gx + ticket;       // published by this K step's barrier
+        if (st == 2) {
+          next_li = *s_next;
+          has_next = next_li < csize;
+          if (has_next) fetch_idx(cbase + next_li);
+        }
+        if (st == 3 && has_next) fetch_x();
+      } else {
+        if (st == 0) {
+          next_li = li + gx;
+          has_next = next_li < csize;
+          if (has_next) fetch_idx(cbase + next_li);
+        }
+        if (st == 1 && has_next) fetch_x();
       }
-      if (st == 1 && has_next) fetch_x();
+      const bool last_unit_k = tile_ends && !has_next;     // final from st >= 2 (DYN) / st >= 0
+      (void)last_unit_k;
       // the next W2^T slice: a continuous stream across units (the last K step of a workgroup re-reads slice 0 of
       // its MLP: never used; unconditional, so that the compiler counts the loads in flight exactly)
       const int sq = more ? q : qn, sks = more ? kt + 1 : 0;
+#ifdef DSBDD_EDGE_DMA
+      if (more || !last_unit_k) streamB(sq, sks, (bslice + 1) & 1);
+#endif
       const f32x2 dd = splat2(my_d), dz = splat2(my_d0);
+      if constexpr (EMU != 0) DSBDD_PH(0);
       if constexpr (EMU != 0) {
         // ---- emulated path: one 16-k step = 8 activations per lane, split into three bf16x8, 6 (9) MFMAs per column tile.
         // Order of a step: the step's activations, the next P / Q chunk requested, then per pair of column tiles the three
         // B planes (lo: 1 product, mid: 2, hi: 3) and their MFMAs; the next W2E slice travels through staging registers in
-        // two halves.  (B reads one pair ahead behind scheduling fences and the next step's activations one step ahead were
-        // measured neutral to slower, profiles/r5_emu_microbench.md; those builds live in tools/edge_wave_diag.h.)
+        // two halves.  (-DDSBDD_EMU_FENCE / -DDSBDD_EMU_PIPE_A: B reads one pair ahead behind scheduling fences / the next
+        // step's activations one step ahead -- measured neutral to slower, see the top of the file.)
         constexpr int NG1 = (NG + 1) / 2;
         auto act8 = [&](int ks, bf16x8& o_h, bf16x8& o_m, bf16x8& o_l) {       // activations of k step ks from pc / qc
           const float* vk = vq + ks * 16 + 8 * half;       // this lane's k = 16 ks + 8 half + i
           const float* vt = vk + (2 + my_ty) * H;
           float av[8];
+#ifdef DSBDD_DIAG_NOACT
+          {   // DIAGNOSTIC ONLY: no activation arithmetic (the P / Q chunk is consumed with four adds)
+            const f32x4 sm = pc + qc + pc1 + qc1;
+            const unsigned u0 = __float_as_uint(sm.x + sm.y), u1 = __float_as_uint(sm.z + sm.w);
+            const u32x4 w = {u0, u1, u0 ^ u1, u0 + u1};
+            o_h = __builtin_bit_cast(bf16x8, w); o_m = o_h; o_l = o_h;
+            return;
+          }
+#endif
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             const f32x4 pp = hh ? pc1 : pc, qq = hh ? qc1 : qc;
@@ -412,34 +533,59 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
           }
         };
         auto load_pq = [&](int ks) {                       // this lane's P / Q chunk of k step ks (32 bytes of either row)
+#ifdef DSBDD_DIAG_NOGATHER
+          pc = f32x4{0.1f, 0.2f, 0.3f, 0.4f} * (float)ks; pc1 = pc; qc = pc; qc1 = pc; return;   // DIAGNOSTIC ONLY
+#endif
           pc = ldv4(Pp + 16 * ks); pc1 = ldv4(Pp + 16 * ks + 4);
           qc = ldv4(Qp + 16 * ks); qc1 = ldv4(Qp + 16 * ks + 4);
         };
-        act8(kt, a_h, a_m, a_l);                           // the step's activations in front of its MFMAs
+#ifdef DSBDD_EMU_NOPIPE_A
+        act8(kt, a_h, a_m, a_l);                           // (A/B timing: activations in front of the step's MFMAs)
         load_pq(more ? kt + 1 : 0);
+#else
+        if (kt == 0) {                                     // first step of a unit: nothing to hide behind
+          act8(0, a_h, a_m, a_l);
+          load_pq(NK > 1 ? 1 : 0);
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < NG1; ++g) stage_load(sq, sks, g);
         const float* bl = sB + (bslice & 1) * L::B_BUF + lane * 4;       // + (c * 3 + plane) * 256 floats
         bf16x8 bh[2], bm[2], blo[2];
         auto rdb = [&](int cp, int plane, bf16x8 (&dst)[2]) {
+#ifdef DSBDD_DIAG_NOBREAD
+          dst[0] = plane == 0 ? a_h : a_m; dst[1] = plane == 2 ? a_l : a_h; return;   // DIAGNOSTIC ONLY: no B reads
+#endif
 #pragma unroll
           for (int u = 0; u < 2; ++u)
             dst[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bl + (2 * cp + u) * 768 + plane * 256));
         };
         rdb(0, 2, blo); rdb(0, 1, bm); rdb(0, 0, bh);
+#ifndef DSBDD_EMU_NOPIPE_A
+        // next step's activations (the last step of a unit computes step 0's again: no branch inside the pipeline)
+        bf16x8 n_h, n_m, n_l;
+        act8(more ? kt + 1 : 0, n_h, n_m, n_l);
+        load_pq(kt + 2 < NK ? kt + 2 : 0);
+#endif
 #define EMU_MM(a, b) do { _Pragma("unroll") for (int u = 0; u < 2; ++u) \
           acc[2 * cp + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[2 * cp + u], 0, 0, 0); } while (0)
-        __builtin_amdgcn_s_setprio(1);
+        DSBDD_PH(1);
+        if (SETPRIO_EMU) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int cp = 0; cp < CT / 2; ++cp) {
           const bool nxt = cp + 1 < CT / 2;
           if constexpr (EMU == 9) { EMU_MM(a_l, blo); EMU_MM(a_m, blo); }
           EMU_MM(a_h, blo);
+          EMU_FENCE();
           if (nxt) rdb(cp + 1, 2, blo);
+          EMU_FENCE();
           if constexpr (EMU == 9) EMU_MM(a_l, bm);
           EMU_MM(a_m, bm); EMU_MM(a_h, bm);
+          EMU_FENCE();
           if (nxt) rdb(cp + 1, 1, bm);
+          EMU_FENCE();
           EMU_MM(a_l, bh); EMU_MM(a_m, bh); EMU_MM(a_h, bh);           // (the leading product last)
+          EMU_FENCE();
           if (nxt) rdb(cp + 1, 0, bh);
           if (NG > 1 && cp == CT / 4 - 1) {                // half way: first half of the slice -> LDS, request the second
 #pragma unroll
@@ -447,11 +593,17 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
             for (int g = NG1; g < NG; ++g) stage_load(sq, sks, g);
           }
+          EMU_FENCE();
         }
 #undef EMU_MM
-        __builtin_amdgcn_s_setprio(0);
+        if (SETPRIO_EMU) __builtin_amdgcn_s_setprio(0);
+        DSBDD_PH(2);
 #pragma unroll
         for (int g = (NG > 1 ? NG1 : 0); g < NG; ++g) stage_store((bslice + 1) & 1, g);
+        DSBDD_PH(3);
+#ifndef DSBDD_EMU_NOPIPE_A
+        a_h = n_h; a_m = n_m; a_l = n_l;
+#endif
       } else {
       const float* bcur = sB + (bslice & 1) * L::B_BUF + (4 * half) * H + (bperm ? j * CT + 4 * swb : j);
       const float* vk = vq + kt * BK + 4 * half;           // this lane's k = kt*BK + 8g + 4*half + i
@@ -459,11 +611,17 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         const int kb = kt * BK + 8 * g;                    // this lane's k = kb + 4*half + i
+#ifndef DSBDD_EDGE_DMA
         if (g > 0) stage_store((bslice + 1) & 1, g - 1);
         stage_load(sq, sks, g);
+#endif
         if (g + 1 < BK / 8 || more) {                      // prefetch the next group's P/Q chunk
+#ifdef DSBDD_DIAG_NOGATHER
+          pn = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; qn4 = pn;   // DIAGNOSTIC ONLY
+#else
           pn = ldv4(Pp + kb + 8);
           qn4 = ldv4(Qp + kb + 8);
+#endif
         }
         // A operand: SiLU((P + Q) + d wd + d0 wd0 + tab), two values per instruction (explicit fma: the same
         // arithmetic in every instantiation of the kernel)
@@ -472,25 +630,40 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
         const f32x4 tb4 = *reinterpret_cast<const f32x4*>(vt + 8 * g);
         f32x2 alo = pk_fma(dz, wz4.xy, pk_fma(dd, wd4.xy, pc.xy + qc.xy)) + tb4.xy;
         f32x2 ahi = pk_fma(dz, wz4.zw, pk_fma(dd, wd4.zw, pc.zw + qc.zw)) + tb4.zw;
+#ifndef DSBDD_DIAG_NOSILU
         alo = silu2(alo);
         ahi = silu2(ahi);
+#endif
         const float a[4] = {alo.x, alo.y, ahi.x, ahi.y};
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float* brow = bcur + (8 * g + i) * H;
+#ifdef DSBDD_DIAG_NOBREAD
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], a[(i + c) & 3], acc[c]);   // DIAGNOSTIC ONLY
+#else
           float bv[CT];
           read_b(brow, bv);
 #pragma unroll
           for (int c = 0; c < CT; ++c) acc[c] = mfma32(a[i], bv[c], acc[c]);
+#endif
         }
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         pc = pn; qc = qn4;
       }
+#ifndef DSBDD_EDGE_DMA
       stage_store((bslice + 1) & 1, BK / 8 - 1);
+#endif
       }   // exact path
       ++bslice;
+#ifdef DSBDD_DIAG_NOBARRIER
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // DIAGNOSTIC ONLY (racy): vmcnt(0) without the workgroup barrier
+#else
       __syncthreads();
+#endif
+      if constexpr (EMU != 0) DSBDD_PH(4);
+      DSBDD_TS();           // marks 2 .. NK+1: end of every K step
     }
 
     const bool last_unit = tile_ends && !has_next;
@@ -504,6 +677,16 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     }
 
     // ================= wave-private epilogue =================
+#ifdef DSBDD_DIAG_NOEPI
+    if (MODE == MODE_GCL) {   // DIAGNOSTIC ONLY: consume the accumulators with 127 adds
+      float tot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += acc[c][r];
+      if (tot == 12345.678f) p.agg[lane] = tot;
+    } else
+#endif
     if (MODE == MODE_GCL) {
       // messages m = SiLU(acc)   (egnn_new.py:18-19; the bias is already in the accumulators), register pairs
 #pragma unroll
@@ -688,6 +871,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       }
     }
 
+    DSBDD_TS();             // epilogue of this unit done
     // advance to the next unit
     if (tile_ends) {
       if (last_unit) break;
@@ -698,6 +882,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
       ++q;
     }
   }  // units
+#ifdef DSBDD_DIAG_PHASES
+  DSBDD_PH(0);
+  if (p.ts && lane == 0)
+    for (int i = 0; i < 5; ++i) p.ts[(blockIdx.x * 4 + (t >> 6)) * 8 + i] = ph[i];
+#endif
+  check_out();
 }
 
 }  // namespace dsbdd

@@ -22,7 +22,7 @@
 
 #include "../diffsbdd_amd/csrc/common.h"
 #include "../diffsbdd_amd/csrc/edge_mlp.h"
-#include "../diffsbdd_amd/csrc/edge_wave.h"
+#include "edge_wave_diag.h"   // the round-5 state of csrc/edge_wave.h with its A/B and diagnostic build switches
 #include "../diffsbdd_amd/csrc/graph.h"
 #include "../diffsbdd_amd/csrc/node_linear.h"
 #include "../diffsbdd_amd/csrc/node_chain.h"

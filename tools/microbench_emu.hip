@@ -24,7 +24,7 @@
 
 #include "../diffsbdd_amd/csrc/common.h"
 #include "../diffsbdd_amd/csrc/edge_mlp.h"
-#include "../diffsbdd_amd/csrc/edge_wave.h"
+#include "edge_wave_diag.h"   // the round-5 state of csrc/edge_wave.h with its A/B and diagnostic build switches
 #include "../diffsbdd_amd/csrc/graph.h"
 
 using namespace dsbdd;
