@@ -268,7 +268,7 @@ def ref_flops(cfg, N, E, n_lig_nodes):
     return 2.0 * mac
 
 
-def secondary_workloads(device, n_lig_atoms, steps=3):
+def secondary_workloads(device, n_lig_atoms, steps=3, emulated_legs=True):
     """`steps` timed chains (after one warm-up chain) of the other single-GPU configurations, so that the driver's record of
     the default run holds them: BASELINE.json configs[1] (crossdock_ca_cond x 32), configs[4] on ONE GPU
     (moad_fullatom_joint x 64, RePaint resamplings = 2: 1000 EGNN calls) and the heterogeneous-pocket variant of
@@ -328,6 +328,24 @@ def secondary_workloads(device, n_lig_atoms, steps=3):
                     "edge_granule16": "auto (EnVariationalDiffusion.granule16_auto): mask 0x%08x" %
                                       (eng._options.get(2, 0) & 0xFFFFFFFF),
                     "edge_splitk": "auto (EnVariationalDiffusion.splitk_auto): mask 0x%08x" % (eng._options.get(4, 0) & 0xFFFFFFFF)})
+        # the same workload with the edge kernels' H x H layer emulated on the bf16 matrix cores (opt-in path, DSBDD_OPT_EMU = 6;
+        # the granule / split-K masks are ignored by the engine then: every edge stage runs the emulated 32-edge kernel)
+        if emulated_legs:
+            try:
+                model.edge_granule16 = model.edge_splitk = None
+                model.edge_emulation = 6
+                chain(300)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    out_e = chain(400 + k)[0]
+                torch.cuda.synchronize(device)
+                dte = (time.perf_counter() - t0) / steps
+                assert torch.isfinite(out_e).all()
+                out[-1]["emulated"] = {"value": B / dte, "unit": "ligands/s", "ms_per_step": dte * 1e3, "steps": steps, "warmup": 1,
+                                       "dtype": emu_dtype(6), "vs_exact_value": (B / dte) / out[-1]["value"]}
+            except Exception as exc:      # an emulated leg must not cost the benchmark line
+                out[-1]["emulated"] = {"value": None, "error": repr(exc)[:200]}
         del model, eng
         torch.cuda.empty_cache()
     return out
@@ -743,7 +761,7 @@ def main():
         other_workloads = None
         if world == 1 and not args.no_other_workloads and args.workload == "crossdock_fullatom_cond" and \
                 args.pockets == "same" and args.timesteps is None and args.batch is None:
-            other_workloads = secondary_workloads(device, args.n_lig, steps=args.secondary_steps)
+            other_workloads = secondary_workloads(device, args.n_lig, steps=args.secondary_steps, emulated_legs=not args.no_emulated_leg)
             try:
                 other_workloads.append(training_leg(device, args.n_lig))
             except Exception as exc:      # the training leg must not cost the benchmark line

@@ -76,9 +76,9 @@ def test_emulated_rows_spanning_many_tiles(arch, max_wg, emu6, monkeypatch):
     GP.test_rows_spanning_many_tiles(arch, max_wg, "32", monkeypatch)
 
 
-def test_emulated_chains_vs_golden_and_invariances(emu6):
-    GP.test_bitwise_reproducible_and_forced_multi_tile_loop()                   # the emulated path is bitwise reproducible too
-    GP.test_batch_composition_invariance_bitwise()                              # ... and independent of the batch composition
+def test_emulated_chains_vs_golden_and_invariances(emu6, monkeypatch):
+    GP.test_bitwise_reproducible_and_forced_multi_tile_loop("32", monkeypatch)  # the emulated path is bitwise reproducible too
+    GP.test_batch_composition_invariance_bitwise("32", monkeypatch)             # ... and independent of the batch composition
     for name in ("ddpm_small_cond", "ddpm_small_variant"):
         GP.test_sample_given_pocket_free_running(name)
     GP.test_cond_inpaint_and_diversify_vs_golden()
