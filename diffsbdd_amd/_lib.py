@@ -127,6 +127,15 @@ SIGNATURES = {
     "dsbdd_train_radial_backward": (C.c_int, [_P, _P, _P, _P, _P]),
     "dsbdd_train_wgrad": (C.c_int, [_P, _P, _I32, _P, _I32, _I64, _I32, _I32, _P, _P, C.c_size_t]),
     "dsbdd_train_colsum": (C.c_int, [_P, _P, _I32, _I64, _I32, _P, _P, C.c_size_t]),
+    "dsbdd_train_net_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "dsbdd_train_net_destroy": (None, [_P]),
+    "dsbdd_train_net_param_count": (C.c_int, [_P]),
+    "dsbdd_train_net_pack_bytes": (C.c_size_t, [_P]),
+    "dsbdd_train_net_workspace_bytes": (C.c_size_t, [_P, C.POINTER(TrainGraph)]),
+    "dsbdd_train_net_forward": (C.c_int, [_P, _P, C.POINTER(TrainGraph), C.POINTER(_P), _P, C.c_size_t, _P, C.c_size_t, _P, _P,
+                                          _P, _I64, _I32, _P, _P, _P]),
+    "dsbdd_train_net_backward": (C.c_int, [_P, _P, C.POINTER(TrainGraph), C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t, _P,
+                                           C.c_size_t, _I64, _P, _P, _P, _P]),
 }
 
 _lib = None

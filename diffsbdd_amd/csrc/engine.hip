@@ -2025,3 +2025,6 @@ int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int
 }
 
 }  // extern "C"
+
+// ---- the training step as one launch sequence per direction (round 6) ------------------------------------------------
+#include "train_net.h"

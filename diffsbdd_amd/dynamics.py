@@ -208,14 +208,20 @@ class EGNNDynamics(nn.Module):
         wants_grad = torch.is_grad_enabled() and (self.training or any(
             isinstance(v, torch.Tensor) and v.requires_grad for v in (xh_atoms, xh_residues, t)))
         if wants_grad:
-            # the training step: forward AND backward on the HIP kernels (train_hip.py: autograd
-            # Functions over csrc/train.h); DSBDD_TRAIN=torch selects round 3's eager torch path (train_path.py, A/B)
+            # the training step: forward AND backward on the HIP kernels.  Default (round 6): ONE autograd
+            # node over one C++ launch sequence per direction (train_net.py, csrc/train_net.h).  A/B switches:
+            # DSBDD_TRAIN=functions -- the per-stage autograd Functions of rounds 4 - 5 (train_hip.py over csrc/train.h);
+            # DSBDD_TRAIN=torch -- round 3's eager torch path (train_path.py)
             import os
-            if os.environ.get("DSBDD_TRAIN", "hip") == "torch":
+            mode = os.environ.get("DSBDD_TRAIN", "net")
+            if mode == "torch":
                 from .train_path import dynamics_forward_autograd
                 return dynamics_forward_autograd(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
-            from .train_hip import dynamics_forward_hip
-            return dynamics_forward_hip(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+            if mode in ("functions", "hip"):
+                from .train_hip import dynamics_forward_hip
+                return dynamics_forward_hip(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
+            from .train_net import dynamics_forward_net
+            return dynamics_forward_net(self, xh_atoms, xh_residues, t, mask_atoms, mask_residues)
         with torch.no_grad():
             return self._forward_hip(xh_atoms, xh_residues, t, mask_atoms, mask_residues)
 

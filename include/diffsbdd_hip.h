@@ -457,6 +457,41 @@ int dsbdd_train_wgrad(void* stream, const float* A, int32_t lda, const float* B,
 int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int32_t N, float* out, void* scratch,
                        size_t scratch_bytes);
 
+/* ---- the training step as ONE launch sequence per direction (round 6; csrc/train_net.h) ---------------------------
+ * Replaces, for the training step, the composition of the building blocks above by PyTorch autograd nodes:
+ * lightning_modules.py:337-363 -> conditional_model.py:202-330 / en_diffusion.py:336-469 -> EGNNDynamics.forward
+ * (dynamics.py:87-167) under autograd.  The reference-side binding is ONE torch.autograd.Function.
+ *
+ * params / grads: the module's parameter tensors in nn.Linear layout [out][in], in the order
+ *   {atom_encoder.0, atom_encoder.2, atom_decoder.0, atom_decoder.2, residue_encoder.0, residue_encoder.2,
+ *    residue_decoder.0, residue_decoder.2}.{weight, bias}, [edge_embedding.weight], egnn.embedding.{weight, bias},
+ *   egnn.embedding_out.{weight, bias}, then per block i: per sublayer s gcl_s.{edge_mlp.0, edge_mlp.2, node_mlp.0,
+ *   node_mlp.2, [att_mlp.0]}.{weight, bias}, gcl_equiv.{coord_mlp.0, coord_mlp.2}.{weight, bias}, coord_mlp.4.weight,
+ *   [cross_product_mlp.{0, 2}.{weight, bias}]
+ * (dsbdd_train_net_param_count entries; the aliased cross_product_mlp.4.weight IS coord_mlp.4.weight and is not listed:
+ * its gradient is the sum over both MLPs).  Every gradient tensor is OVERWRITTEN.
+ * graph: dsbdd_build_edges + dsbdd_train_edge_rev on the call's input coordinates (n_edges is a host value).
+ * pack: persistent caller-owned buffer (dsbdd_train_net_pack_bytes) for the re-laid-out weights, rewritten by every
+ * forward; ws: per-call workspace (dsbdd_train_net_workspace_bytes) that carries the activations from forward to backward.
+ * Nothing is allocated by the library; no host synchronisation inside (beyond the first call's descriptor upload).
+ * zero_nan: training mode replaces NaN velocities by 0 (dynamics.py:155-159); otherwise bit 1 of *status is raised.
+ * e_upd (backward): row_ptr[n_lig] as a host value (pocket-conditioned models; ignored when update_pocket_coords).
+ * d_xh_lig / d_xh_pocket: gradients w.r.t. the inputs, or NULL. */
+typedef struct dsbdd_train_net dsbdd_train_net;
+int dsbdd_train_net_create(const dsbdd_config* cfg, dsbdd_train_net** out);
+void dsbdd_train_net_destroy(dsbdd_train_net* net);
+int dsbdd_train_net_param_count(const dsbdd_train_net* net);
+size_t dsbdd_train_net_pack_bytes(const dsbdd_train_net* net);
+size_t dsbdd_train_net_workspace_bytes(const dsbdd_train_net* net, const dsbdd_train_graph* g);
+int dsbdd_train_net_forward(dsbdd_train_net* net, void* stream, const dsbdd_train_graph* g, const float* const* params,
+                            void* pack, size_t pack_bytes, void* ws, size_t ws_bytes, const float* xh_lig,
+                            const float* xh_pocket, const float* t, int64_t t_count, int32_t zero_nan, float* eps_lig,
+                            float* eps_pocket, int32_t* status);
+int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_train_graph* g, const float* const* params,
+                             float* const* grads, void* pack, size_t pack_bytes, void* ws, size_t ws_bytes,
+                             int64_t e_upd, const float* d_eps_lig, const float* d_eps_pocket, float* d_xh_lig,
+                             float* d_xh_pocket);
+
 /* ---- post-processing of a finished batch ------------------*/
 /* Distance-based bond orders of a batch of molecules: replaces
  * get_bond_order_batch + the (X, A, E) step of make_mol_edm
