@@ -124,6 +124,7 @@ class EGNNTrainFunction(torch.autograd.Function):
         ctx.in_grad = (xh_atoms.requires_grad, xh_residues.requires_grad)
         ctx.shapes = (xl.shape, xp.shape)
         ctx.mark_non_differentiable(status)
+        ctx.set_materialize_grads(False)       # an unused output arrives as None (see backward), not as a zero tensor
         return eps_l, eps_p, status
 
     @staticmethod
@@ -132,6 +133,7 @@ class EGNNTrainFunction(torch.autograd.Function):
         lib = net.lib
         dev = ps[0].device
         f32 = dict(dtype=torch.float32, device=dev)
+        ctx.none_l, ctx.none_p = d_l is None, d_p is None
         d_l = torch.zeros(ctx.shapes[0], **f32) if d_l is None else d_l.to(**f32).contiguous()
         d_p = torch.zeros(ctx.shapes[1], **f32) if d_p is None else d_p.to(**f32).contiguous()
         grads = [torch.empty_like(p) for p in ps]
@@ -144,6 +146,13 @@ class EGNNTrainFunction(torch.autograd.Function):
             dx_l.data_ptr() if dx_l is not None else None, dx_p.data_ptr() if dx_p is not None else None),
             "dsbdd_train_net_backward")
         ctx.ws = None          # the activations are consumed
+        # a decoder whose output the loss never read has NO gradient (autograd's None, as for the reference's modules:
+        # the pocket-conditioned loss ignores eps_pocket, so residue_decoder stays untouched by the optimiser), not zeros
+        for unused, prefix in ((ctx.none_l, "atom_decoder."), (ctx.none_p, "residue_decoder.")):
+            if unused:
+                for i, n in enumerate(net.names):
+                    if n.startswith(prefix):
+                        grads[i] = None
         return (None, None, None, None, None, dx_l if want_l else None, dx_p if want_p else None, *grads)
 
 

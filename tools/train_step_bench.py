@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--paths", default="hip,torch")
+    ap.add_argument("--paths", default="net,functions,torch",
+                    help="DSBDD_TRAIN values: net (one launch sequence per direction, round 6), functions (= hip: the per-stage autograd "
+                         "Functions of rounds 4 - 5), torch (round 3's eager path)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     key = "ca" if "ca_" in a.workload else "fa"
