@@ -1772,8 +1772,8 @@ static TrainScratch carve_train(char* base, int H, int64_t N, int64_t E) {
   const size_t EH = (size_t)(E > 0 ? E : 1) * H;
   const int slots = 256 * 8;
   t.dz2 = take(EH); t.a1 = take(EH); t.dz1 = take(EH);
-  t.partA = take((size_t)slots * kPartA * H); t.partB = take((size_t)slots * kPartB * H);
-  t.rtmp = take((size_t)(slots / 32 + 1) * kPartB * H);
+  t.partA = take((size_t)slots * kPartAll * H); t.partB = t.partA;      // one [8][H] slot per workgroup for both kernels
+  t.rtmp = take((size_t)(slots / 32 + 1) * kPartAll * H);
   t.wg_floats = wgrad_floats_upto(E > N ? E : N, H, H);   // any K <= max(E, N): the coordinate stage runs on an edge prefix
   t.wg = take(t.wg_floats);
   t.gd = take(E + 1); t.gxr = take(3 * (size_t)E + 4); t.gxc = take(3 * (size_t)E + 4); t.gm = take(3 * (size_t)E + 4);
@@ -1832,13 +1832,13 @@ static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph*
   // A: dz2, a1, partial bias / head vectors
   a.Bmat = m->W2T; a.dz_out = ts.dz2; a.part = ts.partA;
   HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
-  HIP_TRY(reduce_parts(s, ts.partA, slots, (size_t)kPartA * H, kPartA * H, out->d_vec + 5 * (size_t)H, ts.rtmp));
   // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
   { const int rc = wgrad_impl(s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg, ts.wg_floats); if (rc != DSBDD_OK) return rc; }
   // B: dz1, partial first-layer vectors, per-edge distance gradients
   a.Bmat = m->W2; a.dz_in = ts.dz2; a.dz_out = ts.dz1; a.part = ts.partB;
   HIP_TRY(launch_bwd_b(H, s, a, grid));
-  HIP_TRY(reduce_parts(s, ts.partB, slots, (size_t)kPartB * H, kPartB * H, out->d_vec, ts.rtmp));
+  // ONE ordered reduction for both kernels' partial vectors (they share the grid and the [8][H] slots) -> d_vec [8][H]
+  HIP_TRY(reduce_parts(s, ts.partB, slots, (size_t)kPartAll * H, kPartAll * H, out->d_vec, ts.rtmp));
   // dP / dQ
   const int N = (int)g->n_nodes;
   hipLaunchKernelGGL(rows_gather_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.dz1, H, g->row_ptr,

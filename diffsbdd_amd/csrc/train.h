@@ -46,13 +46,16 @@ struct TrainEdgeArgs {
   float* a1_out;         // kernel A: [E][H]
   const float* dz_in;    // kernel B: dz2 [E][H]
   float* dz_out;         // kernel A: dz2 [E][H]; kernel B: dz1 [E][H]
-  float* part;           // [gridDim.x][NPV][H] partial vectors, one slot per workgroup (its 8 (wave, half) sums added in order)
+  float* part;           // [gridDim.x][8][H] partial vectors, one slot per workgroup (its 8 (wave, half) sums added in order):
+                         // kernel B writes rows 0 .. 4, kernel A rows 5 .. 7 (same grid for both)
   float* gxr; float* gxc; float* gm;   // COORD kernel A: [E][3] gradient pieces for x[row], x[col], the sample mean
   float* gd; float* gd0; // kernel B: [E] gradient w.r.t. the current and the input squared distance
 };
 
 constexpr int kPartA = 3;   // kernel A: d_b2, d_head (att_w / w3), [0] = d_att_b
 constexpr int kPartB = 5;   // kernel B: d_wd, d_wd0, d_tab[0..2]
+constexpr int kPartAll = kPartA + kPartB;   // one [8][H] slot per workgroup, B's rows first: the layout of dsbdd_train_mlp_grad::d_vec,
+                                            // so ONE ordered reduction behind kernel B serves both kernels (round 6)
 
 __device__ __forceinline__ float dsilu_from(float z, float sg) { return sg * (1.0f + z * (1.0f - sg)); }
 
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += sB[(size_t)q * kPartA * H + i];
-    p.part[(size_t)blockIdx.x * kPartA * H + i] = v;
+    p.part[(size_t)blockIdx.x * kPartAll * H + (size_t)kPartB * H + i] = v;      // rows 5 .. 7 of the workgroup's [8][H] slot
   }
 }
 
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_b_kernel(TrainEdgeArgs p
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += sB[(size_t)q * kPartB * H + i];
-    p.part[(size_t)blockIdx.x * kPartB * H + i] = v;
+    p.part[(size_t)blockIdx.x * kPartAll * H + i] = v;                           // rows 0 .. 4 of the workgroup's [8][H] slot
   }
 }
 
