@@ -1710,9 +1710,11 @@ static hipError_t reduce_parts(hipStream_t s, const float* part, int n_part, siz
 struct WgradPlan { int chunks, kc; size_t floats; };
 static WgradPlan wgrad_plan(int64_t K, int64_t M, int64_t N) {
   // short chunks for the node-level gradients (K = a few thousand rows: the launch is a latency chain), at most
-  // 768 / tiles chunks for the edge-level ones (the reduction reads every partial once)
+  // 256 / tiles chunks for the edge-level ones: <= 96 partial slabs reduce in ONE ordered launch (round 6: 768 -> 256,
+  // 14.46 -> 14.03 ms per training step, profiles/r6_train_step.md; round 4's sweep had preferred 768 when the reduction
+  // was two launches either way)
   static const int min_kc = [] { const char* v = getenv("DSBDD_WGRAD_MINKC"); return v && atoi(v) >= 32 ? atoi(v) : 64; }();
-  static const int max_wg = [] { const char* v = getenv("DSBDD_WGRAD_MAXWG"); return v && atoi(v) >= 1 ? atoi(v) : 768; }();
+  static const int max_wg = [] { const char* v = getenv("DSBDD_WGRAD_MAXWG"); return v && atoi(v) >= 1 ? atoi(v) : 256; }();
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
   int64_t chunks = (K + min_kc - 1) / min_kc;
   const int64_t cap = max_wg / tiles > 1 ? max_wg / tiles : 1;
@@ -1732,7 +1734,7 @@ static WgradPlan wgrad_plan(int64_t K, int64_t M, int64_t N) {
 // stage's backward calls wgrad with K = e_upd < E on a scratch sized for E.)
 static size_t wgrad_floats_upto(int64_t K_max, int64_t M, int64_t N) {
   static const int min_kc = [] { const char* v = getenv("DSBDD_WGRAD_MINKC"); return v && atoi(v) >= 32 ? atoi(v) : 64; }();
-  static const int max_wg = [] { const char* v = getenv("DSBDD_WGRAD_MAXWG"); return v && atoi(v) >= 1 ? atoi(v) : 768; }();
+  static const int max_wg = [] { const char* v = getenv("DSBDD_WGRAD_MAXWG"); return v && atoi(v) >= 1 ? atoi(v) : 256; }();
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int64_t cap = max_wg / tiles > 1 ? max_wg / tiles : 1;
   int64_t chunks = (K_max + min_kc - 1) / min_kc;

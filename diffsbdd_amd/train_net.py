@@ -13,6 +13,7 @@ gradients, which neither implements), `DSBDD_TRAIN=torch` round 3's eager path.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -77,11 +78,13 @@ class _Net:
             pass
 
 
+_NETS = weakref.WeakKeyDictionary()     # module -> _Net; kept OUT of the module (deepcopy / pickling of the module stay plain)
+
+
 def _net_of(module):
-    net = module.__dict__.get("_train_net")
+    net = _NETS.get(module)
     if net is None:
-        net = _Net(module)
-        module.__dict__["_train_net"] = net        # (not a registered submodule / buffer: plain attribute)
+        net = _NETS[module] = _Net(module)
     return net
 
 
@@ -130,6 +133,9 @@ class EGNNTrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_l, d_p, _d_status):
         net, g, ws, pack, ps = ctx.net, ctx.g, ctx.ws, ctx.pack, ctx.ps
+        if ws is None:
+            raise RuntimeError("EGNNTrainFunction keeps its activations for ONE backward pass (retain_graph / a second "
+                               "backward through the same forward is not supported; DSBDD_TRAIN=functions is the per-stage path)")
         lib = net.lib
         dev = ps[0].device
         f32 = dict(dtype=torch.float32, device=dev)

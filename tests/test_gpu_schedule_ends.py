@@ -88,8 +88,8 @@ def test_reverse_steps_at_the_schedule_ends_and_final_decode(arch, B):
 def test_heterogeneous_pocket_batches_teacher_forced_vs_oracle(n_same):
     """bench.py's `--pockets mixed` (n_same = 0: 64 distinct pockets) and `grouped` (40 copies of one pocket + 24
     singletons) batches at B = 64: the frame / group / cone decisions `_begin_chain` takes for them (every pocket its own
-    representative resp. 25 groups; the per-chain rule leaves the forward cone off: radii [4,4,4,3,2,1]), then two
-    teacher-forced iterations of the anchored loop body and one free reverse step against the oracle."""
+    representative resp. 25 groups; the per-chain rule leaves the forward cone off: radii [4,4,4,3,2,1]), then one
+    teacher-forced iteration of the anchored loop body and one free reverse step against the oracle."""
     from diffsbdd_amd import synthetic
     arch, B, n_lig = "crossdock_fullatom_cond", 64, 23
     cfg, dd = W.arch_cfg(arch)
@@ -124,7 +124,7 @@ def test_heterogeneous_pocket_batches_teacher_forced_vs_oracle(n_same):
         co = model._coefs(T)
         eng = model.dynamics.engine()
         worst = -1.0
-        for k, mode in enumerate(("inpaint", "inpaint", "sample")):
+        for k, mode in enumerate(("inpaint", "sample")):
             s = s0 - k
             z_d.copy_(z_o); xp_d.copy_(xp_o)
             pre = do.NoiseTape(60 + k)

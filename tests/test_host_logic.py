@@ -565,6 +565,43 @@ def test_per_chain_engine_choices_are_pure_functions_of_the_batch():
     assert D.splitk_auto(ca, p_ca["mask"], 32, 6, 6, 2, 192, pocket_x=p_ca["x"], cutoff_pocket=5.0) == 0   # hidden_nf 256 only
 
 
+def test_training_net_parameter_order_and_sizes():
+    """Round 6, the training step as one launch sequence (csrc/train_net.h): the parameter order the C side indexes is the
+    module's own construction order minus the aliased cross_product_mlp.4.weight; the size queries are host-only."""
+    import ctypes as C
+    from diffsbdd_amd import synthetic
+    from diffsbdd_amd.dynamics import EGNNDynamics
+    from diffsbdd_amd.engine import make_config
+    from diffsbdd_amd.train_net import param_names
+    lib = _lib.load()
+    for arch in ("small_cond", "small_joint", "small_variant", "crossdock_fullatom_cond"):
+        cfg, _ = synthetic.arch_cfg(arch)
+        m = EGNNDynamics(**cfg, device="cpu")
+        names = param_names(m._hp)
+        named = dict(m.named_parameters())
+        assert set(names) == set(named)                                  # named_parameters() lists the shared tensor once
+        assert names == [k for k in synthetic.dynamics_param_shapes(cfg) if not k.endswith("cross_product_mlp.4.weight")]
+        h = C.c_void_p()
+        c = make_config(**m._hp)
+        assert lib.dsbdd_train_net_create(C.byref(c), C.byref(h)) == _lib.OK
+        try:
+            assert lib.dsbdd_train_net_param_count(h) == len(names)
+            assert lib.dsbdd_train_net_pack_bytes(h) > 4 * sum(p.numel() for p in named.values())
+            dummy = 4096
+            g = _lib.TrainGraph(erow=dummy, ecol=dummy, ed0=dummy, row_ptr=dummy, deg=dummy, rev=dummy, node_batch=dummy,
+                                lig_off=dummy, poc_off=dummy, n_lig=23, n_nodes=309, n_edges=5000, batch=1)
+            small = lib.dsbdd_train_net_workspace_bytes(h, C.byref(g))
+            g.n_edges = 50000
+            assert lib.dsbdd_train_net_workspace_bytes(h, C.byref(g)) > small > 0
+            g.n_nodes = 0
+            assert lib.dsbdd_train_net_workspace_bytes(h, C.byref(g)) == 0                  # not a graph
+        finally:
+            lib.dsbdd_train_net_destroy(h)
+    bad = make_config(**{**m._hp, "hidden_nf": 96})
+    h = C.c_void_p()
+    assert lib.dsbdd_train_net_create(C.byref(bad), C.byref(h)) == _lib.ERR_ARG
+
+
 def test_training_c_abi_argument_errors_and_sizes():
     """The dsbdd_train_* entry points reject misuse with DSBDD_ERR_ARG / _CAPACITY before anything is launched (no GPU)."""
     lib = _lib.load()
@@ -574,9 +611,10 @@ def test_training_c_abi_argument_errors_and_sizes():
     assert lib.dsbdd_train_wgrad_scratch_bytes(0, 4, 4) == 0
     w = lib.dsbdd_train_wgrad_scratch_bytes(91152, 256, 256)
     assert 256 * 256 * 4 <= w <= 200 * 256 * 256 * 4
-    # the split-K plan is not monotonic in K (K = 30 000 needs more chunks than K = 160 000 at 256 x 256);
-    # the scratch bound must cover every prefix K' <= K -- the coordinate stage's backward runs on an edge prefix
-    assert lib.dsbdd_train_wgrad_plan_bytes(30000, 256, 256) > lib.dsbdd_train_wgrad_plan_bytes(160000, 256, 256)
+    # the split-K plan is not monotonic in K (the chunk length is rounded up to 32 rows after the chunk cap: with
+    # round 6's cap of 256 workgroups K = 10 000 needs more chunks than K = 16 385 at 256 x 256); the scratch bound must cover
+    # every prefix K' <= K -- the coordinate stage's backward runs on an edge prefix
+    assert lib.dsbdd_train_wgrad_plan_bytes(10000, 256, 256) > lib.dsbdd_train_wgrad_plan_bytes(16385, 256, 256)
     rng = np.random.default_rng(0)
     for H in (64, 128, 192, 256):
         for E in [int(v) for v in rng.integers(1, 400000, 40)] + [30857, 160000, 91152]:
