@@ -43,6 +43,11 @@ struct TnUnpackDesc {     // one edge MLP's first layer: d W1 [H][ld], d b1 [H],
   const float* W1; const float* emb; int enf; int H;
 };
 struct TnCopyDesc { float* dst; const float* a; const float* b; int n; };    // dst[i] = a[i] (+ b[i])
+// The gradient-assembly tables travel BY VALUE in the kernel arguments (<= 4 KB): they depend on the per-call workspace,
+// and a per-step host-to-device copy of a table would need either pinned memory or a synchronisation to be safe.
+constexpr int kTnUnpackPerLaunch = 16, kTnCopyPerLaunch = 64;
+struct TnUnpackTable { TnUnpackDesc d[kTnUnpackPerLaunch]; };
+struct TnCopyTable { TnCopyDesc d[kTnCopyPerLaunch]; };
 
 __global__ void tn_pack_kernel(const TnPackDesc* descs) {
   const TnPackDesc d = descs[blockIdx.y];
@@ -75,8 +80,8 @@ __global__ void tn_tab_kernel(const TnTabDesc* descs) {
   }
 }
 
-__global__ void tn_unpack_kernel(const TnUnpackDesc* descs) {
-  const TnUnpackDesc d = descs[blockIdx.y];
+__global__ void tn_unpack_kernel(const TnUnpackTable tab) {
+  const TnUnpackDesc& d = tab.d[blockIdx.y];
   const int H = d.H, ld = d.ld, total = H * ld;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int o = i / ld, c = i % ld;
@@ -105,8 +110,8 @@ __global__ void tn_unpack_kernel(const TnUnpackDesc* descs) {
   }
 }
 
-__global__ void tn_copy_kernel(const TnCopyDesc* descs) {
-  const TnCopyDesc d = descs[blockIdx.y];
+__global__ void tn_copy_kernel(const TnCopyTable tab) {
+  const TnCopyDesc& d = tab.d[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += gridDim.x * blockDim.x)
     d.dst[i] = d.b ? d.a[i] + d.b[i] : d.a[i];
 }
@@ -275,9 +280,6 @@ struct dsbdd_train_net {
   std::vector<const float*> last_params;
   void* last_pack = nullptr;
   int n_pack = 0, n_tab = 0;
-  std::vector<TnUnpackDesc> ud[2];
-  std::vector<TnCopyDesc> cd[2];
-  int flip = 0;
 };
 
 // sizes of one call
@@ -342,7 +344,6 @@ struct TnWs {
   float *d_vel, *deh_l, *deh_p, *d_h[2], *d_x[2], *d_xg, *d_pq4, *d_pq, *da, *dz, *d_agg, *xcat, *d_hout, *d_h0, *d_hf_l, *d_hf_p,
       *d_small, *gd0, *gd0_tot, *d_mean, *colscr, *dWpq, *d_vec, *demb_part, *wg;
   size_t wg_floats;
-  TnUnpackDesc* d_unpack; TnCopyDesc* d_copy;
   char* scratch; size_t scratch_bytes;
   size_t bytes;
 };
@@ -379,8 +380,6 @@ static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d) {
     for (const auto& sh : shapes) { const size_t f = wgrad_floats_upto((int64_t)N, sh[0], sh[1]); if (f > w.wg_floats) w.wg_floats = f; }
   }
   w.wg = take(w.wg_floats);
-  w.d_unpack = reinterpret_cast<TnUnpackDesc*>(takeb(sizeof(TnUnpackDesc) * 64));
-  w.d_copy = reinterpret_cast<TnCopyDesc*>(takeb(sizeof(TnCopyDesc) * 256));
   w.scratch_bytes = carve_train(nullptr, d.H, d.N, d.E).bytes;
   w.scratch = takeb(w.scratch_bytes);
   (void)c;
@@ -596,12 +595,8 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
   const int64_t n_upd = c.update_pocket_coords ? d.N : d.n_l;
   if (c.update_pocket_coords) e_upd = E;         // (else: row_ptr[n_lig], the edge prefix of the ligand rows, a host value)
   if (e_upd < 0 || e_upd > E) return fail(DSBDD_ERR_ARG, "e_upd out of range");
-  // (host-side descriptor tables: members of the net, two sets used alternately, so that a table is not rewritten
-  // while the previous step's asynchronous copy of it could still be in flight)
-  net->flip ^= 1;
-  std::vector<TnUnpackDesc>& ud = net->ud[net->flip];
-  std::vector<TnCopyDesc>& cd = net->cd[net->flip];
-  ud.clear(); cd.clear();
+  std::vector<TnUnpackDesc> ud;      // gradient-assembly tables, launched at the end (by value, see TnUnpackTable)
+  std::vector<TnCopyDesc> cd;
   const float* emb = ix.emb_tab >= 0 ? P[ix.emb_tab] : nullptr;
   const int ld1 = 2 * H + d.A;
   int mlp_no = 0;                        // running index of the edge MLPs (d_vec / dWpq / demb_part slots)
@@ -757,13 +752,20 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
   { int rc = mlp2_bwd(w.d_h0, JP, J, 2 * a, a, w.hf_l, a, w.ze_l, w.ae_l, ix.ae0, pk.ae0, ix.ae2, pk.ae2, w.d_hf_l, a, nl_, want_in); if (rc) return rc; }
   { int rc = mlp2_bwd(w.d_h0 + (size_t)nl_ * JP, JP, J, 2 * r, r, w.hf_p, r, w.ze_p, w.ae_p, ix.re0, pk.re0, ix.re2, pk.re2, w.d_hf_p, r, np_, want_in); if (rc) return rc; }
   // the assembled first layers, the copied vectors, the edge-type embedding
-  if (ud.size() > 64 || cd.size() > 256) return fail(DSBDD_ERR_CAPACITY, "too many layers for the gradient descriptor tables");
-  HIP_TRY(hipMemcpyAsync(w.d_unpack, ud.data(), ud.size() * sizeof(TnUnpackDesc), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(w.d_copy, cd.data(), cd.size() * sizeof(TnCopyDesc), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(tn_unpack_kernel, dim3(64, (unsigned)ud.size()), dim3(256), 0, s, (const TnUnpackDesc*)w.d_unpack);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(tn_copy_kernel, dim3(1, (unsigned)cd.size()), dim3(256), 0, s, (const TnCopyDesc*)w.d_copy);
-  HIP_TRY(hipGetLastError());
+  for (size_t o = 0; o < ud.size(); o += kTnUnpackPerLaunch) {
+    TnUnpackTable tab{};
+    const int n = (int)std::min<size_t>(kTnUnpackPerLaunch, ud.size() - o);
+    for (int i = 0; i < n; ++i) tab.d[i] = ud[o + i];
+    hipLaunchKernelGGL(tn_unpack_kernel, dim3(64, (unsigned)n), dim3(256), 0, s, tab);
+    HIP_TRY(hipGetLastError());
+  }
+  for (size_t o = 0; o < cd.size(); o += kTnCopyPerLaunch) {
+    TnCopyTable tab{};
+    const int n = (int)std::min<size_t>(kTnCopyPerLaunch, cd.size() - o);
+    for (int i = 0; i < n; ++i) tab.d[i] = cd[o + i];
+    hipLaunchKernelGGL(tn_copy_kernel, dim3(1, (unsigned)n), dim3(256), 0, s, tab);
+    HIP_TRY(hipGetLastError());
+  }
   if (emb) {
     hipLaunchKernelGGL(tn_sum_parts_kernel, dim3(1), dim3(256), 0, s, (const float*)w.demb_part, mlp_no, 3 * d.enf, 3 * d.enf, G[ix.emb_tab]);
     HIP_TRY(hipGetLastError());

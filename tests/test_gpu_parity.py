@@ -715,7 +715,13 @@ def test_edge_granule_variants_agree(arch, monkeypatch):
     for other in variants[1:]:
         for u, v in zip(out["32"], out[other]):
             assert (u - v).abs().max().item() < 2e-5 * max(1.0, v.abs().max().item()), other
-        assert not torch.equal(out["32"][0], out[other][0]) or arch == "small_joint"     # (the variant really switched)
+        # (the variant really switched -- except under the emulated path of the DSBDD_EMU gate run, where the engine ignores
+        # both masks by design: every edge stage then runs the emulated 32-edge kernel, include/diffsbdd_hip.h DSBDD_OPT_EMU)
+        import os
+        if os.environ.get("DSBDD_EMU", "0") in ("", "0"):
+            assert not torch.equal(out["32"][0], out[other][0]) or arch == "small_joint"
+        else:
+            assert torch.equal(out["32"][0], out[other][0])
 
 
 def test_ligand_without_pocket_neighbours_and_batch_of_one():

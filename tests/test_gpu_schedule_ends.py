@@ -212,3 +212,36 @@ def test_joint_repaint_iteration_with_jump_teacher_forced_vs_oracle():
     finally:
         model.set_noise_source(None)
         model._end_chain()
+
+
+def test_splitk_auto_chain_on_the_calpha_config_vs_oracle_chain():
+    """`ddpm.edge_splitk = "auto"` (EnVariationalDiffusion.splitk_auto) through the public sampling call: on
+    crossdock_ca_cond every stage goes to the split-K kernels (csrc/edge_splitk.h), the mask reaches the engine as a
+    chain constant, and a short free-running `sample_given_pocket` equals the oracle's chain on the same noise tape
+    (1e-3 on coordinates, identical atom types: the tolerance of the other free-running chains); the same chain with the
+    default kernels agrees with it to rounding, and with `edge_splitk = None` the engine's mask is back to 0."""
+    from diffsbdd_amd import _lib, synthetic
+    arch, B, T = "crossdock_ca_cond", 8, 4
+    cfg, dd = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, 0)
+    pocket = synthetic.load_pocket("ca", B, "cpu")
+    n_lig = torch.full((B,), 23)
+    om = _oracle_model(arch, sd)
+    tape = do.NoiseTape(12)
+    with oracle_threads():
+        o_l, o_p, _, _ = do.cond_sample_given_pocket(om, {k: v.clone() for k, v in pocket.items()}, n_lig, tape, timesteps=T)
+    outs = {}
+    for mode in ("auto", None):
+        model = _make_ddpm(arch, sd)
+        model.edge_splitk = mode
+        model.set_noise_source(do.NoiseReplay(tape.draws))
+        h_l, h_p, _, _ = model.sample_given_pocket({k: v.clone() for k, v in pocket.items()}, n_lig, timesteps=T)
+        mask = model.dynamics.engine().get_option(_lib.OPT_SPLITK) & 0xFFFFFFFF
+        assert mask == (0x003F003F if mode == "auto" else 0), hex(mask)
+        assert (h_l.cpu()[:, :3] - o_l[:, :3]).abs().max().item() < 1e-3
+        assert torch.equal(h_l.cpu()[:, 3:].long(), o_l[:, 3:].long())
+        outs[mode] = h_l.cpu()
+    assert (outs["auto"] - outs[None]).abs().max().item() < 1e-4
+    import os
+    if os.environ.get("DSBDD_EMU", "0") in ("", "0"):                     # (the emulated path ignores the mask by design)
+        assert not torch.equal(outs["auto"], outs[None])                  # the variant really ran
