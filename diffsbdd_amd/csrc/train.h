@@ -192,6 +192,10 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
       const int4 v = *reinterpret_cast<const int4*>(s_row + 8 * q4 + 4 * half);
       rowm[4 * q4] = v.x; rowm[4 * q4 + 1] = v.y; rowm[4 * q4 + 2] = v.z; rowm[4 * q4 + 3] = v.w;
     }
+    // from here on rowm[q] is the BYTE offset of this lane's first column in row q's d_agg row (-1: inactive entry): the
+    // row-gathered loads of the epilogue take it as it is, everything else only looks at its sign
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rowm[q] = rowm[q] >= 0 ? (rowm[q] * H + j) * 4 : -1;
     auto bcast16 = [&](const float* src, float (&dst)[16]) {     // dst[q] = src[mfma_row(q, lane)]
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -204,30 +208,40 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
       float att[16], tt[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) { att[q] = 1.f; tt[q] = 0.f; }
-      if (attention) {
-        float part[16];
+      // d_out = d_agg[row] / nf in accumulator layout: 16 row-gathered loads per column tile.  They are requested one
+      // column tile AHEAD of their use (round 6: the epilogue's waves were waiting half of their cycles on these loads in
+      // 16 dependent batches, profiles/r6q_train_pmc_2.md), and the gate's dot product and s = sum_f d_out m share ONE
+      // SiLU pass over the accumulators (same operations in the same order as the two passes they replace: same bits).
+      // (buffer loads: one 32-bit byte offset per register row, the column tile as scalar offset; an inactive row's offset
+      // lies outside the descriptor and reads as 0 -- no per-lane 64-bit addresses, no selects)
+      const __amdgpu_buffer_rsrc_t dagg_rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.d_agg), 0, (int)min((size_t)p.n_nodes * H * 4, (size_t)0x7FFFFFFF), 0x00020000);
+      auto load_dout = [&](int c, float (&dst)[16]) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) part[q] = 0.f;
+        for (int q = 0; q < 16; ++q)
+          dst[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dagg_rs, rowm[q], 32 * c * 4, 0)) * inv_norm;
+      };
+      if (attention) {
+        float part[16], part_s[16], dcur[16], dnxt[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { part[q] = 0.f; part_s[q] = 0.f; }
+        load_dout(0, dcur);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
+          if (c + 1 < CT) load_dout(c + 1, dnxt);
           const float aw = sV[6 * H + 32 * c + j];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) part[q] = fmaf(silu(acc[c][q]), aw, part[q]);
-        }
-        const float gate = sigmoidf_fast(reduce16_half_wave(part, j) + att_b);   // register j >> 1 of this half
-        // s = sum_f d_out m   (d_out = d_agg[row] / nf)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) part[q] = 0.f;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-#pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float dout = rowm[q] >= 0 ? p.d_agg[(size_t)rowm[q] * H + 32 * c + j] * inv_norm : 0.f;
-            part[q] = fmaf(dout, silu(acc[c][q]), part[q]);
+            const float m = silu(acc[c][q]);
+            part[q] = fmaf(m, aw, part[q]);
+            part_s[q] = fmaf(dcur[q], m, part_s[q]);
           }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) dcur[q] = dnxt[q];
           __builtin_amdgcn_sched_barrier(0);
         }
-        const float stot = reduce16_half_wave(part, j);
+        const float gate = sigmoidf_fast(reduce16_half_wave(part, j) + att_b);   // register j >> 1 of this half
+        const float stot = reduce16_half_wave(part_s, j);                        // s = sum_f d_out m
         // the 16 registers of this half are rows mfma_row(q, lane) = (q & 3) + 8 (q >> 2) + 4 half
         s_phi[mfma_row(j >> 1, lane)] = gate;
         s_aux[mfma_row(j >> 1, lane)] = stot * gate * (1.0f - gate);
@@ -240,8 +254,11 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
           for (int q = 0; q < 16; ++q) ps += tt[q];
         }
       }
+      float dcur3[16], dnxt3[16];
+      load_dout(0, dcur3);
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
+        if (c + 1 < CT) load_dout(c + 1, dnxt3);
         const float aw = sV[6 * H + 32 * c + j];
         float b2p = 0.f, awp = 0.f;
 #pragma unroll
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
           const float z = acc[c][q];
           const float sg = sigmoidf_fast(z);
           const float m = z * sg;
-          const float dout = rowm[q] >= 0 ? p.d_agg[(size_t)rowm[q] * H + 32 * c + j] * inv_norm : 0.f;
+          const float dout = dcur3[q];
           const float dm = fmaf(tt[q], aw, dout * att[q]);
           const float dz = dm * dsilu_from(z, sg);
           acc[c][q] = dz;
@@ -257,6 +274,8 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
           awp = fmaf(tt[q], m, awp);
         }
         pb2[c] += b2p; pv1[c] += awp;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dcur3[q] = dnxt3[q];
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
