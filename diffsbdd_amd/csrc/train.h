@@ -474,19 +474,27 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_b_kernel(TrainEdgeArgs p
     // ================= epilogue: dz1 = da1 * SiLU'(z1), z1 recomputed in accumulator layout =================
     wave_lds_fence();
     float pg[16], pg0[16];
+    // the row-gathered P / Q values of accumulator row q are requested one row AHEAD of their use (round 6: 16 dependent
+    // load batches per tile left the waves waiting; same arithmetic, same bits)
+    float pv[CT], qv[CT], pvn[CT], qvn[CT];
+    auto load_pq = [&](int q, float (&pd)[CT], float (&qd)[CT]) {
+      const int m = mfma_row(q, lane);
+      const int rowm = s_row[m], colm = s_col[m];
+      const float* Pr = p.P + (size_t)(rowm >= 0 ? rowm : 0) * p.ldpq + j;
+      const float* Qr = p.Q + (size_t)colm * p.ldpq + j;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { pd[c] = Pr[32 * c]; qd[c] = Qr[32 * c]; }
+    };
+    load_pq(0, pv, qv);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
+      if (q + 1 < 16) load_pq(q + 1, pvn, qvn);
       const int m = mfma_row(q, lane);
-      const int rowm = s_row[m], colm = s_col[m], tym = s_ty[m];
+      const int rowm = s_row[m], tym = s_ty[m];
       const float dm = s_d[m], d0m = s_d0[m];
       const bool valid = rowm >= 0;
-      const float* Pr = p.P + (size_t)(valid ? rowm : 0) * p.ldpq + j;
-      const float* Qr = p.Q + (size_t)colm * p.ldpq + j;
       const float* tb = sV + (2 + tym) * H + j;
       float gdp = 0.f, gd0p = 0.f;
-      float pv[CT], qv[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) { pv[c] = Pr[32 * c]; qv[c] = Qr[32 * c]; }
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const float z1 = fmaf(d0m, wd0v[c], fmaf(dm, wdv[c], pv[c] + qv[c])) + tb[32 * c];
@@ -502,6 +510,8 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_b_kernel(TrainEdgeArgs p
         gd0p = fmaf(dz, wd0v[c], gd0p);
       }
       pg[q] = gdp; pg0[q] = gd0p;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { pv[c] = pvn[c]; qv[c] = qvn[c]; }
       __builtin_amdgcn_sched_barrier(0);
     }
     const float gdt = reduce16_half_wave(pg, j);
