@@ -1821,11 +1821,47 @@ static bool mlp_ok(const dsbdd_train_mlp* m) {
   return m && m->P && m->Q && m->wd && m->wd0 && m->tab && m->W2 && m->W2T && m->b2 && (m->ldpq & 3) == 0;
 }
 
+// Side streams of the training backward (round 6, dsbdd_train_net_backward only).  The weight gradients leave the
+// dependency chain of the input gradients, and the two edge MLPs of a coordinate stage are independent of each other:
+// `wg` takes the weight-gradient launches, `co` the second MLP's chain, fork / join by events.  Every kernel and every
+// reduction order is the one of the single-stream sequence (DSBDD_TRAIN_STREAMS=0), so the gradients keep their bits.
+enum { SIDE_CO = 1, SIDE_NODE_WG = 2, SIDE_COORD_WG = 4, SIDE_GCL_WG = 8 };
+struct TrainSide {
+  hipStream_t wg = nullptr, co = nullptr;
+  int mask = 0;                  // SIDE_* : what runs beside the main chain
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  // everything queued on `to` after this call starts after everything queued on `from` before it
+  hipError_t link(hipStream_t from, hipStream_t to) {
+    hipEvent_t e = ev[next++ % ev.size()];
+    const hipError_t r = hipEventRecord(e, from);
+    return r != hipSuccess ? r : hipStreamWaitEvent(to, e, 0);
+  }
+  hipError_t create() {
+    hipError_t r = hipStreamCreateWithFlags(&wg, hipStreamNonBlocking);
+    if (r == hipSuccess) r = hipStreamCreateWithFlags(&co, hipStreamNonBlocking);
+    ev.resize(32);
+    for (size_t i = 0; r == hipSuccess && i < ev.size(); ++i) r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    return r;
+  }
+  void destroy() {
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    ev.clear();
+    if (wg) (void)hipStreamDestroy(wg);
+    if (co) (void)hipStreamDestroy(co);
+    wg = co = nullptr;
+  }
+};
+
 // the backward of ONE edge MLP: kernel A -> weight gradient -> kernel B -> node gathers; returns the per-edge gradient
-// w.r.t. the current squared distance in ts.gd
+// w.r.t. the current squared distance in ts.gd.  `sd` (optional): the weight gradient goes to sd->wg; unless `linked`,
+// the chain first waits for that stream (the previous weight gradient reads ts.dz2 / ts.a1 / ts.wg, which kernel A and
+// this weight gradient overwrite).
 static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
-                        int64_t E, TrainEdgeArgs a, const dsbdd_train_mlp_grad* out, const TrainScratch& ts) {
+                        int64_t E, TrainEdgeArgs a, const dsbdd_train_mlp_grad* out, const TrainScratch& ts,
+                        TrainSide* sd = nullptr, bool linked = false) {
   const int grid = train_grid(E);
+  if (sd && !linked) HIP_TRY(sd->link(sd->wg, s));
   const int slots = grid;                  // one partial-vector slot per workgroup
   a.erow = g->erow; a.ecol = g->ecol; a.ed0 = g->ed0; a.E = (int)E; a.x = x; a.n_lig = (int)g->n_lig;
   a.n_nodes = (int)g->n_nodes; a.P = m->P; a.Q = m->Q; a.ldpq = m->ldpq; a.wd = m->wd; a.wd0 = m->wd0; a.table = m->tab;
@@ -1835,7 +1871,9 @@ static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph*
   a.Bmat = m->W2T; a.dz_out = ts.dz2; a.part = ts.partA;
   HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
   // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
-  { const int rc = wgrad_impl(s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg, ts.wg_floats); if (rc != DSBDD_OK) return rc; }
+  const bool side_w = sd && (sd->mask & (mode == MODE_GCL ? SIDE_GCL_WG : SIDE_COORD_WG));
+  if (side_w) HIP_TRY(sd->link(s, sd->wg));
+  { const int rc = wgrad_impl(side_w ? sd->wg : s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg, ts.wg_floats); if (rc != DSBDD_OK) return rc; }
   // B: dz1, partial first-layer vectors, per-edge distance gradients
   a.Bmat = m->W2; a.dz_in = ts.dz2; a.dz_out = ts.dz1; a.part = ts.partB;
   HIP_TRY(launch_bwd_b(H, s, a, grid));
@@ -1908,9 +1946,9 @@ int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g,
   return DSBDD_OK;
 }
 
-int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+static int gcl_backward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                              float norm_factor, const float* d_agg, const dsbdd_train_mlp_grad* out, float* d_x,
-                             void* scratch, size_t scratch_bytes) {
+                             void* scratch, size_t scratch_bytes, TrainSide* sd) {
   StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !g->rev || !mlp_ok(m) || !x || !d_agg || !out || !out->dP || !out->dQ ||
       !out->d_vec || !out->d_W2 || !out->gd0 || (out->ldo & 3) || !d_x || !scratch)
@@ -1920,7 +1958,7 @@ int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g
   hipStream_t s = static_cast<hipStream_t>(stream);
   TrainEdgeArgs a{};
   a.d_agg = d_agg; a.norm_factor = norm_factor;
-  { const int rc = mlp_backward(s, H, MODE_GCL, g, m, x, g->n_edges, a, out, ts); if (rc != DSBDD_OK) return rc; }
+  { const int rc = mlp_backward(s, H, MODE_GCL, g, m, x, g->n_edges, a, out, ts, sd); if (rc != DSBDD_OK) return rc; }
   const int N = (int)g->n_nodes;
   hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.gd,
                      (const float*)nullptr, (const float*)nullptr, x, g->ecol, g->row_ptr, g->deg, g->rev,
@@ -1960,11 +1998,11 @@ int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* 
   return DSBDD_OK;
 }
 
-int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
+static int coord_backward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
                                const float* x, const float* mean, int64_t n_upd, int64_t e_upd, float norm_constant,
                                float coords_range, int32_t use_tanh, float norm_factor, const float* d_xout,
                                const dsbdd_train_mlp_grad* out, float* d_x, float* d_mean, void* scratch,
-                               size_t scratch_bytes) {
+                               size_t scratch_bytes, TrainSide* sd) {
   StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !g->rev || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) ||
       (n_mlp == 2 && (!mlp_ok(m + 1) || !mean || !d_mean)) || !m->head || !x || !d_xout || !out || !d_x || n_upd < 0 ||
@@ -1977,25 +2015,50 @@ int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph*
   if (ts.bytes > scratch_bytes) return fail(DSBDD_ERR_CAPACITY, "scratch too small (dsbdd_train_scratch_bytes)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = (int)g->n_nodes;
+  // with side streams and two MLPs the second chain (kernel A .. node gathers) runs on sd->co out of its own scratch
+  // (the second half of `scratch`, 2 x dsbdd_train_scratch_bytes) while the first runs here; d_x is still added in the
+  // order q = 0, 1 on this stream
+  const bool two = sd && (sd->mask & SIDE_CO) && n_mlp == 2 && scratch_bytes >= 2 * ts.bytes;
+  const TrainScratch ts1 = two ? carve_train(static_cast<char*>(scratch) + ts.bytes, H, g->n_nodes, g->n_edges) : ts;
+  if (sd) HIP_TRY(sd->link(sd->wg, s));
+  if (two) HIP_TRY(sd->link(s, sd->co));
   for (int q = 0; q < n_mlp; ++q) {
     TrainEdgeArgs a{};
     a.d_xagg = d_xout; a.node_batch = g->node_batch; a.mean = mean; a.norm_constant = norm_constant;
     a.coords_range = coords_range; a.use_tanh = use_tanh; a.which = q; a.norm_factor = norm_factor;
-    a.gm = q == 1 ? ts.gm : nullptr;
+    const TrainScratch& tq = q == 1 ? ts1 : ts;
+    a.gm = q == 1 ? tq.gm : nullptr;
     dsbdd_train_mlp mq = m[q];
     mq.head = m[0].head;                      // the output layer is shared by both MLPs (egnn_new.py:78,85,91)
-    { const int rc = mlp_backward(s, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, ts); if (rc != DSBDD_OK) return rc; }
-    hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.gd,
-                       (const float*)ts.gxr, (const float*)ts.gxc, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)e_upd, N,
+    hipStream_t sq = two && q == 1 ? sd->co : s;
+    { const int rc = mlp_backward(sq, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, tq, sd, true); if (rc != DSBDD_OK) return rc; }
+    if (sq != s) HIP_TRY(sd->link(sq, s));
+    hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)tq.gd,
+                       (const float*)tq.gxr, (const float*)tq.gxc, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)e_upd, N,
                        d_x, q);
     HIP_TRY(hipGetLastError());
     if (q == 1) {
-      hipLaunchKernelGGL(sample_edge_sum3_kernel, dim3((unsigned)g->batch), dim3(kThreads), 0, s, (const float*)ts.gm,
+      hipLaunchKernelGGL(sample_edge_sum3_kernel, dim3((unsigned)g->batch), dim3(kThreads), 0, s, (const float*)tq.gm,
                          g->row_ptr, g->lig_off, g->poc_off, (int)g->n_lig, (int)e_upd, d_mean);
       HIP_TRY(hipGetLastError());
     }
   }
   return DSBDD_OK;
+}
+
+int dsbdd_train_gcl_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+                             float norm_factor, const float* d_agg, const dsbdd_train_mlp_grad* out, float* d_x,
+                             void* scratch, size_t scratch_bytes) {
+  return gcl_backward_impl(stream, H, g, m, x, norm_factor, d_agg, out, d_x, scratch, scratch_bytes, nullptr);
+}
+
+int dsbdd_train_coord_backward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
+                               const float* x, const float* mean, int64_t n_upd, int64_t e_upd, float norm_constant,
+                               float coords_range, int32_t use_tanh, float norm_factor, const float* d_xout,
+                               const dsbdd_train_mlp_grad* out, float* d_x, float* d_mean, void* scratch,
+                               size_t scratch_bytes) {
+  return coord_backward_impl(stream, H, g, m, n_mlp, x, mean, n_upd, e_upd, norm_constant, coords_range, use_tanh, norm_factor,
+                             d_xout, out, d_x, d_mean, scratch, scratch_bytes, nullptr);
 }
 
 int dsbdd_train_radial_backward(void* stream, const dsbdd_train_graph* g, const float* x, const float* gd, float* d_x) {

@@ -273,6 +273,7 @@ static TnParamIndex tn_index(const dsbdd_config& c) {
   return p;
 }
 
+static const int kTnSideDefault = SIDE_CO | SIDE_NODE_WG | SIDE_COORD_WG;     // DSBDD_TRAIN_STREAMS (bit mask of SIDE_*, engine.hip) overrides
 struct dsbdd_train_net {
   dsbdd_config cfg;
   TnParamIndex ix;
@@ -280,6 +281,10 @@ struct dsbdd_train_net {
   std::vector<const float*> last_params;
   void* last_pack = nullptr;
   int n_pack = 0, n_tab = 0;
+  // side streams of the backward (TrainSide, engine.hip), created on the first backward call; DSBDD_TRAIN_STREAMS=0: none
+  TrainSide side;
+  bool side_ready = false;
+  int side_mask = 0;
 };
 
 // sizes of one call
@@ -380,7 +385,8 @@ static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d) {
     for (const auto& sh : shapes) { const size_t f = wgrad_floats_upto((int64_t)N, sh[0], sh[1]); if (f > w.wg_floats) w.wg_floats = f; }
   }
   w.wg = take(w.wg_floats);
-  w.scratch_bytes = carve_train(nullptr, d.H, d.N, d.E).bytes;
+  // (two scratch sets when a coordinate stage has two edge MLPs: their backward chains run side by side)
+  w.scratch_bytes = carve_train(nullptr, d.H, d.N, d.E).bytes * (d.M == 2 ? 2 : 1);
   w.scratch = takeb(w.scratch_bytes);
   (void)c;
   w.bytes = off;
@@ -481,10 +487,14 @@ int dsbdd_train_net_create(const dsbdd_config* cfg, dsbdd_train_net** out) {
     return fail(DSBDD_ERR_ARG, "unsupported configuration");
   auto* n = new dsbdd_train_net();
   n->cfg = *cfg; n->ix = tn_index(*cfg);
+  { const char* v = getenv("DSBDD_TRAIN_STREAMS"); n->side_mask = v ? atoi(v) & 15 : kTnSideDefault; }
   *out = n;
   return DSBDD_OK;
 }
-void dsbdd_train_net_destroy(dsbdd_train_net* n) { delete n; }
+void dsbdd_train_net_destroy(dsbdd_train_net* n) {
+  if (n && n->side_ready) n->side.destroy();
+  delete n;
+}
 int dsbdd_train_net_param_count(const dsbdd_train_net* n) { return n ? n->ix.n : 0; }
 size_t dsbdd_train_net_pack_bytes(const dsbdd_train_net* n) { return n ? tn_carve_pack(nullptr, n->cfg).bytes : 0; }
 size_t dsbdd_train_net_workspace_bytes(const dsbdd_train_net* n, const dsbdd_train_graph* g) {
@@ -587,6 +597,14 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
   const TnWs w = tn_carve_ws(static_cast<char*>(ws), c, d);
   if (pk.bytes > pack_bytes || w.bytes > ws_bytes) return fail(DSBDD_ERR_CAPACITY, "buffer too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (net->side_mask && !net->side_ready) {
+    HIP_TRY(net->side.create());
+    net->side.mask = net->side_mask;
+    net->side_ready = true;
+  }
+  TrainSide* sd = net->side_mask ? &net->side : nullptr;
+  hipStream_t sw = sd && (sd->mask & SIDE_NODE_WG) ? sd->wg : s;      // the stream of the block loop's weight gradients (w.wg / w.colscr are its scratch there)
+  auto fork_w = [&]() -> int { if (sw != s) HIP_TRY(sd->link(s, sd->wg)); return DSBDD_OK; };
   const float* const* P = params;
   float* const* G = grads;
   const int H = d.H, a = d.a, r = d.r, J = d.J, JP = d.JP, N = (int)d.N, nl_ = (int)d.n_l, np_ = (int)d.n_p, M = d.M;
@@ -668,9 +686,9 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
     float* dxi = w.d_x[cx ^ 1];
     if (e_upd > 0 && n_upd > 0) {
       if (want_in) HIP_TRY(hipMemsetAsync(w.gd0, 0, (size_t)2 * (E > 0 ? E : 1) * 4, s));
-      { const int rc = dsbdd_train_coord_backward(stream, H, g, mm, M, w.x[b], M == 2 ? w.mean[b] : nullptr, n_upd, e_upd, c.norm_constant,
-                                                 c.coords_range, c.use_tanh, c.normalization_factor, dxo, og, dxi,
-                                                 M == 2 ? w.d_mean : nullptr, w.scratch, w.scratch_bytes); if (rc) return rc; }
+      { const int rc = coord_backward_impl(stream, H, g, mm, M, w.x[b], M == 2 ? w.mean[b] : nullptr, n_upd, e_upd, c.norm_constant,
+                                          c.coords_range, c.use_tanh, c.normalization_factor, dxo, og, dxi,
+                                          M == 2 ? w.d_mean : nullptr, w.scratch, w.scratch_bytes, sd); if (rc) return rc; }
       for (int q = 0; q < M; ++q) { const int rc = add_gd0(og[q].gd0); if (rc) return rc; }
       // identity path x -> x_out
       hipLaunchKernelGGL(tn_add_kernel, dim3(tn_blocks(3 * (size_t)N)), dim3(256), 0, s, dxi, (const float*)dxo, 3 * (size_t)N);
@@ -683,7 +701,8 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       // d_h += d_pq4 W4; d W4 = d_pq4^T h
       { int rc = tn_lin(s, w.d_pq4, 2 * H * M, 2 * H * M, nullptr, 0, 0, pk.W4[b], H, nullptr, w.d_h[cur], H, w.d_h[cur ^ 1], H, N, H); if (rc) return rc; }
       cur ^= 1;
-      { int rc = tn_wgrad(s, w.d_pq4, 2 * H * M, hb, H, N, 2 * H * M, H, dW4, w); if (rc) return rc; }
+      { int rc = fork_w(); if (rc) return rc; }
+      { int rc = tn_wgrad(sw, w.d_pq4, 2 * H * M, hb, H, N, 2 * H * M, H, dW4, w); if (rc) return rc; }
     } else {
       HIP_TRY(hipMemcpyAsync(dxi, dxo, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
       HIP_TRY(hipMemsetAsync(dW4, 0, (size_t)2 * H * M * H * 4, s));
@@ -707,15 +726,20 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       const float* hin = w.h[gi];
       float* dout = w.d_h[cur];
       // node MLP backward
-      { int rc = tn_wgrad(s, dout, H, w.act[gi], H, N, H, H, G[base + 6], w); if (rc) return rc; }
-      { int rc = tn_colsum(s, dout, H, N, H, G[base + 7], w); if (rc) return rc; }
+      // (weight gradients on the side stream; the main stream meets it again before the next edge kernel A -- which is
+      //  before anything these launches read is overwritten: dout by the message stage's tn_lin, dz / xcat / d_pq by the
+      //  next sublayer)
+      { int rc = fork_w(); if (rc) return rc; }
+      { int rc = tn_wgrad(sw, dout, H, w.act[gi], H, N, H, H, G[base + 6], w); if (rc) return rc; }
+      { int rc = tn_colsum(sw, dout, H, N, H, G[base + 7], w); if (rc) return rc; }
       { int rc = tn_lin(s, dout, H, H, nullptr, 0, 0, P[base + 6], H, nullptr, nullptr, 0, w.da, H, N, H); if (rc) return rc; }
       hipLaunchKernelGGL(tn_silu_bwd_kernel, dim3(tn_blocks((size_t)N * H)), dim3(256), 0, s, (const float*)w.da, (const float*)w.z[gi], w.dz, (size_t)N * H);
       HIP_TRY(hipGetLastError());
       hipLaunchKernelGGL(tn_cat_kernel, dim3(tn_blocks((size_t)N * 2 * H)), dim3(256), 0, s, hin, (const float*)w.agg[gi], w.xcat, N, H);
       HIP_TRY(hipGetLastError());
-      { int rc = tn_wgrad(s, w.dz, H, w.xcat, 2 * H, N, H, 2 * H, G[base + 4], w); if (rc) return rc; }
-      { int rc = tn_colsum(s, w.dz, H, N, H, G[base + 5], w); if (rc) return rc; }
+      { int rc = fork_w(); if (rc) return rc; }
+      { int rc = tn_wgrad(sw, w.dz, H, w.xcat, 2 * H, N, H, 2 * H, G[base + 4], w); if (rc) return rc; }
+      { int rc = tn_colsum(sw, w.dz, H, N, H, G[base + 5], w); if (rc) return rc; }
       // d_hin = dz W1[:, :H] + d_out (residual);  d_agg = dz W1[:, H:]
       { int rc = tn_lin(s, w.dz, H, H, nullptr, 0, 0, P[base + 4], 2 * H, nullptr, dout, H, w.d_h[cur ^ 1], H, N, H); if (rc) return rc; }
       { int rc = tn_lin(s, w.dz, H, H, nullptr, 0, 0, P[base + 4] + H, 2 * H, nullptr, nullptr, 0, w.d_agg, H, N, H); if (rc) return rc; }
@@ -728,13 +752,14 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       float* dWpq = w.dWpq + (size_t)gi * 2 * H * H;
       o.dP = w.d_pq; o.dQ = w.d_pq + H; o.ldo = 2 * H; o.d_vec = vec_of(k); o.d_W2 = G[base + 2]; o.gd0 = w.gd0;
       if (want_in) HIP_TRY(hipMemsetAsync(w.gd0, 0, (size_t)(E > 0 ? E : 1) * 4, s));
-      { const int rc = dsbdd_train_gcl_backward(stream, H, g, &m, w.x[b], c.normalization_factor, w.d_agg, &o, w.d_xg, w.scratch, w.scratch_bytes); if (rc) return rc; }
+      { const int rc = gcl_backward_impl(stream, H, g, &m, w.x[b], c.normalization_factor, w.d_agg, &o, w.d_xg, w.scratch, w.scratch_bytes, sd); if (rc) return rc; }
       { const int rc = add_gd0(w.gd0); if (rc) return rc; }
       hipLaunchKernelGGL(tn_add_kernel, dim3(tn_blocks(3 * (size_t)N)), dim3(256), 0, s, w.d_x[cx], (const float*)w.d_xg, 3 * (size_t)N);
       HIP_TRY(hipGetLastError());
       { int rc = tn_lin(s, w.d_pq, 2 * H, 2 * H, nullptr, 0, 0, pk.Wpq[gi], H, nullptr, w.d_h[cur], H, w.d_h[cur ^ 1], H, N, H); if (rc) return rc; }
       cur ^= 1;
-      { int rc = tn_wgrad(s, w.d_pq, 2 * H, hin, H, N, 2 * H, H, dWpq, w); if (rc) return rc; }
+      { int rc = fork_w(); if (rc) return rc; }
+      { int rc = tn_wgrad(sw, w.d_pq, 2 * H, hin, H, N, 2 * H, H, dWpq, w); if (rc) return rc; }
       ud.push_back(TnUnpackDesc{G[base], ld1, G[base + 1], emb ? w.demb_part + (size_t)k * 3 * d.enf : nullptr, dWpq, H, vec_of(k), P[base], emb,
                                 d.enf, H});
       cd.push_back(TnCopyDesc{G[base + 3], vec_of(k) + 5 * H, nullptr, H});                        // d b2
@@ -744,6 +769,7 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       }
     }
   }
+  if (sd) HIP_TRY(sd->link(sd->wg, s));      // every weight gradient of the blocks is complete from here on
   // embedding
   { int rc = tn_wgrad(s, w.d_h[cur], H, w.h0, JP, N, H, d.D, G[ix.emb], w); if (rc) return rc; }
   { int rc = tn_colsum(s, w.d_h[cur], H, N, H, G[ix.emb + 1], w); if (rc) return rc; }

@@ -412,3 +412,49 @@ def test_input_gradients_match_the_torch_path(arch):
     o_l, o_p = m(xl.to(dev()), xp.to(dev()), t.to(dev()), ml.to(dev()), mp.to(dev()))
     assert o_l.grad_fn is None and not o_l.requires_grad
     assert rel_err(o_l, o_h) < 1e-4
+
+
+@pytest.mark.parametrize("arch,n_lig,n_poc", [("crossdock_fullatom_cond", [23] * 6, [286] * 6),
+                                              ("crossdock_ca_cond", [23, 20, 25, 11], [36, 40, 30, 33]),
+                                              ("small_joint", [5, 7, 6], [40, 35, 38])])
+def test_side_streams_of_the_backward_keep_the_bits(arch, n_lig, n_poc):
+    """Round 6: the network backward runs the weight gradients and the second coordinate MLP's chain on side streams
+    (DSBDD_TRAIN_STREAMS, a bit mask read when the per-module handle is created; csrc/engine.hip TrainSide).  Kernels and
+    reduction orders are those of the single-stream sequence, so every parameter and input gradient must be IDENTICAL --
+    a missing fork / join would show up here as a difference between the masks or between repeats."""
+    import copy
+    cfg, _ = W.arch_cfg(arch)
+    sd = W.random_state_dict(cfg, seed=1)
+    xl, xp, t, ml, mp = problem(cfg, n_lig, n_poc, seed=8, spread=0.6 if arch == "small_joint" else 3.0)
+    gen = torch.Generator().manual_seed(6)
+    wl, wp = torch.randn(xl.shape, generator=gen).to(dev()), torch.randn(xp.shape, generator=gen).to(dev())
+
+    def run(m):
+        m.zero_grad(set_to_none=True)
+        a = xl.to(dev()).clone().requires_grad_(True)
+        b = xp.to(dev()).clone().requires_grad_(True)
+        o_l, o_p = m(a, b, t.to(dev()), ml.to(dev()), mp.to(dev()))
+        ((o_l * wl).sum() + (o_p * wp).sum()).backward()
+        out = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        out["d_xh_atoms"], out["d_xh_residues"] = a.grad.clone(), b.grad.clone()
+        return out
+    results = {}
+    old = os.environ.get("DSBDD_TRAIN_STREAMS")
+    try:
+        for mask in ("0", "15", "7"):
+            os.environ["DSBDD_TRAIN_STREAMS"] = mask
+            m = make_dynamics(cfg, copy.deepcopy(sd))          # a new module: a new handle, created under this mask
+            m.train(True)
+            results[mask] = [run(m) for _ in range(3)]
+    finally:
+        if old is None:
+            os.environ.pop("DSBDD_TRAIN_STREAMS", None)
+        else:
+            os.environ["DSBDD_TRAIN_STREAMS"] = old
+    ref = results["0"][0]
+    assert len(ref) > 10
+    for mask, runs in results.items():
+        for i, r in enumerate(runs):
+            assert set(r) == set(ref)
+            for k in ref:
+                assert torch.equal(r[k], ref[k]), (mask, i, k, (r[k] - ref[k]).abs().max().item())

@@ -10,4 +10,5 @@ DB=$(find /tmp/tr_$TAG -name "*.db" | head -1)
 if [ -z "$DB" ]; then echo "no rocpd database"; tail -5 /tmp/tr_$TAG.log; exit 1; fi
 grep "^| cross" /tmp/tr_$TAG.log > $R/gpurun_out/${TAG}_train_under_rocprof.md
 python $R/tools/rocpd_stats.py $DB 40 > $R/gpurun_out/${TAG}_train_kernel_stats.md
+python $R/tools/rocpd_sequence.py $DB 2 tn_pack_kernel > $R/gpurun_out/${TAG}_train_call_sequence.md
 rm -rf /tmp/tr_$TAG

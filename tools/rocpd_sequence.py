@@ -3,7 +3,7 @@
 launches between two consecutive `prep_assemble_kernel` dispatches (default: the last
 complete call), one line per dispatch with its duration and the gap to the
 previous one, plus a summary grouped by (kernel, grid).
-Usage: rocpd_sequence.py results.db [call_index_from_end=2]"""
+Usage: rocpd_sequence.py results.db [call_index_from_end=2] [marker kernel, e.g. tn_pack_kernel for a training step]"""
 import re
 import sqlite3
 import sys
@@ -20,7 +20,8 @@ def main():
     rows = db.execute("select name, start, end, grid_x, grid_y, workgroup_x from kernels order by start").fetchall()
     # a forward call starts with prep_assemble_kernel (prep_kernel in older builds; a chain's pocket frame also runs
     # one prep_kernel, which is not a call boundary)
-    marks = [i for i, r in enumerate(rows) if "prep_assemble_kernel" in r[0]]
+    marker = sys.argv[3] if len(sys.argv) > 3 else "prep_assemble_kernel"
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
     if not marks:
         marks = [i for i, r in enumerate(rows) if "prep_kernel" in r[0]]
     if len(marks) < back + 1:
