@@ -1681,6 +1681,17 @@ static hipError_t launch_edge_plain(int H, hipStream_t s, int mode, const EdgeAr
   int64_t g = tiles < 2LL * device_cus() ? tiles : 2LL * device_cus();
   int grid = (int)((g + 7) / 8 * 8);
   if (grid < 8) grid = 8;
+  if (a.z2_out) {          // training forward of the network path: the message stage keeps z2 (edge_wave_kernel<.., STORE>)
+    if (mode != MODE_GCL) return hipErrorInvalidValue;
+    switch (H) {
+      case 64: hipLaunchKernelGGL((edge_wave_kernel<64, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
+      case 128: hipLaunchKernelGGL((edge_wave_kernel<128, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
+      case 192: hipLaunchKernelGGL((edge_wave_kernel<192, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
+      case 256: hipLaunchKernelGGL((edge_wave_kernel<256, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (H) {
     case 64: return launch_wave_t<64>(s, mode, a, grid);
     case 128: return launch_wave_t<128>(s, mode, a, grid);
@@ -1812,6 +1823,17 @@ static hipError_t launch_bwd_b(int H, hipStream_t s, const TrainEdgeArgs& a, int
   return hipGetLastError();
 }
 
+static hipError_t launch_bwd_e(int H, hipStream_t s, const TrainEdgeArgs& a, const float* z2, int grid) {
+  switch (H) {
+    case 64: hipLaunchKernelGGL((edge_bwd_e_kernel<64>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+    case 128: hipLaunchKernelGGL((edge_bwd_e_kernel<128>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+    case 192: hipLaunchKernelGGL((edge_bwd_e_kernel<192>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+    case 256: hipLaunchKernelGGL((edge_bwd_e_kernel<256>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 static bool train_h_ok(int H) { return H == 64 || H == 128 || H == 192 || H == 256; }
 static bool graph_ok(const dsbdd_train_graph* g) {
   return g && g->erow && g->ecol && g->ed0 && g->row_ptr && g->deg && g->node_batch && g->lig_off && g->poc_off &&
@@ -1859,7 +1881,7 @@ struct TrainSide {
 // this weight gradient overwrite).
 static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                         int64_t E, TrainEdgeArgs a, const dsbdd_train_mlp_grad* out, const TrainScratch& ts,
-                        TrainSide* sd = nullptr, bool linked = false) {
+                        TrainSide* sd = nullptr, bool linked = false, const float* z2 = nullptr) {
   const int grid = train_grid(E);
   if (sd && !linked) HIP_TRY(sd->link(sd->wg, s));
   const int slots = grid;                  // one partial-vector slot per workgroup
@@ -1869,7 +1891,8 @@ static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph*
   a.a1_out = ts.a1; a.gxr = ts.gxr; a.gxc = ts.gxc; a.gd = ts.gd; a.gd0 = out->gd0;
   // A: dz2, a1, partial bias / head vectors
   a.Bmat = m->W2T; a.dz_out = ts.dz2; a.part = ts.partA;
-  HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
+  if (z2 && mode == MODE_GCL) HIP_TRY(launch_bwd_e(H, s, a, z2, grid));     // the forward pass kept z2: no H x H layer here
+  else HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
   // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
   const bool side_w = sd && (sd->mask & (mode == MODE_GCL ? SIDE_GCL_WG : SIDE_COORD_WG));
   if (side_w) HIP_TRY(sd->link(s, sd->wg));
@@ -1924,8 +1947,14 @@ int dsbdd_train_sample_mean(void* stream, const float* x, const dsbdd_train_grap
   return DSBDD_OK;
 }
 
+static int gcl_forward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+                            float norm_factor, float* agg, void* scratch, size_t scratch_bytes, float* z2_store);
 int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                             float norm_factor, float* agg, void* scratch, size_t scratch_bytes) {
+  return gcl_forward_impl(stream, H, g, m, x, norm_factor, agg, scratch, scratch_bytes, nullptr);
+}
+static int gcl_forward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
+                            float norm_factor, float* agg, void* scratch, size_t scratch_bytes, float* z2_store) {
   StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !mlp_ok(m) || !x || !agg || !scratch) return fail(DSBDD_ERR_ARG, "bad argument");
   const TrainScratch ts = carve_train(static_cast<char*>(scratch), H, g->n_nodes, g->n_edges);
@@ -1938,7 +1967,7 @@ int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g,
   ea.mlp[0] = EdgeMlpW{m->P, m->Q, m->wd, m->wd0, m->tab, m->W2T, m->b2, nullptr};
   ea.mlp[1] = ea.mlp[0];
   ea.att_w = m->head; ea.att_b = m->head_b; ea.attention = m->head != nullptr;
-  ea.agg = agg; ea.agg_head = ts.agg_head; ea.norm_factor = norm_factor;
+  ea.agg = agg; ea.agg_head = ts.agg_head; ea.norm_factor = norm_factor; ea.z2_out = z2_store;
   if (g->n_edges > 0) HIP_TRY(launch_edge_plain(H, s, MODE_GCL, ea, g->n_edges));
   hipLaunchKernelGGL(agg_complete_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, agg, (const float*)ts.agg_head,
                      g->row_ptr, g->deg, N, (int)H, (int)((g->n_edges + 31) / 32 + 1), 5);
@@ -1948,7 +1977,7 @@ int dsbdd_train_gcl_forward(void* stream, int32_t H, const dsbdd_train_graph* g,
 
 static int gcl_backward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                              float norm_factor, const float* d_agg, const dsbdd_train_mlp_grad* out, float* d_x,
-                             void* scratch, size_t scratch_bytes, TrainSide* sd) {
+                             void* scratch, size_t scratch_bytes, TrainSide* sd, const float* z2 = nullptr) {
   StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !g->rev || !mlp_ok(m) || !x || !d_agg || !out || !out->dP || !out->dQ ||
       !out->d_vec || !out->d_W2 || !out->gd0 || (out->ldo & 3) || !d_x || !scratch)
@@ -1958,7 +1987,7 @@ static int gcl_backward_impl(void* stream, int32_t H, const dsbdd_train_graph* g
   hipStream_t s = static_cast<hipStream_t>(stream);
   TrainEdgeArgs a{};
   a.d_agg = d_agg; a.norm_factor = norm_factor;
-  { const int rc = mlp_backward(s, H, MODE_GCL, g, m, x, g->n_edges, a, out, ts, sd); if (rc != DSBDD_OK) return rc; }
+  { const int rc = mlp_backward(s, H, MODE_GCL, g, m, x, g->n_edges, a, out, ts, sd, false, z2); if (rc != DSBDD_OK) return rc; }
   const int N = (int)g->n_nodes;
   hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)ts.gd,
                      (const float*)nullptr, (const float*)nullptr, x, g->ecol, g->row_ptr, g->deg, g->rev,

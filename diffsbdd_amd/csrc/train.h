@@ -384,6 +384,130 @@ __global__ __launch_bounds__(kThreads, 1) void edge_bwd_a_kernel(TrainEdgeArgs p
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// kernel E (round 6): the message stage's kernel A WITHOUT its H x H layer.  The forward pass of the network path keeps
+// z2 = W2 a1 + b2 of every edge (edge_wave_kernel<.., STORE>, 4 E H bytes per message stage -- the device has 288 GB), so
+// what is left of kernel A is element-wise per edge: a1 = SiLU(z1) from the row-gathered projections (for the weight
+// gradient), m = SiLU(z2), the attention gate and its backward, dz2.  One WAVE per edge, lane l holds columns
+// V l .. V l + V - 1 (V = H / 64: 16-byte accesses at H = 256, every row a contiguous 4 H bytes), 16 waves per workgroup,
+// the grid of kernel B (one [8][H] partial-vector slot per workgroup: rows 5 .. 7 here, as kernel A).  Row sums are wave
+// butterflies in a fixed order: bitwise reproducible, and within rounding of kernel A's (which sums the same products in
+// accumulator-tile order).
+constexpr int kThreadsE = 1024;
+template <int V>
+__device__ __forceinline__ void ld_cols(const float* row, int lane, float (&v)[V]) {
+  if constexpr (V == 4) { const float4 q = *reinterpret_cast<const float4*>(row + 4 * lane); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+  else if constexpr (V == 2) { const float2 q = *reinterpret_cast<const float2*>(row + 2 * lane); v[0] = q.x; v[1] = q.y; }
+  else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = row[V * lane + k];
+  }
+}
+template <int V>
+__device__ __forceinline__ void st_cols(float* row, int lane, const float (&v)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(row + 4 * lane) = float4{v[0], v[1], v[2], v[3]};
+  else if constexpr (V == 2) *reinterpret_cast<float2*>(row + 2 * lane) = float2{v[0], v[1]};
+  else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) row[V * lane + k] = v[k];
+  }
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreadsE) void edge_bwd_e_kernel(TrainEdgeArgs p, const float* __restrict__ z2) {
+  constexpr int V = H / 64, NW = kThreadsE / 64;
+  __shared__ __attribute__((aligned(16))) float sP[NW][2 * H + 4];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool attention = p.head != nullptr;
+  float wd[V], wd0[V], tb[3][V], aw[V];
+  ld_cols<V>(p.wd, lane, wd);
+  ld_cols<V>(p.wd0, lane, wd0);
+#pragma unroll
+  for (int y = 0; y < 3; ++y) ld_cols<V>(p.table + y * H, lane, tb[y]);
+#pragma unroll
+  for (int k = 0; k < V; ++k) aw[k] = 0.f;
+  if (attention) ld_cols<V>(p.head, lane, aw);
+  const float att_b = attention ? p.head_b[0] : 0.f;
+  const float inv_norm = 1.0f / p.norm_factor;
+  float pb2[V], pv1[V], ps = 0.f;
+#pragma unroll
+  for (int k = 0; k < V; ++k) { pb2[k] = 0.f; pv1[k] = 0.f; }
+
+#pragma unroll 1
+  for (int e = blockIdx.x * NW + w; e < p.E; e += gridDim.x * NW) {
+    int r = __builtin_amdgcn_readfirstlane(p.erow[e]), c = __builtin_amdgcn_readfirstlane(p.ecol[e]);
+    const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ed0[e])));
+    const bool active = (unsigned)r < (unsigned)p.n_nodes && (unsigned)c < (unsigned)p.n_nodes;
+    float zv[V], a1[V], dz[V];
+    if (!active) {          // (wave-uniform) rows of inactive list entries are zeros: the weight-gradient GEMM sums every row
+#pragma unroll
+      for (int k = 0; k < V; ++k) zv[k] = 0.f;
+      st_cols<V>(p.a1_out + (size_t)e * H, lane, zv);
+      st_cols<V>(p.dz_out + (size_t)e * H, lane, zv);
+      continue;
+    }
+    float pv[V], qv[V], dout[V];
+    ld_cols<V>(z2 + (size_t)e * H, lane, zv);
+    ld_cols<V>(p.P + (size_t)r * p.ldpq, lane, pv);
+    ld_cols<V>(p.Q + (size_t)c * p.ldpq, lane, qv);
+    ld_cols<V>(p.d_agg + (size_t)r * H, lane, dout);
+    const float ddx = p.x[3 * r] - p.x[3 * c], ddy = p.x[3 * r + 1] - p.x[3 * c + 1], ddz = p.x[3 * r + 2] - p.x[3 * c + 2];
+    const float d = ddx * ddx + ddy * ddy + ddz * ddz;
+    const bool rl = r < p.n_lig, cl = c < p.n_lig;
+    const int ty = (rl && cl) ? 1 : ((!rl && !cl) ? 2 : 0);
+    // a1 = SiLU(z1), the first layer as kernel A evaluates it
+#pragma unroll
+    for (int k = 0; k < V; ++k) a1[k] = silu(fmaf(d0, wd0[k], fmaf(d, wd[k], pv[k] + qv[k])) + tb[ty][k]);
+    st_cols<V>(p.a1_out + (size_t)e * H, lane, a1);
+    float m[V], sg[V], dot = 0.f, sdot = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      dout[k] *= inv_norm;
+      sg[k] = sigmoidf_fast(zv[k]);
+      m[k] = zv[k] * sg[k];
+      dot = fmaf(m[k], aw[k], dot);
+      sdot = fmaf(dout[k], m[k], sdot);
+    }
+    float att = 1.f, tt = 0.f;
+    if (attention) {
+      const float gate = sigmoidf_fast(wave_sum_f(dot) + att_b);
+      att = gate;
+      tt = wave_sum_f(sdot) * gate * (1.0f - gate);
+      ps += tt;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float dm = fmaf(tt, aw[k], dout[k] * att);
+      dz[k] = dm * dsilu_from(zv[k], sg[k]);
+      pb2[k] += dz[k];
+      pv1[k] = fmaf(tt, m[k], pv1[k]);
+    }
+    st_cols<V>(p.dz_out + (size_t)e * H, lane, dz);
+  }
+  // partial vectors of the workgroup: the 16 waves' sums in wave order -> rows 5 .. 7 of its slot
+  st_cols<V>(sP[w], lane, pb2);
+  st_cols<V>(sP[w] + H, lane, pv1);
+  if (lane == 0) sP[w][2 * H] = ps;
+  __syncthreads();
+  for (int i = t; i < kPartA * H; i += kThreadsE) {
+    float v = 0.f;
+    if (i < 2 * H) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += sP[q][i];
+    } else if (i == 2 * H) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += sP[q][2 * H];
+    }
+    p.part[(size_t)blockIdx.x * kPartAll * H + (size_t)kPartB * H + i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // kernel B
 template <int H>
 __global__ __launch_bounds__(kThreads, 1) void edge_bwd_b_kernel(TrainEdgeArgs p) {

@@ -243,6 +243,12 @@ using namespace dsbdd;
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 static inline int tn_pad4(int v) { return (v + 3) & ~3; }
+// The forward pass keeps z2 [E][H] of every message stage for the backward pass (4 E H bytes per stage: 93 MB at the
+// reference batch) instead of recomputing the H x H layer there; DSBDD_TRAIN_STORE_Z2=0: recompute (kernel A, rounds 4-5).
+static bool tn_store_z2() {
+  static const bool on = [] { const char* v = getenv("DSBDD_TRAIN_STORE_Z2"); return !(v && atoi(v) == 0); }();
+  return on;
+}
 
 // parameter tensors in the order of EGNNDynamics' own construction (diffsbdd_amd/synthetic.dynamics_param_shapes; the
 // aliased cross_product_mlp.4.weight is NOT listed: it IS coord_mlp.4.weight, egnn_new.py:78,85,91)
@@ -345,6 +351,7 @@ static TnPack tn_carve_pack(char* base, const dsbdd_config& c) {
 struct TnWs {
   float *x0, *hf_l, *hf_p, *ze_l, *ae_l, *ze_p, *ae_p, *h0, *hout, *zd_l, *ad_l, *zd_p, *ad_p, *eh_l, *eh_p, *vel, *meanv;
   std::vector<float*> h, x, mean, pq, agg, z, act, pq4;       // h [G + 1], x [L + 1], mean [L], pq/agg/z/act [G], pq4 [L]
+  std::vector<float*> z2;                                     // [G] x [E][H]: the message stages' second-layer pre-activations
   // backward
   float *d_vel, *deh_l, *deh_p, *d_h[2], *d_x[2], *d_xg, *d_pq4, *d_pq, *da, *dz, *d_agg, *xcat, *d_hout, *d_h0, *d_hf_l, *d_hf_p,
       *d_small, *gd0, *gd0_tot, *d_mean, *colscr, *dWpq, *d_vec, *demb_part, *wg;
@@ -368,6 +375,7 @@ static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d) {
   for (int b = 0; b <= d.L; ++b) w.x.push_back(take(3 * N));
   for (int b = 0; b < d.L; ++b) { w.mean.push_back(take(3 * (size_t)d.B)); w.pq4.push_back(take(N * 2 * H * d.M)); }
   for (int g = 0; g < d.G; ++g) { w.pq.push_back(take(N * 2 * H)); w.agg.push_back(take(N * H)); w.z.push_back(take(N * H)); w.act.push_back(take(N * H)); }
+  for (int g = 0; g < d.G; ++g) w.z2.push_back(tn_store_z2() ? take(E * H) : nullptr);
   w.d_vel = take(3 * N); w.deh_l = take(nl * d.a); w.deh_p = take(np * d.r);
   w.d_h[0] = take(N * H); w.d_h[1] = take(N * H); w.d_x[0] = take(3 * N); w.d_x[1] = take(3 * N); w.d_xg = take(3 * N);
   w.d_pq4 = take(N * 2 * H * d.M); w.d_pq = take(N * 2 * H); w.da = take(N * H); w.dz = take(N * H); w.d_agg = take(N * H);
@@ -550,7 +558,7 @@ int dsbdd_train_net_forward(dsbdd_train_net* net, void* stream, const dsbdd_trai
       { int rc = tn_lin(s, hin, H, H, nullptr, 0, 0, pk.WpqT[gi], 2 * H, nullptr, nullptr, 0, w.pq[gi], 2 * H, N, 2 * H); if (rc) return rc; }
       const dsbdd_train_mlp m = tn_mlp(w.pq[gi], 0, H, 2 * H, pk.gcl[gi], P[base + 2], P[base + 3],
                                        ix.att ? P[base + 8] : nullptr, ix.att ? P[base + 9] : nullptr);
-      { const int rc = dsbdd_train_gcl_forward(stream, H, g, &m, w.x[b], c.normalization_factor, w.agg[gi], w.scratch, w.scratch_bytes); if (rc) return rc; }
+      { const int rc = gcl_forward_impl(stream, H, g, &m, w.x[b], c.normalization_factor, w.agg[gi], w.scratch, w.scratch_bytes, w.z2[gi]); if (rc) return rc; }
       // node MLP (egnn_new.py:53-58): h + W2 SiLU(W1 [h | agg] + b1) + b2
       { int rc = tn_lin(s, hin, H, H, w.agg[gi], H, H, pk.n1[gi].WT, pk.n1[gi].ldT, P[base + 5], nullptr, 0, w.z[gi], H, N, H); if (rc) return rc; }
       hipLaunchKernelGGL(tn_silu_kernel, dim3(tn_blocks((size_t)N * H)), dim3(256), 0, s, (const float*)w.z[gi], w.act[gi], (size_t)N * H);
@@ -752,7 +760,7 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       float* dWpq = w.dWpq + (size_t)gi * 2 * H * H;
       o.dP = w.d_pq; o.dQ = w.d_pq + H; o.ldo = 2 * H; o.d_vec = vec_of(k); o.d_W2 = G[base + 2]; o.gd0 = w.gd0;
       if (want_in) HIP_TRY(hipMemsetAsync(w.gd0, 0, (size_t)(E > 0 ? E : 1) * 4, s));
-      { const int rc = gcl_backward_impl(stream, H, g, &m, w.x[b], c.normalization_factor, w.d_agg, &o, w.d_xg, w.scratch, w.scratch_bytes, sd); if (rc) return rc; }
+      { const int rc = gcl_backward_impl(stream, H, g, &m, w.x[b], c.normalization_factor, w.d_agg, &o, w.d_xg, w.scratch, w.scratch_bytes, sd, w.z2[gi]); if (rc) return rc; }
       { const int rc = add_gd0(w.gd0); if (rc) return rc; }
       hipLaunchKernelGGL(tn_add_kernel, dim3(tn_blocks(3 * (size_t)N)), dim3(256), 0, s, w.d_x[cx], (const float*)w.d_xg, 3 * (size_t)N);
       HIP_TRY(hipGetLastError());

@@ -474,6 +474,10 @@ int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int
  * pack: persistent caller-owned buffer (dsbdd_train_net_pack_bytes) for the re-laid-out weights, rewritten by every
  * forward; ws: per-call workspace (dsbdd_train_net_workspace_bytes) that carries the activations from forward to backward.
  * Nothing is allocated by the library; no host synchronisation inside (beyond the first call's descriptor upload).
+ * Streams: everything is ordered on `stream` as seen by the caller.  Inside, the backward runs the second coordinate
+ * MLP's chain and the node-level / coordinate weight gradients on two internal non-blocking streams of the handle
+ * (created by the first backward call; fork / join by events, all joined before the call's last launches on `stream`;
+ * same kernels and reduction orders, so the gradients are bitwise those of DSBDD_TRAIN_STREAMS=0, one stream).
  * zero_nan: training mode replaces NaN velocities by 0 (dynamics.py:155-159); otherwise bit 1 of *status is raised.
  * e_upd (backward): row_ptr[n_lig] as a host value (pocket-conditioned models; ignored when update_pocket_coords).
  * d_xh_lig / d_xh_pocket: gradients w.r.t. the inputs, or NULL. */
