@@ -101,10 +101,11 @@ struct EdgeArgs {
   // walks two lists (block 0 of a framed call: ligand-endpoint edges + the frame's pocket-pocket edges).
   const int* erow_b; const int* ecol_b; const float* ed0_b; const int* e_count_b; int e_cap_b; int wt_base_b;
   float* agg_b; float* agg_head_b;
-  // edge_wave_kernel<.., STORE = true> (training forward, message stage, single list from slot 0): the second layer's
-  // pre-activation z2 = W2 a1 + b2 of every list slot, [e_cap][H] -- the backward pass reads it instead of recomputing
-  // the H x H layer (train.h, edge_bwd_e_kernel)
+  // edge_wave_kernel<.., STORE = true> (training forward, single list from slot 0, no pass split): the second layer's
+  // pre-activation z2 = W2 a1 + b2 of every list slot, [e_cap][H] (coordinate stage: one copy per MLP) -- the backward
+  // pass reads it instead of recomputing the H x H layer (train.h, edge_bwd_e_kernel / edge_bwd_ec_kernel)
   float* z2_out;
+  size_t z2_stride;       // MODE_COORD: floats between the two MLPs' copies of z2
 };
 
 enum { MODE_GCL = 0, MODE_COORD = 1 };

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pack_w2e_kernel(const float* __restrict__
 template <int H, int MODE, bool BPERM, int EMU = 0, bool STORE = false>
 __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
   using L = WaveLayout<H, MODE, EMU>;
-  static_assert(!STORE || (MODE == MODE_GCL && !BPERM && EMU == 0), "z2 is stored by the plain exact message-stage kernel only");
+  static_assert(!STORE || (!BPERM && EMU == 0), "z2 is stored by the plain exact kernels only");
   constexpr int BK = L::BK;
   constexpr int CT = H / 32;            // 32-col MFMA tiles per wave (all features)
   constexpr int NK = H / BK;            // K slices per unit
@@ -505,20 +505,20 @@ __global__ __launch_bounds__(kThreads, 2) void edge_wave_kernel(EdgeArgs p) {
     }
 
     // ================= wave-private epilogue =================
-    if (MODE == MODE_GCL) {
-      if constexpr (STORE) {
-        // training forward: z2 (bias included) of the wave tile's valid slots, 128-byte row segments per half-wave
-        const int e0 = (my_wt - p.wt_base) * BMW;
-        float* zb = p.z2_out + (size_t)e0 * H + j;
+    if constexpr (STORE) {
+      // training forward: z2 (bias included) of the wave tile's valid slots, 128-byte row segments per half-wave
+      const int e0 = (my_wt - p.wt_base) * BMW;
+      float* zb = p.z2_out + (MODE == MODE_COORD ? (size_t)(qsel + q) * p.z2_stride : (size_t)0) + (size_t)e0 * H + j;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 8 * (r >> 2) + 4 * half + (r & 3);
-          if (e0 + row < E) {
+      for (int r = 0; r < 16; ++r) {
+        const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+        if (e0 + row < E) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) zb[(size_t)row * H + 32 * c] = acc[c][r];
-          }
+          for (int c = 0; c < CT; ++c) zb[(size_t)row * H + 32 * c] = acc[c][r];
         }
       }
+    }
+    if (MODE == MODE_GCL) {
       // messages m = SiLU(acc)   (egnn_new.py:18-19; the bias is already in the accumulators), register pairs
 #pragma unroll
       for (int c = 0; c < CT; ++c)

@@ -1681,15 +1681,17 @@ static hipError_t launch_edge_plain(int H, hipStream_t s, int mode, const EdgeAr
   int64_t g = tiles < 2LL * device_cus() ? tiles : 2LL * device_cus();
   int grid = (int)((g + 7) / 8 * 8);
   if (grid < 8) grid = 8;
-  if (a.z2_out) {          // training forward of the network path: the message stage keeps z2 (edge_wave_kernel<.., STORE>)
-    if (mode != MODE_GCL) return hipErrorInvalidValue;
+  if (a.z2_out) {          // training forward of the network path: the stage keeps z2 (edge_wave_kernel<.., STORE>)
+    if (a.pass_split || a.e_count_b || a.wt_base) return hipErrorInvalidValue;
+#define DSBDD_STORE_CASE(HH) \
+    case HH: if (mode == MODE_GCL) hipLaunchKernelGGL((edge_wave_kernel<HH, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); \
+             else hipLaunchKernelGGL((edge_wave_kernel<HH, MODE_COORD, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); \
+             break;
     switch (H) {
-      case 64: hipLaunchKernelGGL((edge_wave_kernel<64, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
-      case 128: hipLaunchKernelGGL((edge_wave_kernel<128, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
-      case 192: hipLaunchKernelGGL((edge_wave_kernel<192, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
-      case 256: hipLaunchKernelGGL((edge_wave_kernel<256, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); break;
+      DSBDD_STORE_CASE(64) DSBDD_STORE_CASE(128) DSBDD_STORE_CASE(192) DSBDD_STORE_CASE(256)
       default: return hipErrorInvalidValue;
     }
+#undef DSBDD_STORE_CASE
     return hipGetLastError();
   }
   switch (H) {
@@ -1823,7 +1825,17 @@ static hipError_t launch_bwd_b(int H, hipStream_t s, const TrainEdgeArgs& a, int
   return hipGetLastError();
 }
 
-static hipError_t launch_bwd_e(int H, hipStream_t s, const TrainEdgeArgs& a, const float* z2, int grid) {
+static hipError_t launch_bwd_e(int H, hipStream_t s, int mode, const TrainEdgeArgs& a, const float* z2, int grid) {
+  if (mode == MODE_COORD) {
+    switch (H) {
+      case 64: hipLaunchKernelGGL((edge_bwd_ec_kernel<64>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+      case 128: hipLaunchKernelGGL((edge_bwd_ec_kernel<128>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+      case 192: hipLaunchKernelGGL((edge_bwd_ec_kernel<192>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+      case 256: hipLaunchKernelGGL((edge_bwd_ec_kernel<256>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (H) {
     case 64: hipLaunchKernelGGL((edge_bwd_e_kernel<64>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
     case 128: hipLaunchKernelGGL((edge_bwd_e_kernel<128>), dim3(grid), dim3(kThreadsE), 0, s, a, z2); break;
@@ -1891,7 +1903,7 @@ static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph*
   a.a1_out = ts.a1; a.gxr = ts.gxr; a.gxc = ts.gxc; a.gd = ts.gd; a.gd0 = out->gd0;
   // A: dz2, a1, partial bias / head vectors
   a.Bmat = m->W2T; a.dz_out = ts.dz2; a.part = ts.partA;
-  if (z2 && mode == MODE_GCL) HIP_TRY(launch_bwd_e(H, s, a, z2, grid));     // the forward pass kept z2: no H x H layer here
+  if (z2) HIP_TRY(launch_bwd_e(H, s, mode, a, z2, grid));     // the forward pass kept z2: no H x H layer here
   else HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
   // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
   const bool side_w = sd && (sd->mask & (mode == MODE_GCL ? SIDE_GCL_WG : SIDE_COORD_WG));
@@ -1996,9 +2008,20 @@ static int gcl_backward_impl(void* stream, int32_t H, const dsbdd_train_graph* g
   return DSBDD_OK;
 }
 
+static int coord_forward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
+                              const float* x, const float* mean, int64_t n_upd, float norm_constant, float coords_range,
+                              int32_t use_tanh, float norm_factor, float* x_out, void* scratch, size_t scratch_bytes,
+                              float* z2_store, size_t z2_stride);
 int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
                               const float* x, const float* mean, int64_t n_upd, float norm_constant, float coords_range,
                               int32_t use_tanh, float norm_factor, float* x_out, void* scratch, size_t scratch_bytes) {
+  return coord_forward_impl(stream, H, g, m, n_mlp, x, mean, n_upd, norm_constant, coords_range, use_tanh, norm_factor, x_out,
+                            scratch, scratch_bytes, nullptr, 0);
+}
+static int coord_forward_impl(void* stream, int32_t H, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, int32_t n_mlp,
+                              const float* x, const float* mean, int64_t n_upd, float norm_constant, float coords_range,
+                              int32_t use_tanh, float norm_factor, float* x_out, void* scratch, size_t scratch_bytes,
+                              float* z2_store, size_t z2_stride) {
   StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) || (n_mlp == 2 && (!mlp_ok(m + 1) || !mean)) ||
       !m->head || !x || !x_out || n_upd < 0 || n_upd > g->n_nodes || !scratch)
@@ -2019,6 +2042,7 @@ int dsbdd_train_coord_forward(void* stream, int32_t H, const dsbdd_train_graph* 
   ea.w3 = m->head; ea.node_batch = g->node_batch; ea.mean = mean; ea.norm_constant = norm_constant;
   ea.coords_range = coords_range; ea.use_tanh = use_tanh; ea.n_mlp = n_mlp; ea.xagg = ts.xagg; ea.xagg_head = ts.xagg_head;
   ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = 4 * (size_t)((g->n_edges + 31) / 32 + 2); ea.norm_factor = norm_factor;
+  ea.z2_out = z2_store; ea.z2_stride = z2_stride;
   HIP_TRY(launch_edge_plain(H, s, MODE_COORD, ea, g->n_edges));
   hipLaunchKernelGGL(coord_update_kernel, dim3((unsigned)((3 * n_upd + 255) / 256)), dim3(256), 0, s, x_out,
                      (const float*)ts.xagg, (const float*)ts.xagg_head, 1, ea.xagg_stride, ea.xhead_stride, g->row_ptr,
@@ -2031,7 +2055,7 @@ static int coord_backward_impl(void* stream, int32_t H, const dsbdd_train_graph*
                                const float* x, const float* mean, int64_t n_upd, int64_t e_upd, float norm_constant,
                                float coords_range, int32_t use_tanh, float norm_factor, const float* d_xout,
                                const dsbdd_train_mlp_grad* out, float* d_x, float* d_mean, void* scratch,
-                               size_t scratch_bytes, TrainSide* sd) {
+                               size_t scratch_bytes, TrainSide* sd, const float* z2 = nullptr, size_t z2_stride = 0) {
   StreamDevice stream_device_(stream);
   if (!train_h_ok(H) || !graph_ok(g) || !g->rev || n_mlp < 1 || n_mlp > 2 || !mlp_ok(m) ||
       (n_mlp == 2 && (!mlp_ok(m + 1) || !mean || !d_mean)) || !m->head || !x || !d_xout || !out || !d_x || n_upd < 0 ||
@@ -2060,7 +2084,8 @@ static int coord_backward_impl(void* stream, int32_t H, const dsbdd_train_graph*
     dsbdd_train_mlp mq = m[q];
     mq.head = m[0].head;                      // the output layer is shared by both MLPs (egnn_new.py:78,85,91)
     hipStream_t sq = two && q == 1 ? sd->co : s;
-    { const int rc = mlp_backward(sq, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, tq, sd, true); if (rc != DSBDD_OK) return rc; }
+    { const int rc = mlp_backward(sq, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, tq, sd, true, z2 ? z2 + (size_t)q * z2_stride : nullptr);
+      if (rc != DSBDD_OK) return rc; }
     if (sq != s) HIP_TRY(sd->link(sq, s));
     hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)tq.gd,
                        (const float*)tq.gxr, (const float*)tq.gxc, x, g->ecol, g->row_ptr, g->deg, g->rev, (int)e_upd, N,

@@ -507,6 +507,119 @@ __global__ __launch_bounds__(kThreadsE) void edge_bwd_e_kernel(TrainEdgeArgs p, 
   }
 }
 
+// kernel E of the coordinate stage: phi = w3 . SiLU(z2) from the kept z2, the geometry gradients of kernel A's
+// MODE_COORD epilogue (every lane evaluates the edge's scalars; lane 0 stores them), dz2 = d_phi w3 SiLU'(z2).
+template <int H>
+__global__ __launch_bounds__(kThreadsE) void edge_bwd_ec_kernel(TrainEdgeArgs p, const float* __restrict__ z2) {
+  constexpr int V = H / 64, NW = kThreadsE / 64;
+  __shared__ __attribute__((aligned(16))) float sP[NW][2 * H + 4];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  float wd[V], wd0[V], tb[3][V], w3[V];
+  ld_cols<V>(p.wd, lane, wd);
+  ld_cols<V>(p.wd0, lane, wd0);
+#pragma unroll
+  for (int y = 0; y < 3; ++y) ld_cols<V>(p.table + y * H, lane, tb[y]);
+  ld_cols<V>(p.head, lane, w3);
+  const float inv_norm = 1.0f / p.norm_factor;
+  float pb2[V], pv1[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { pb2[k] = 0.f; pv1[k] = 0.f; }
+
+#pragma unroll 1
+  for (int e = blockIdx.x * NW + w; e < p.E; e += gridDim.x * NW) {
+    const int r = __builtin_amdgcn_readfirstlane(p.erow[e]), c = __builtin_amdgcn_readfirstlane(p.ecol[e]);
+    const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.ed0[e])));
+    const bool active = (unsigned)r < (unsigned)p.n_nodes && (unsigned)c < (unsigned)p.n_nodes;
+    float zv[V], a1[V], dz[V];
+    if (!active) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) zv[k] = 0.f;
+      st_cols<V>(p.a1_out + (size_t)e * H, lane, zv);
+      st_cols<V>(p.dz_out + (size_t)e * H, lane, zv);
+      if (lane < 3) {
+        p.gxr[3 * (size_t)e + lane] = 0.f; p.gxc[3 * (size_t)e + lane] = 0.f;
+        if (p.gm) p.gm[3 * (size_t)e + lane] = 0.f;
+      }
+      continue;
+    }
+    float pv[V], qv[V];
+    ld_cols<V>(z2 + (size_t)e * H, lane, zv);
+    ld_cols<V>(p.P + (size_t)r * p.ldpq, lane, pv);
+    ld_cols<V>(p.Q + (size_t)c * p.ldpq, lane, qv);
+    const float xr[3] = {p.x[3 * r], p.x[3 * r + 1], p.x[3 * r + 2]}, xc[3] = {p.x[3 * c], p.x[3 * c + 1], p.x[3 * c + 2]};
+    const float ddx = xr[0] - xc[0], ddy = xr[1] - xc[1], ddz = xr[2] - xc[2];
+    const float d = ddx * ddx + ddy * ddy + ddz * ddz;
+    const bool rl = r < p.n_lig, cl = c < p.n_lig;
+    const int ty = (rl && cl) ? 1 : ((!rl && !cl) ? 2 : 0);
+#pragma unroll
+    for (int k = 0; k < V; ++k) a1[k] = silu(fmaf(d0, wd0[k], fmaf(d, wd[k], pv[k] + qv[k])) + tb[ty][k]);
+    st_cols<V>(p.a1_out + (size_t)e * H, lane, a1);
+    float m[V], sg[V], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      sg[k] = sigmoidf_fast(zv[k]);
+      m[k] = zv[k] * sg[k];
+      dot = fmaf(m[k], w3[k], dot);
+    }
+    const float ph = wave_sum_f(dot);
+    // d_phi and the geometry gradients (egnn_new.py:100-109, 296-316), as kernel A's MODE_COORD epilogue
+    const float g0 = p.d_xagg[3 * r] * inv_norm, g1 = p.d_xagg[3 * r + 1] * inv_norm, g2 = p.d_xagg[3 * r + 2] * inv_norm;
+    float T = ph, dT = 1.f;
+    if (p.use_tanh) { const float th = tanhf(ph); T = th * p.coords_range; dT = (1.0f - th * th) * p.coords_range; }
+    float dphi = 0.f, ar[3] = {0.f, 0.f, 0.f}, ac[3] = {0.f, 0.f, 0.f}, am[3] = {0.f, 0.f, 0.f};
+    if (p.which == 0) {
+      const float nrm = sqrtf(d + 1e-8f), den = nrm + p.norm_constant;
+      const float ux = ddx / den, uy = ddy / den, uz = ddz / den;
+      dphi = (g0 * ux + g1 * uy + g2 * uz) * dT;
+      const float du0 = g0 * T, du1 = g1 * T, du2 = g2 * T;
+      const float sdot = (du0 * ddx + du1 * ddy + du2 * ddz) / (nrm * den * den);
+      ar[0] = du0 / den - ddx * sdot; ar[1] = du1 / den - ddy * sdot; ar[2] = du2 / den - ddz * sdot;
+      ac[0] = -ar[0]; ac[1] = -ar[1]; ac[2] = -ar[2];
+    } else {
+      const int b = p.node_batch[r];
+      const float m0 = p.mean[3 * b], m1 = p.mean[3 * b + 1], m2 = p.mean[3 * b + 2];
+      const float a0 = xr[0] - m0, a1_ = xr[1] - m1, a2 = xr[2] - m2;
+      const float b0 = xc[0] - m0, b1 = xc[1] - m1, b2 = xc[2] - m2;
+      const float c0 = a1_ * b2 - a2 * b1, c1 = a2 * b0 - a0 * b2, c2 = a0 * b1 - a1_ * b0;
+      const float cn = sqrtf(c0 * c0 + c1 * c1 + c2 * c2), cden = cn + p.norm_constant;
+      dphi = (g0 * c0 + g1 * c1 + g2 * c2) / cden * dT;
+      const float dc0 = g0 * T, dc1 = g1 * T, dc2 = g2 * T;
+      const float sdot = cn > 0.f ? (dc0 * c0 + dc1 * c1 + dc2 * c2) / (cn * cden * cden) : 0.f;
+      const float e0 = dc0 / cden - c0 * sdot, e1 = dc1 / cden - c1 * sdot, e2 = dc2 / cden - c2 * sdot;   // d cr
+      ar[0] = b1 * e2 - b2 * e1; ar[1] = b2 * e0 - b0 * e2; ar[2] = b0 * e1 - b1 * e0;
+      ac[0] = e1 * a2 - e2 * a1_; ac[1] = e2 * a0 - e0 * a2; ac[2] = e0 * a1_ - e1 * a0;
+      am[0] = -(ar[0] + ac[0]); am[1] = -(ar[1] + ac[1]); am[2] = -(ar[2] + ac[2]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        p.gxr[3 * (size_t)e + k] = ar[k];
+        p.gxc[3 * (size_t)e + k] = ac[k];
+        if (p.gm) p.gm[3 * (size_t)e + k] = am[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      dz[k] = dphi * w3[k] * dsilu_from(zv[k], sg[k]);
+      pb2[k] += dz[k];
+      pv1[k] = fmaf(dphi, m[k], pv1[k]);
+    }
+    st_cols<V>(p.dz_out + (size_t)e * H, lane, dz);
+  }
+  st_cols<V>(sP[w], lane, pb2);
+  st_cols<V>(sP[w] + H, lane, pv1);
+  __syncthreads();
+  for (int i = t; i < kPartA * H; i += kThreadsE) {
+    float v = 0.f;
+    if (i < 2 * H) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += sP[q][i];
+    }
+    p.part[(size_t)blockIdx.x * kPartAll * H + (size_t)kPartB * H + i] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // kernel B
 template <int H>

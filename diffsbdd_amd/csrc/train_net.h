@@ -351,7 +351,7 @@ static TnPack tn_carve_pack(char* base, const dsbdd_config& c) {
 struct TnWs {
   float *x0, *hf_l, *hf_p, *ze_l, *ae_l, *ze_p, *ae_p, *h0, *hout, *zd_l, *ad_l, *zd_p, *ad_p, *eh_l, *eh_p, *vel, *meanv;
   std::vector<float*> h, x, mean, pq, agg, z, act, pq4;       // h [G + 1], x [L + 1], mean [L], pq/agg/z/act [G], pq4 [L]
-  std::vector<float*> z2;                                     // [G] x [E][H]: the message stages' second-layer pre-activations
+  std::vector<float*> z2, z2c;                                // z2 [G] x [E][H], z2c [L] x [M][E][H]: the edge MLPs' second-layer pre-activations
   // backward
   float *d_vel, *deh_l, *deh_p, *d_h[2], *d_x[2], *d_xg, *d_pq4, *d_pq, *da, *dz, *d_agg, *xcat, *d_hout, *d_h0, *d_hf_l, *d_hf_p,
       *d_small, *gd0, *gd0_tot, *d_mean, *colscr, *dWpq, *d_vec, *demb_part, *wg;
@@ -376,6 +376,7 @@ static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d) {
   for (int b = 0; b < d.L; ++b) { w.mean.push_back(take(3 * (size_t)d.B)); w.pq4.push_back(take(N * 2 * H * d.M)); }
   for (int g = 0; g < d.G; ++g) { w.pq.push_back(take(N * 2 * H)); w.agg.push_back(take(N * H)); w.z.push_back(take(N * H)); w.act.push_back(take(N * H)); }
   for (int g = 0; g < d.G; ++g) w.z2.push_back(tn_store_z2() ? take(E * H) : nullptr);
+  for (int b = 0; b < d.L; ++b) w.z2c.push_back(tn_store_z2() ? take(E * H * d.M) : nullptr);
   w.d_vel = take(3 * N); w.deh_l = take(nl * d.a); w.deh_p = take(np * d.r);
   w.d_h[0] = take(N * H); w.d_h[1] = take(N * H); w.d_x[0] = take(3 * N); w.d_x[1] = take(3 * N); w.d_xg = take(3 * N);
   w.d_pq4 = take(N * 2 * H * d.M); w.d_pq = take(N * 2 * H); w.da = take(N * H); w.dz = take(N * H); w.d_agg = take(N * H);
@@ -572,8 +573,9 @@ int dsbdd_train_net_forward(dsbdd_train_net* net, void* stream, const dsbdd_trai
     dsbdd_train_mlp mm[2];
     mm[0] = tn_mlp(w.pq4[b], 0, H, 2 * H * M, pk.eqm[b * M], P[e + 2], P[e + 3], P[e + 4], nullptr);
     if (M == 2) mm[1] = tn_mlp(w.pq4[b], 2 * H, 3 * H, 2 * H * M, pk.eqm[b * M + 1], P[e + 7], P[e + 8], P[e + 4], nullptr);
-    { const int rc = dsbdd_train_coord_forward(stream, H, g, mm, M, w.x[b], M == 2 ? w.mean[b] : nullptr, n_upd, c.norm_constant,
-                                              c.coords_range, c.use_tanh, c.normalization_factor, w.x[b + 1], w.scratch, w.scratch_bytes); if (rc) return rc; }
+    { const int rc = coord_forward_impl(stream, H, g, mm, M, w.x[b], M == 2 ? w.mean[b] : nullptr, n_upd, c.norm_constant,
+                                       c.coords_range, c.use_tanh, c.normalization_factor, w.x[b + 1], w.scratch, w.scratch_bytes,
+                                       w.z2c[b], (size_t)(d.E > 0 ? d.E : 1) * H); if (rc) return rc; }
   }
   // egnn_new.py:241-243, dynamics.py:136-167
   { int rc = tn_lin(s, w.h[d.G], H, H, nullptr, 0, 0, pk.emb_out.WT, pk.emb_out.ldT, P[ix.emb_out + 1], nullptr, 0, w.hout, JP, N, d.D); if (rc) return rc; }
@@ -696,7 +698,8 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       if (want_in) HIP_TRY(hipMemsetAsync(w.gd0, 0, (size_t)2 * (E > 0 ? E : 1) * 4, s));
       { const int rc = coord_backward_impl(stream, H, g, mm, M, w.x[b], M == 2 ? w.mean[b] : nullptr, n_upd, e_upd, c.norm_constant,
                                           c.coords_range, c.use_tanh, c.normalization_factor, dxo, og, dxi,
-                                          M == 2 ? w.d_mean : nullptr, w.scratch, w.scratch_bytes, sd); if (rc) return rc; }
+                                          M == 2 ? w.d_mean : nullptr, w.scratch, w.scratch_bytes, sd, w.z2c[b],
+                                          (size_t)(E > 0 ? E : 1) * H); if (rc) return rc; }
       for (int q = 0; q < M; ++q) { const int rc = add_gd0(og[q].gd0); if (rc) return rc; }
       // identity path x -> x_out
       hipLaunchKernelGGL(tn_add_kernel, dim3(tn_blocks(3 * (size_t)N)), dim3(256), 0, s, dxi, (const float*)dxo, 3 * (size_t)N);

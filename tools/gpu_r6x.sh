@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, session x: the forward pass keeps z2 of the message stages; kernel E (element-wise) replaces kernel A there.
+# Round 6, session x: the forward pass keeps z2 of the edge MLPs; the element-wise kernels E / EC replace kernel A.
 TAG=${1:-r6x}
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests/test_gpu_train.py tests/test_gpu_reference_caller.py -m gpu -x -q > gpurun_out/${TAG}_train_tests.log 2>&1
