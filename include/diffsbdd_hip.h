@@ -472,7 +472,9 @@ int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int
  * its gradient is the sum over both MLPs).  Every gradient tensor is OVERWRITTEN.
  * graph: dsbdd_build_edges + dsbdd_train_edge_rev on the call's input coordinates (n_edges is a host value).
  * pack: persistent caller-owned buffer (dsbdd_train_net_pack_bytes) for the re-laid-out weights, rewritten by every
- * forward; ws: per-call workspace (dsbdd_train_net_workspace_bytes) that carries the activations from forward to backward.
+ * forward; ws: per-call workspace (dsbdd_train_net_workspace_bytes) that carries the activations from forward to backward
+ * -- including the second-layer pre-activation z2 [E][H] of every edge MLP (4 E H bytes each; DSBDD_TRAIN_STORE_Z2=0:
+ * recomputed in the backward pass instead) -- and two scratch sets for the coordinate stage's two MLPs.
  * Nothing is allocated by the library; no host synchronisation inside (beyond the first call's descriptor upload).
  * Streams: everything is ordered on `stream` as seen by the caller.  Inside, the backward runs the second coordinate
  * MLP's chain and the node-level / coordinate weight gradients on two internal non-blocking streams of the handle
