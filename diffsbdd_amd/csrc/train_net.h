@@ -243,12 +243,10 @@ using namespace dsbdd;
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 static inline int tn_pad4(int v) { return (v + 3) & ~3; }
-// The forward pass keeps z2 [E][H] of every message stage for the backward pass (4 E H bytes per stage: 93 MB at the
-// reference batch) instead of recomputing the H x H layer there; DSBDD_TRAIN_STORE_Z2=0: recompute (kernel A, rounds 4-5).
-static bool tn_store_z2() {
-  static const bool on = [] { const char* v = getenv("DSBDD_TRAIN_STORE_Z2"); return !(v && atoi(v) == 0); }();
-  return on;
-}
+// The forward pass keeps z2 [E][H] of every edge MLP for the backward pass (4 E H bytes each: 93 MB at the reference
+// batch) instead of recomputing the H x H layer there; DSBDD_TRAIN_STORE_Z2=0 (read when the handle is created): recompute
+// (kernel A, rounds 4-5).
+static bool tn_store_z2_env() { const char* v = getenv("DSBDD_TRAIN_STORE_Z2"); return !(v && atoi(v) == 0); }
 
 // parameter tensors in the order of EGNNDynamics' own construction (diffsbdd_amd/synthetic.dynamics_param_shapes; the
 // aliased cross_product_mlp.4.weight is NOT listed: it IS coord_mlp.4.weight, egnn_new.py:78,85,91)
@@ -291,6 +289,7 @@ struct dsbdd_train_net {
   TrainSide side;
   bool side_ready = false;
   int side_mask = 0;
+  bool store_z2 = true;
 };
 
 // sizes of one call
@@ -359,7 +358,7 @@ struct TnWs {
   char* scratch; size_t scratch_bytes;
   size_t bytes;
 };
-static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d) {
+static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d, bool store_z2) {
   TnWs w{};
   size_t off = 0;
   auto takeb = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += al256(bytes); return q; };
@@ -375,8 +374,8 @@ static TnWs tn_carve_ws(char* base, const dsbdd_config& c, const TnDims& d) {
   for (int b = 0; b <= d.L; ++b) w.x.push_back(take(3 * N));
   for (int b = 0; b < d.L; ++b) { w.mean.push_back(take(3 * (size_t)d.B)); w.pq4.push_back(take(N * 2 * H * d.M)); }
   for (int g = 0; g < d.G; ++g) { w.pq.push_back(take(N * 2 * H)); w.agg.push_back(take(N * H)); w.z.push_back(take(N * H)); w.act.push_back(take(N * H)); }
-  for (int g = 0; g < d.G; ++g) w.z2.push_back(tn_store_z2() ? take(E * H) : nullptr);
-  for (int b = 0; b < d.L; ++b) w.z2c.push_back(tn_store_z2() ? take(E * H * d.M) : nullptr);
+  for (int g = 0; g < d.G; ++g) w.z2.push_back(store_z2 ? take(E * H) : nullptr);
+  for (int b = 0; b < d.L; ++b) w.z2c.push_back(store_z2 ? take(E * H * d.M) : nullptr);
   w.d_vel = take(3 * N); w.deh_l = take(nl * d.a); w.deh_p = take(np * d.r);
   w.d_h[0] = take(N * H); w.d_h[1] = take(N * H); w.d_x[0] = take(3 * N); w.d_x[1] = take(3 * N); w.d_xg = take(3 * N);
   w.d_pq4 = take(N * 2 * H * d.M); w.d_pq = take(N * 2 * H); w.da = take(N * H); w.dz = take(N * H); w.d_agg = take(N * H);
@@ -497,6 +496,7 @@ int dsbdd_train_net_create(const dsbdd_config* cfg, dsbdd_train_net** out) {
   auto* n = new dsbdd_train_net();
   n->cfg = *cfg; n->ix = tn_index(*cfg);
   { const char* v = getenv("DSBDD_TRAIN_STREAMS"); n->side_mask = v ? atoi(v) & 15 : kTnSideDefault; }
+  n->store_z2 = tn_store_z2_env();
   *out = n;
   return DSBDD_OK;
 }
@@ -508,7 +508,7 @@ int dsbdd_train_net_param_count(const dsbdd_train_net* n) { return n ? n->ix.n :
 size_t dsbdd_train_net_pack_bytes(const dsbdd_train_net* n) { return n ? tn_carve_pack(nullptr, n->cfg).bytes : 0; }
 size_t dsbdd_train_net_workspace_bytes(const dsbdd_train_net* n, const dsbdd_train_graph* g) {
   if (!n || !graph_ok(g)) return 0;
-  return tn_carve_ws(nullptr, n->cfg, tn_dims(n->cfg, g)).bytes;
+  return tn_carve_ws(nullptr, n->cfg, tn_dims(n->cfg, g), n->store_z2).bytes;
 }
 
 int dsbdd_train_net_forward(dsbdd_train_net* net, void* stream, const dsbdd_train_graph* g, const float* const* params,
@@ -525,7 +525,7 @@ int dsbdd_train_net_forward(dsbdd_train_net* net, void* stream, const dsbdd_trai
   const TnDims d = tn_dims(c, g);
   const TnPack pk = tn_carve_pack(static_cast<char*>(pack), c);
   if (pk.bytes > pack_bytes) return fail(DSBDD_ERR_CAPACITY, "pack buffer too small (dsbdd_train_net_pack_bytes)");
-  const TnWs w = tn_carve_ws(static_cast<char*>(ws), c, d);
+  const TnWs w = tn_carve_ws(static_cast<char*>(ws), c, d, net->store_z2);
   if (w.bytes > ws_bytes) return fail(DSBDD_ERR_CAPACITY, "workspace too small (dsbdd_train_net_workspace_bytes)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* const* P = params;
@@ -604,7 +604,7 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
   const TnDims d = tn_dims(c, g);
   if ((d.n_l > 0 && !d_eps_lig) || (d.n_p > 0 && !d_eps_pocket)) return fail(DSBDD_ERR_ARG, "null output gradient");
   const TnPack pk = tn_carve_pack(static_cast<char*>(pack), c);
-  const TnWs w = tn_carve_ws(static_cast<char*>(ws), c, d);
+  const TnWs w = tn_carve_ws(static_cast<char*>(ws), c, d, net->store_z2);
   if (pk.bytes > pack_bytes || w.bytes > ws_bytes) return fail(DSBDD_ERR_CAPACITY, "buffer too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (net->side_mask && !net->side_ready) {
