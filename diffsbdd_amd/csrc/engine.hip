@@ -1678,11 +1678,14 @@ static int device_cus() {      // CU count of the CURRENT device (cached per dev
 
 static hipError_t launch_edge_plain(int H, hipStream_t s, int mode, const EdgeArgs& a, int64_t edge_bound) {
   int64_t tiles = (edge_bound + 127) / 128;
-  int64_t g = tiles < 2LL * device_cus() ? tiles : 2LL * device_cus();
-  int grid = (int)((g + 7) / 8 * 8);
-  if (grid < 8) grid = 8;
+  const bool split = mode == MODE_COORD && a.pass_split && a.n_mlp == 2;      // one workgroup per (tile, MLP)
+  int64_t g = split ? 2 * tiles : tiles;
+  if (g > 2LL * device_cus()) g = 2LL * device_cus();
+  const int q8 = split ? 16 : 8;
+  int grid = (int)((g + q8 - 1) / q8 * q8);
+  if (grid < q8) grid = q8;
   if (a.z2_out) {          // training forward of the network path: the stage keeps z2 (edge_wave_kernel<.., STORE>)
-    if (a.pass_split || a.e_count_b || a.wt_base) return hipErrorInvalidValue;
+    if (a.e_count_b || a.wt_base) return hipErrorInvalidValue;
 #define DSBDD_STORE_CASE(HH) \
     case HH: if (mode == MODE_GCL) hipLaunchKernelGGL((edge_wave_kernel<HH, MODE_GCL, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); \
              else hipLaunchKernelGGL((edge_wave_kernel<HH, MODE_COORD, false, 0, true>), dim3(grid), dim3(kThreads), 0, s, a); \
@@ -1793,7 +1796,7 @@ static TrainScratch carve_train(char* base, int H, int64_t N, int64_t E) {
   t.wg = take(t.wg_floats);
   t.gd = take(E + 1); t.gxr = take(3 * (size_t)E + 4); t.gxc = take(3 * (size_t)E + 4); t.gm = take(3 * (size_t)E + 4);
   t.agg_head = take((size_t)((E + 31) / 32 + 2) * H);
-  t.xagg = take(3 * (size_t)N + 4); t.xagg_head = take(4 * (size_t)((E + 31) / 32 + 2));
+  t.xagg = take(2 * (3 * (size_t)N + 4)); t.xagg_head = take(2 * 4 * (size_t)((E + 31) / 32 + 2));   // one sum per MLP (pass split)
   t.vec = take(8 * (size_t)H);
   t.bytes = off;
   return t;
@@ -2043,9 +2046,12 @@ static int coord_forward_impl(void* stream, int32_t H, const dsbdd_train_graph* 
   ea.coords_range = coords_range; ea.use_tanh = use_tanh; ea.n_mlp = n_mlp; ea.xagg = ts.xagg; ea.xagg_head = ts.xagg_head;
   ea.xagg_stride = (size_t)N * 3; ea.xhead_stride = 4 * (size_t)((g->n_edges + 31) / 32 + 2); ea.norm_factor = norm_factor;
   ea.z2_out = z2_store; ea.z2_stride = z2_stride;
+  // two MLPs: alternate workgroups take one MLP of a tile each (the updated rows' edge prefix is a fraction of a tile per
+  // CU: twice as many, half as long work items), one coordinate sum per MLP, added by coord_update_kernel
+  ea.pass_split = n_mlp == 2 ? 1 : 0;
   HIP_TRY(launch_edge_plain(H, s, MODE_COORD, ea, g->n_edges));
   hipLaunchKernelGGL(coord_update_kernel, dim3((unsigned)((3 * n_upd + 255) / 256)), dim3(256), 0, s, x_out,
-                     (const float*)ts.xagg, (const float*)ts.xagg_head, 1, ea.xagg_stride, ea.xhead_stride, g->row_ptr,
+                     (const float*)ts.xagg, (const float*)ts.xagg_head, ea.pass_split ? 2 : 1, ea.xagg_stride, ea.xhead_stride, g->row_ptr,
                      g->deg, (int)(3 * n_upd), (int)((g->n_edges + 31) / 32 + 1), 5);
   HIP_TRY(hipGetLastError());
   return DSBDD_OK;
