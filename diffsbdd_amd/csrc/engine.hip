@@ -1866,6 +1866,7 @@ enum { SIDE_CO = 1, SIDE_NODE_WG = 2, SIDE_COORD_WG = 4, SIDE_GCL_WG = 8 };
 struct TrainSide {
   hipStream_t wg = nullptr, co = nullptr;
   int mask = 0;                  // SIDE_* : what runs beside the main chain
+  int device = -1;               // the device the streams live on (a module moved to another GPU gets new ones)
   std::vector<hipEvent_t> ev;
   size_t next = 0;
   // everything queued on `to` after this call starts after everything queued on `from` before it
@@ -1875,7 +1876,8 @@ struct TrainSide {
     return r != hipSuccess ? r : hipStreamWaitEvent(to, e, 0);
   }
   hipError_t create() {
-    hipError_t r = hipStreamCreateWithFlags(&wg, hipStreamNonBlocking);
+    hipError_t r = hipGetDevice(&device);
+    if (r == hipSuccess) r = hipStreamCreateWithFlags(&wg, hipStreamNonBlocking);
     if (r == hipSuccess) r = hipStreamCreateWithFlags(&co, hipStreamNonBlocking);
     ev.resize(32);
     for (size_t i = 0; r == hipSuccess && i < ev.size(); ++i) r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);

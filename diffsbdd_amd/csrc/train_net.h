@@ -607,6 +607,11 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
   const TnWs w = tn_carve_ws(static_cast<char*>(ws), c, d, net->store_z2);
   if (pk.bytes > pack_bytes || w.bytes > ws_bytes) return fail(DSBDD_ERR_CAPACITY, "buffer too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (net->side_ready) {          // (the StreamDevice guard above made the stream's device current)
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != net->side.device) { net->side.destroy(); net->side_ready = false; }
+  }
   if (net->side_mask && !net->side_ready) {
     HIP_TRY(net->side.create());
     net->side.mask = net->side_mask;
