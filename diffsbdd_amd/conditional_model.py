@@ -350,8 +350,9 @@ class ConditionalDDPM(EnVariationalDiffusion):
         mu = self.alpha(gamma_T, xh_lig)[mask_lig] * xh_lig
         sigma_T = self.sigma(gamma_T, xh_lig).squeeze()
         one = torch.ones_like(sigma_T)
-        kl_h = self.gaussian_KL(self.sum_except_batch(mu[:, nd:] ** 2, mask_lig), sigma_T, one, d=1)
-        kl_x = self.gaussian_KL(self.sum_except_batch(mu[:, :nd] ** 2, mask_lig), sigma_T, one,
+        nb = len(num_nodes)
+        kl_h = self.gaussian_KL(self.sum_except_batch(mu[:, nd:] ** 2, mask_lig, nb), sigma_T, one, d=1)
+        kl_x = self.gaussian_KL(self.sum_except_batch(mu[:, :nd] ** 2, mask_lig, nb), sigma_T, one,
                                 self.subspace_dimensionality(num_nodes))
         return kl_x + kl_h
 
@@ -378,25 +379,37 @@ class ConditionalDDPM(EnVariationalDiffusion):
             xh0_lig = torch.cat([xl, xh0_lig[:, nd:]], dim=1)
             xh0_pocket = torch.cat([xp, xh0_pocket[:, nd:]], dim=1)
             z_t, xh_pocket, eps_t = self.noised_representation(xh0_lig, xh0_pocket, lm, pm, gamma_t)
-            net, _ = self.dynamics(z_t, xh_pocket, t, lm, pm)
-            xh_lig_hat = self.xh_given_zt_and_epsilon(z_t, net, gamma_t, lm)
-            squared_error = (eps_t - net) ** 2
-            if self.vnode_idx is not None:       # coordinates of virtual atoms do not contribute (:253-255)
-                squared_error[ligand['one_hot'][:, self.vnode_idx].bool(), :nd] = 0
-            error_t_lig = self.sum_except_batch(squared_error, lm)
+            # the terms that do not read the network's output come first: the host issues them while the GPU still works
+            # on the previous step, and nothing but the error terms stands between the network call and backward()
+            # (same values: none of them draws random numbers).  No term below synchronises with the device.
             SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
             neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=ligand['size'], device=dev)
             kl_prior = self.kl_prior(xh0_lig, lm, ligand['size'])
+            log_pN = self.log_pN(ligand['size'], pocket['size'])
+            vmask = vmask2 = None
+            if self.vnode_idx is not None:
+                vmask = ligand['one_hot'][:, self.vnode_idx].bool()
+                vmask2 = torch.zeros(vmask.shape[0], nd + ligand['one_hot'].shape[1], dtype=torch.bool, device=dev)
+                vmask2[:, :nd] = vmask.unsqueeze(1)
+            l0_h_train = -self._log_ph_given_z0(ligand['one_hot'], z_t[:, nd:], lm, gamma_t) if self.training else None
+            net, _ = self.dynamics(z_t, xh_pocket, t, lm, pm)
+            xh_lig_hat = self.xh_given_zt_and_epsilon(z_t, net, gamma_t, lm)
+            squared_error = (eps_t - net) ** 2
+            if vmask is not None:                # coordinates of virtual atoms do not contribute (:253-255)
+                squared_error = squared_error.masked_fill(vmask2, 0)      # (no boolean-index assignment: that is a nonzero() + sync)
+            error_t_lig = self.sum_except_batch(squared_error, lm, n)
 
-            def loss0(z0, e0, n0, g):
+            def loss0(z0, e0, n0, g, l0_h=None):
                 sq = (e0[:, :nd] - n0[:, :nd]) ** 2
-                if self.vnode_idx is not None:
-                    sq[ligand['one_hot'][:, self.vnode_idx].bool(), :nd] = 0
-                return 0.5 * self.sum_except_batch(sq, lm), -self._log_ph_given_z0(ligand['one_hot'], z0[:, nd:], lm, g)
+                if vmask is not None:
+                    sq = sq.masked_fill(vmask.unsqueeze(1), 0)
+                if l0_h is None:
+                    l0_h = -self._log_ph_given_z0(ligand['one_hot'], z0[:, nd:], lm, g)
+                return 0.5 * self.sum_except_batch(sq, lm, n), l0_h
 
             if self.training:
                 tz = t_is_zero.squeeze()
-                l0_x, l0_h = loss0(z_t, eps_t, net, gamma_t)
+                l0_x, l0_h = loss0(z_t, eps_t, net, gamma_t, l0_h_train)
                 l0_x, l0_h = l0_x * tz, l0_h * tz
                 error_t_lig = error_t_lig * (1 - tz)
             else:                                   # separate pass at t = 0 (:285-302)
@@ -405,7 +418,6 @@ class ConditionalDDPM(EnVariationalDiffusion):
                 z_0, xh_pocket0, eps_0 = self.noised_representation(xh0_lig, xh0_pocket, lm, pm, gamma_0)
                 net_0, _ = self.dynamics(z_0, xh_pocket0, t_zeros, lm, pm)
                 l0_x, l0_h = loss0(z_0, eps_0, net_0, gamma_0)
-            log_pN = self.log_pN(ligand['size'], pocket['size'])
             info = {
                 'eps_hat_lig_x': seg_mean(net[:, :nd].abs().mean(1), lm, n).mean(),
                 'eps_hat_lig_h': seg_mean(net[:, nd:].abs().mean(1), lm, n).mean(),

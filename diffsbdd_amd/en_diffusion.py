@@ -181,6 +181,7 @@ class DistributionNodes:
                             for j in range(n2)]
         self.n2_given_n1 = [torch.distributions.Categorical(self.prob[i, :], validate_args=True)
                             for i in range(n1)]
+        self._tables = {}
 
     def sample(self, n_samples=1):
         idx = self.m.sample((n_samples,))
@@ -195,21 +196,31 @@ class DistributionNodes:
 
     def log_prob(self, batch_n_nodes_1, batch_n_nodes_2):
         assert batch_n_nodes_1.dim() == 1 and batch_n_nodes_2.dim() == 1
-        idx = torch.tensor([self.n_nodes_to_idx[(a, b)] for a, b in
-                            zip(batch_n_nodes_1.tolist(), batch_n_nodes_2.tolist())])
-        return self.m.log_prob(idx).to(batch_n_nodes_1.device)
+        key = (2, str(batch_n_nodes_1.device))
+        if key not in self._tables:          # the joint categorical's logits as an [n1][n2] table on the device
+            self._tables[key] = self.m.logits.view(self.prob.shape).to(batch_n_nodes_1.device)
+        return self._tables[key][batch_n_nodes_1.long(), batch_n_nodes_2.long()]
+
+    def _table(self, which, device):
+        """[n1][n2] log-probabilities of the conditional categoricals -- the `logits` the per-sample
+        `Categorical.log_prob` calls gather from (same numbers), on `device`, built once: one gather per batch instead
+        of a host loop over the samples with two device-to-host copies."""
+        key = (which, str(device))
+        if key not in self._tables:
+            if which == 0:     # log p(n1 | n2)
+                t = torch.stack([d.logits for d in self.n1_given_n2], dim=1)
+            else:              # log p(n2 | n1)
+                t = torch.stack([d.logits for d in self.n2_given_n1], dim=0)
+            self._tables[key] = t.to(device)
+        return self._tables[key]
 
     def log_prob_n1_given_n2(self, n1, n2):
         assert n1.dim() == 1 and n2.dim() == 1
-        n1c, n2c = n1.cpu(), n2.cpu()             # one copy each (a device tensor would synchronise per sample)
-        return torch.stack([self.n1_given_n2[int(c)].log_prob(i)
-                            for i, c in zip(n1c, n2c)]).to(n1.device)
+        return self._table(0, n1.device)[n1.long(), n2.long()]
 
     def log_prob_n2_given_n1(self, n2, n1):
         assert n1.dim() == 1 and n2.dim() == 1
-        n1c, n2c = n1.cpu(), n2.cpu()
-        return torch.stack([self.n2_given_n1[int(c)].log_prob(i)
-                            for i, c in zip(n2c, n1c)]).to(n2.device)
+        return self._table(1, n1.device)[n1.long(), n2.long()]
 
 
 # ---------------------------------------------------------------------------
@@ -454,8 +465,9 @@ class EnVariationalDiffusion(nn.Module):
         return torch.cat([x_l, h_l], dim=1), torch.cat([x_p, h_p], dim=1)
 
     @staticmethod
-    def remove_mean_batch(x, indices):
-        n = int(indices.max()) + 1 if indices.numel() else 0
+    def remove_mean_batch(x, indices, n=None):
+        if n is None:
+            n = int(indices.max()) + 1 if indices.numel() else 0
         return x - seg_mean(x, indices, n)[indices]
 
     @staticmethod
@@ -513,7 +525,7 @@ class EnVariationalDiffusion(nn.Module):
         logp = torch.log(self.cdf_standard_gaussian((centered + 0.5) / sigma_0_cat[mask])
                          - self.cdf_standard_gaussian((centered - 0.5) / sigma_0_cat[mask]) + epsilon)
         logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
-        return self.sum_except_batch(logp * onehot, mask)
+        return self.sum_except_batch(logp * onehot, mask, gamma_0.shape[0])
 
     def kl_prior_with_pocket(self, xh_lig, xh_pocket, mask_lig, mask_pocket, num_nodes):
         """KL(q(z_T | x) || N(0, 1)), en_diffusion.py:109-155."""
@@ -524,8 +536,9 @@ class EnVariationalDiffusion(nn.Module):
         sigma_T = self.sigma(gamma_T, xh_lig).squeeze()
         mu_l, mu_p = alpha_T[mask_lig] * xh_lig, alpha_T[mask_pocket] * xh_pocket
         one = torch.ones_like(sigma_T)
-        mu2_h = self.sum_except_batch(mu_l[:, nd:] ** 2, mask_lig) + self.sum_except_batch(mu_p[:, nd:] ** 2, mask_pocket)
-        mu2_x = self.sum_except_batch(mu_l[:, :nd] ** 2, mask_lig) + self.sum_except_batch(mu_p[:, :nd] ** 2, mask_pocket)
+        nb = len(num_nodes)
+        mu2_h = self.sum_except_batch(mu_l[:, nd:] ** 2, mask_lig, nb) + self.sum_except_batch(mu_p[:, nd:] ** 2, mask_pocket, nb)
+        mu2_x = self.sum_except_batch(mu_l[:, :nd] ** 2, mask_lig, nb) + self.sum_except_batch(mu_p[:, :nd] ** 2, mask_pocket, nb)
         return self.gaussian_KL(mu2_x, sigma_T, one, self.subspace_dimensionality(num_nodes)) + \
             self.gaussian_KL(mu2_h, sigma_T, one, d=1)
 
@@ -560,15 +573,15 @@ class EnVariationalDiffusion(nn.Module):
             z_l, z_p, eps_l, eps_p = self.noised_representation(xh_lig, xh_pocket, lm, pm, gamma_t)
             net_l, net_p = self.dynamics(z_l.contiguous(), z_p.contiguous(), t, lm, pm)
             xh_lig_hat = self.xh_given_zt_and_epsilon(z_l, net_l, gamma_t, lm)
-            error_t_lig = self.sum_except_batch((eps_l - net_l) ** 2, lm)
-            error_t_pocket = self.sum_except_batch((eps_p - net_p) ** 2, pm)
+            error_t_lig = self.sum_except_batch((eps_l - net_l) ** 2, lm, n)
+            error_t_pocket = self.sum_except_batch((eps_p - net_p) ** 2, pm, n)
             SNR_weight = (1 - self.SNR(gamma_s - gamma_t)).squeeze(1)
             neg_log_constants = -self.log_constants_p_x_given_z0(n_nodes=n_nodes, device=dev)
             kl_prior = self.kl_prior_with_pocket(xh_lig, xh_pocket, lm, pm, n_nodes)
 
             def loss0(zl, zp, el, ep, nl, np_, g):
-                lx_l = 0.5 * self.sum_except_batch((el[:, :nd] - nl[:, :nd]) ** 2, lm)
-                lx_p = 0.5 * self.sum_except_batch((ep[:, :nd] - np_[:, :nd]) ** 2, pm)
+                lx_l = 0.5 * self.sum_except_batch((el[:, :nd] - nl[:, :nd]) ** 2, lm, n)
+                lx_p = 0.5 * self.sum_except_batch((ep[:, :nd] - np_[:, :nd]) ** 2, pm, n)
                 lh = -(self._log_ph_given_z0(ligand['one_hot'], zl[:, nd:], lm, g)
                        + self._log_ph_given_z0(pocket['one_hot'], zp[:, nd:], pm, g))
                 return lx_l, lx_p, lh
@@ -1115,8 +1128,12 @@ class EnVariationalDiffusion(nn.Module):
         return -self.subspace_dimensionality(num_nodes) * np.log(self.norm_values[0])
 
     @staticmethod
-    def sum_except_batch(x, indices):
-        n = int(indices.max()) + 1
+    def sum_except_batch(x, indices, n=None):
+        """utils.sum_except_batch.  `n`: the batch size when the caller knows it -- `indices.max()` as a host value is a
+        device synchronisation, and after the network call of a training step it stalls the host behind the whole
+        EGNN forward (round 6: the loss terms pass it)."""
+        if n is None:
+            n = int(indices.max()) + 1
         return seg_sum(x.sum(-1), indices, n)
 
     @staticmethod

@@ -696,3 +696,30 @@ def test_committed_pmc_traffic_was_measured_on_the_committed_kernel_sources():
     # the figure itself: between the algorithmic bytes of the launch (65.5 MB) and a small multiple of them
     assert 60e6 < rec["traffic_bytes_per_launch"] < 200e6
     assert abs(rec["traffic_bytes_per_launch"] - (2 * rec["FETCH_SIZE_kb"] + rec["WRITE_SIZE_kb"]) * 1024) < 1.0
+
+
+def test_size_distribution_log_prob_tables_equal_the_categorical_calls():
+    """Round 6: log p(n1 | n2), log p(n2 | n1) and the joint log p(n1, n2) of a batch are ONE gather from a cached
+    [n1][n2] table of the categoricals' logits (en_diffusion.py:958-1028 evaluates a Categorical per sample on the host) --
+    the same numbers, no host loop and no device synchronisation in the training step's loss terms."""
+    import numpy as np
+    from diffsbdd_amd.en_diffusion import DistributionNodes
+    rng = np.random.default_rng(0)
+    d = DistributionNodes(rng.integers(0, 50, size=(12, 30)).astype(float))
+    n1 = torch.tensor([0, 3, 11, 5, 7, 7])
+    n2 = torch.tensor([29, 0, 4, 4, 10, 10])
+    ref = torch.stack([d.n1_given_n2[int(c)].log_prob(i) for i, c in zip(n1, n2)])
+    assert torch.equal(ref, d.log_prob_n1_given_n2(n1, n2))
+    ref = torch.stack([d.n2_given_n1[int(c)].log_prob(i) for i, c in zip(n2, n1)])
+    assert torch.equal(ref, d.log_prob_n2_given_n1(n2, n1))
+    idx = torch.tensor([d.n_nodes_to_idx[(int(a), int(b))] for a, b in zip(n1, n2)])
+    assert torch.equal(d.m.log_prob(idx), d.log_prob(n1, n2))
+
+
+def test_sum_except_batch_with_a_known_batch_size():
+    from diffsbdd_amd.en_diffusion import EnVariationalDiffusion as D
+    x = torch.arange(24.0).view(8, 3)
+    idx = torch.tensor([0, 0, 1, 1, 1, 3, 3, 3])
+    assert torch.equal(D.sum_except_batch(x, idx), D.sum_except_batch(x, idx, 4))
+    assert D.sum_except_batch(x, idx, 6).shape == (6,)       # trailing samples without nodes: zeros
+    assert torch.equal(D.remove_mean_batch(x, idx), D.remove_mean_batch(x, idx, 4))

@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--paths", default="net,functions,torch",
                     help="DSBDD_TRAIN values: net (one launch sequence per direction, round 6), functions (= hip: the per-stage autograd "
                          "Functions of rounds 4 - 5), torch (round 3's eager path)")
+    ap.add_argument("--bare", action="store_true",
+                    help="free-running loop only: dynamics forward + a one-kernel loss + backward + optimiser, inputs prepared "
+                         "beforehand -- the step without the reference's loss glue (what the ~340 small torch launches cost)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     key = "ca" if "ca_" in a.workload else "fa"
@@ -92,6 +95,22 @@ def main():
             opt.step()
         torch.cuda.synchronize()
         t_free = (time.perf_counter() - t0) / a.steps
+        if a.bare:
+            lm, pm = ligand["mask"], pocket["mask"]
+            nl, npk = lm.numel(), pm.numel()
+            zs = [(torch.randn(nl, 3 + cfg["atom_nf"], device=dev), torch.randn(npk, 3 + cfg["residue_nf"], device=dev) ,
+                   torch.rand(B, 1, device=dev)) for _ in range(a.steps)]
+            for z in zs:
+                z[1][:, :3] = pocket["x"] / dd["norm_values"][0]; z[0][:, :3] = ligand["x"] / dd["norm_values"][0] + 0.1 * z[0][:, :3]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for zl, zp, tt in zs:
+                opt.zero_grad(set_to_none=True)
+                eps, _ = model.dynamics(zl, zp, tt, lm, pm)
+                (eps ** 2).mean().backward()
+                opt.step()
+            torch.cuda.synchronize()
+            print(f"bare step ({path}): {(time.perf_counter() - t0) / a.steps * 1e3:.2f} ms", flush=True)
         n_nodes = int(pocket["mask"].numel() + ligand["mask"].numel())
         with torch.no_grad():
             e = model.dynamics.get_edges(ligand["mask"], pocket["mask"], ligand["x"], pocket["x"])
