@@ -51,6 +51,14 @@ class TrainGraph(C.Structure):
                                           "poc_off")] + [(n, C.c_int64) for n in ("n_lig", "n_nodes", "n_edges", "batch")]
 
 
+class LossCfg(C.Structure):
+    """struct dsbdd_loss_cfg"""
+    _fields_ = [(n, C.c_int32) for n in ("batch", "n_lig", "n_pocket", "atom_nf", "residue_nf", "timesteps", "remove_com",
+                                         "vnode_idx")] + \
+               [(n, C.c_float) for n in ("norm_value_x", "norm_value_h", "norm_bias_h")] + \
+               [(n, C.c_int32) for n in ("n1_tab", "n2_tab")]
+
+
 class TrainMlp(C.Structure):
     """struct dsbdd_train_mlp"""
     _fields_ = [("P", C.c_void_p), ("Q", C.c_void_p), ("ldpq", C.c_int32)] + \
@@ -136,6 +144,12 @@ SIGNATURES = {
                                           _P, _I64, _I32, _P, _P, _P]),
     "dsbdd_train_net_backward": (C.c_int, [_P, _P, C.POINTER(TrainGraph), C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t, _P,
                                            C.c_size_t, _I64, _P, _P, _P, _P]),
+    # the loss terms of the pocket-conditioned training step around the network call (csrc/loss_head.h)
+    "dsbdd_loss_rows": (C.c_int, []),
+    "dsbdd_loss_out_rows": (C.c_int, []),
+    "dsbdd_loss_cond_pre": (C.c_int, [_P, C.POINTER(LossCfg)] + [_P] * 17),
+    "dsbdd_loss_cond_post": (C.c_int, [_P, C.POINTER(LossCfg)] + [_P] * 8),
+    "dsbdd_loss_cond_post_backward": (C.c_int, [_P, C.POINTER(LossCfg)] + [_P] * 9),
 }
 
 _lib = None

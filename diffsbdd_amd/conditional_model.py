@@ -359,6 +359,11 @@ class ConditionalDDPM(EnVariationalDiffusion):
     def forward(self, ligand, pocket, return_info=False):
         """The reference's loss terms for the pocket-conditioned model (conditional_model.py:202-330):
         same 12-tuple as the joint model with error_t_pocket = loss_0_x_pocket = 0."""
+        from . import loss_head
+        if loss_head.fused_ok(self, self._hip_device(None)):
+            # training mode under autograd, predefined schedule: the same terms on three HIP launches around the network
+            # call (csrc/loss_head.h); DSBDD_LOSS=torch keeps the torch terms below
+            return loss_head.conditional_forward(self, ligand, pocket, return_info)
         with self._loss_context():
             dev = self._hip_device(None)
             ligand, pocket = self._to_device(ligand, dev), self._to_device(pocket, dev)

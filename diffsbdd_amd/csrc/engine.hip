@@ -2155,3 +2155,66 @@ int dsbdd_train_colsum(void* stream, const float* A, int32_t lda, int64_t M, int
 
 // ---- the training step as one launch sequence per direction (round 6) ------------------------------------------------
 #include "train_net.h"
+
+// ---- the loss terms of the pocket-conditioned training step around the network call (round 6) --------------------------
+#include "loss_head.h"
+
+static LossCfg loss_cfg_of(const dsbdd_loss_cfg* c) {
+  return LossCfg{c->batch, c->n_lig, c->n_pocket, c->atom_nf, c->residue_nf, c->timesteps, c->remove_com, c->vnode_idx,
+                 c->norm_value_x, c->norm_value_h, c->norm_bias_h, c->n1_tab, c->n2_tab};
+}
+static bool loss_cfg_ok(const dsbdd_loss_cfg* c) {
+  return c && c->batch > 0 && c->n_lig >= 0 && c->n_pocket >= 0 && c->atom_nf > 0 && c->residue_nf > 0 && c->timesteps > 0 &&
+         c->norm_value_x > 0.f && c->norm_value_h > 0.f && c->vnode_idx < c->atom_nf;
+}
+
+extern "C" {
+
+int dsbdd_loss_rows(void) { return LS_ROWS; }
+int dsbdd_loss_out_rows(void) { return LO_ROWS; }
+
+int dsbdd_loss_cond_pre(void* stream, const dsbdd_loss_cfg* cfg, const float* lig_x, const float* lig_h, const int64_t* lig_mask,
+                        const float* pocket_x, const float* pocket_h, const int64_t* pocket_mask, const float* eps,
+                        const float* t_int, const float* gamma_table, const float* logpn_table, float* z_t, float* xh_pocket,
+                        float* per_sample, float* lig_x_norm, float* lig_h_norm, float* pocket_x_norm, float* pocket_h_norm) {
+  StreamDevice stream_device_(stream);
+  if (!loss_cfg_ok(cfg) || !t_int || !gamma_table || !per_sample || (cfg->n_lig > 0 && (!lig_x || !lig_h || !lig_mask || !eps || !z_t)) ||
+      (cfg->n_pocket > 0 && (!pocket_x || !pocket_h || !pocket_mask || !xh_pocket)) || (logpn_table && (cfg->n1_tab < 1 || cfg->n2_tab < 1)))
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(loss_cond_pre_kernel, dim3((unsigned)cfg->batch), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream),
+                     loss_cfg_of(cfg), lig_x, lig_h, reinterpret_cast<const long long*>(lig_mask), pocket_x, pocket_h,
+                     reinterpret_cast<const long long*>(pocket_mask), eps, t_int, gamma_table, logpn_table, z_t, xh_pocket, per_sample,
+                     lig_x_norm, lig_h_norm, pocket_x_norm, pocket_h_norm);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_loss_cond_post(void* stream, const dsbdd_loss_cfg* cfg, const float* net, const float* eps, const float* z_t,
+                         const float* lig_h, const int64_t* lig_mask, const float* per_sample, float* xh_hat, float* out) {
+  StreamDevice stream_device_(stream);
+  if (!loss_cfg_ok(cfg) || !per_sample || !out || (cfg->n_lig > 0 && (!net || !eps || !z_t || !lig_h || !lig_mask || !xh_hat)))
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(loss_cond_post_kernel, dim3((unsigned)cfg->batch), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream),
+                     loss_cfg_of(cfg), net, eps, z_t, lig_h, reinterpret_cast<const long long*>(lig_mask), per_sample, xh_hat, out);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+int dsbdd_loss_cond_post_backward(void* stream, const dsbdd_loss_cfg* cfg, const float* net, const float* eps, const float* lig_h,
+                                  const int64_t* lig_mask, const float* per_sample, const float* g_err, const float* g_l0x,
+                                  const float* g_hat, float* d_net) {
+  StreamDevice stream_device_(stream);
+  if (!loss_cfg_ok(cfg) || !per_sample || (cfg->n_lig > 0 && (!net || !eps || !lig_h || !lig_mask || !d_net)))
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  if (cfg->n_lig == 0) return DSBDD_OK;
+  const size_t n = (size_t)cfg->n_lig * (3 + cfg->atom_nf);
+  unsigned grid = (unsigned)((n + kLossThreads - 1) / kLossThreads);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(loss_cond_post_bwd_kernel, dim3(grid), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream),
+                     loss_cfg_of(cfg), net, eps, lig_h, reinterpret_cast<const long long*>(lig_mask), per_sample, g_err, g_l0x,
+                     g_hat, d_net);
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
+}  // extern "C"

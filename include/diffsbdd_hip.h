@@ -498,6 +498,42 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
                              int64_t e_upd, const float* d_eps_lig, const float* d_eps_pocket, float* d_xh_lig,
                              float* d_xh_pocket);
 
+/* ---- the loss terms of the pocket-conditioned training step --------------------------------------------
+ * ConditionalDDPM.forward around the network call (conditional_model.py:202-330 -> en_diffusion.py:109-262 for the terms):
+ * normalisation, ligand-COM removal, z_t = alpha_t xh0 + sigma_t eps (centred again), and the twelve per-sample terms.
+ * The reference-side binding calls _pre, then EGNNDynamics.forward (dsbdd_train_net_forward), then _post inside ONE
+ * torch.autograd.Function whose backward is _post_backward (diffsbdd_amd/loss_head.py).
+ * Predefined noise schedules only (gamma_table [timesteps + 1], en_diffusion.py:1158-1190); training mode (t may be 0: the
+ * L0 terms are evaluated on z_t and masked by [t = 0], conditional_model.py:285-302).
+ *   lig_x [n_lig][3], lig_h [n_lig][atom_nf] (raw one-hot), lig_mask [n_lig] int64 sorted ascending; pocket likewise;
+ *   eps [n_lig][3 + atom_nf] standard normal draws; t_int [batch] integer-valued floats in [0, timesteps];
+ *   logpn_table [n1_tab][n2_tab] = log p(n_lig | n_pocket) or NULL.
+ * _pre writes z_t [n_lig][3 + atom_nf], xh_pocket [n_pocket][3 + residue_nf] and per_sample [dsbdd_loss_rows()][batch]:
+ *   rows t, gamma_t, gamma_s, alpha_t, sigma_t, SNR_weight, neg_log_constants, kl_prior, loss_0_h (x [t = 0]), log_pN,
+ *   delta_log_px, [t = 0]; optionally (non-NULL) the normalised batch x / norm_value_x, (h - norm_bias_h) / norm_value_h that
+ *   normalize() (en_diffusion.py:880-895) leaves in the caller's dictionaries.
+ * _post writes xh_hat [n_lig][3 + atom_nf] and out [dsbdd_loss_out_rows()][batch]: error_t (x [t > 0]), loss_0_x (x [t = 0]),
+ *   mean |net_x|, mean |net_h| per sample.  _post_backward: d_net from the gradients of error_t / loss_0_x (per sample) and of
+ *   xh_hat (or NULL).  Every per-sample sum is taken in a fixed order (the reference's scatter_add uses atomics). */
+typedef struct {
+  int32_t batch, n_lig, n_pocket, atom_nf, residue_nf, timesteps;
+  int32_t remove_com;     /* 1: ConditionalDDPM (ligand COM removed from ligand and pocket, dof = 3 (n - 1)); 0: SimpleConditionalDDPM */
+  int32_t vnode_idx;      /* class index of the virtual atom (its coordinates do not enter the error terms) or -1 */
+  float norm_value_x, norm_value_h, norm_bias_h;
+  int32_t n1_tab, n2_tab;
+} dsbdd_loss_cfg;
+int dsbdd_loss_rows(void);
+int dsbdd_loss_out_rows(void);
+int dsbdd_loss_cond_pre(void* stream, const dsbdd_loss_cfg* cfg, const float* lig_x, const float* lig_h, const int64_t* lig_mask,
+                        const float* pocket_x, const float* pocket_h, const int64_t* pocket_mask, const float* eps,
+                        const float* t_int, const float* gamma_table, const float* logpn_table, float* z_t, float* xh_pocket,
+                        float* per_sample, float* lig_x_norm, float* lig_h_norm, float* pocket_x_norm, float* pocket_h_norm);
+int dsbdd_loss_cond_post(void* stream, const dsbdd_loss_cfg* cfg, const float* net, const float* eps, const float* z_t,
+                         const float* lig_h, const int64_t* lig_mask, const float* per_sample, float* xh_hat, float* out);
+int dsbdd_loss_cond_post_backward(void* stream, const dsbdd_loss_cfg* cfg, const float* net, const float* eps, const float* lig_h,
+                                  const int64_t* lig_mask, const float* per_sample, const float* g_err, const float* g_l0x,
+                                  const float* g_hat, float* d_net);
+
 /* ---- post-processing of a finished batch ------------------*/
 /* Distance-based bond orders of a batch of molecules: replaces
  * get_bond_order_batch + the (X, A, E) step of make_mol_edm

@@ -7,6 +7,7 @@ autograd on the CPU -- the literal reference graph -- on the small architectures
 B = 8 (E > 40 k, H = 256), every parameter gradient at 1e-4 of that gradient's largest entry.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -510,3 +511,63 @@ def test_kept_z2_backward_agrees_with_the_recompute_backward(arch, n_lig, n_poc)
         worst = max(worst, e)
         assert e < 1e-5, (k, e)
     print(arch, "kept z2 vs recompute: worst relative difference", worst)
+
+
+@pytest.mark.parametrize("workload,vnode", [("crossdock_fullatom_cond", None), ("crossdock_ca_cond", None),
+                                            ("crossdock_fullatom_cond", 3)])
+def test_loss_terms_on_hip_launches_agree_with_the_torch_terms(workload, vnode):
+    """Round 6: in training mode the twelve loss terms of ConditionalDDPM.forward (conditional_model.py:202-330) are
+    evaluated by csrc/loss_head.h -- one launch before the network call, one after, one in backward -- instead of ~ 250
+    torch launches (DSBDD_LOSS=torch keeps those).  Same t (incl. t = 0: the L0 terms), same keyed noise: every term, the two
+    logged means, the normalised batch left in the dictionaries and every parameter gradient of the l2 objective agree to
+    rounding (1e-5 of the term's scale; per-sample sums are fixed-order here, atomics in torch)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from train_step_bench import build, loss_of
+    from diffsbdd_amd import synthetic as S
+    key = "ca" if "ca_" in workload else "fa"
+    B = 6
+    model, cfg, dd = build(workload, dev())
+    model.train(True)
+    model.vnode_idx = vnode
+    rng = np.random.default_rng(3)
+    t_fix = torch.tensor(rng.integers(0, dd["timesteps"] + 1, size=(B, 1)), dtype=torch.float32)
+    t_fix[0, 0] = 0.0
+    t_fix[1, 0] = float(dd["timesteps"])
+    model.t_int_source = lambda b: t_fix
+    res = {}
+    old = os.environ.get("DSBDD_LOSS")
+    try:
+        for mode in ("torch", "hip"):
+            os.environ["DSBDD_LOSS"] = mode
+            pocket = S.load_pocket(key, B, dev())
+            ligand = S.anchor_ligand(B, 23, cfg["atom_nf"], dev())
+            model.seed(77)
+            model.zero_grad(set_to_none=True)
+            out = model(ligand, pocket, return_info=True)
+            loss_of(out[:12]).backward()
+            res[mode] = dict(terms=[torch.as_tensor(v).detach().float().cpu() for v in out[:12]],
+                             info={k: float(v.detach()) for k, v in out[12].items()},
+                             grads={k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None},
+                             batch=[ligand['x'].detach().cpu(), ligand['one_hot'].detach().cpu(), pocket['x'].detach().cpu(),
+                                    pocket['one_hot'].detach().cpu()])
+    finally:
+        if old is None:
+            os.environ.pop("DSBDD_LOSS", None)
+        else:
+            os.environ["DSBDD_LOSS"] = old
+    names = ("delta_log_px", "error_t_lig", "error_t_pocket", "SNR_weight", "loss_0_x_ligand", "loss_0_x_pocket", "loss_0_h",
+             "neg_log_constants", "kl_prior", "log_pN", "t_int", "xh_lig_hat")
+    for nme, a, b in zip(names, res["hip"]["terms"], res["torch"]["terms"]):
+        assert a.shape == b.shape, (nme, a.shape, b.shape)
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 1e-5 * scale, (nme, (a - b).abs().max().item(), scale)
+    assert res["torch"]["terms"][4][0].abs().item() > 0 and res["torch"]["terms"][1][0].item() == 0      # the t = 0 sample: L0_x live, error_t masked
+    for k, v in res["torch"]["info"].items():
+        assert abs(res["hip"]["info"][k] - v) <= 1e-5 * max(1.0, abs(v)), k
+    for a, b in zip(res["hip"]["batch"], res["torch"]["batch"]):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-6
+    assert set(res["hip"]["grads"]) == set(res["torch"]["grads"])
+    for k, g in res["torch"]["grads"].items():
+        scale = max(g.abs().max().item(), 1e-6)
+        assert (res["hip"]["grads"][k] - g).abs().max().item() <= 2e-5 * scale, (k, (res["hip"]["grads"][k] - g).abs().max().item(), scale)
