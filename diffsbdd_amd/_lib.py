@@ -145,6 +145,7 @@ SIGNATURES = {
     "dsbdd_train_net_backward": (C.c_int, [_P, _P, C.POINTER(TrainGraph), C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t, _P,
                                            C.c_size_t, _I64, _P, _P, _P, _P]),
     # the loss terms of the pocket-conditioned training step around the network call (csrc/loss_head.h)
+    "dsbdd_edge_capacity": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _P]),
     "dsbdd_loss_rows": (C.c_int, []),
     "dsbdd_loss_out_rows": (C.c_int, []),
     "dsbdd_loss_cond_pre": (C.c_int, [_P, C.POINTER(LossCfg)] + [_P] * 17),

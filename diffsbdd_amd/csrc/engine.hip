@@ -2170,6 +2170,18 @@ static bool loss_cfg_ok(const dsbdd_loss_cfg* c) {
 
 extern "C" {
 
+int dsbdd_edge_capacity(void* stream, const int64_t* lig_mask, int64_t n_lig, const int64_t* pocket_mask, int64_t n_pocket,
+                        int64_t batch, int64_t* out) {
+  StreamDevice stream_device_(stream);
+  if (!out || batch < 1 || n_lig < 0 || n_pocket < 0 || (n_lig > 0 && !lig_mask) || (n_pocket > 0 && !pocket_mask))
+    return fail(DSBDD_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(edge_capacity_kernel, dim3(1), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(lig_mask), (int)n_lig, reinterpret_cast<const long long*>(pocket_mask),
+                     (int)n_pocket, (int)batch, reinterpret_cast<long long*>(out));
+  HIP_TRY(hipGetLastError());
+  return DSBDD_OK;
+}
+
 int dsbdd_loss_rows(void) { return LS_ROWS; }
 int dsbdd_loss_out_rows(void) { return LO_ROWS; }
 

@@ -54,6 +54,37 @@ __device__ __forceinline__ float gamma_at(const float* table, int T, float t) {
   return table[i];
 }
 
+// engine.edge_capacity in one launch: out[0] = the masks are sorted ascending with ids in [0, batch), out[1] = sum over the
+// samples of the complete graph's edges with every (sample, node set) segment rounded up to 32 (csrc/graph.h).  One
+// workgroup; ~ 25 torch launches (two bincounts, the comparisons, their reductions) before every training forward otherwise.
+__global__ __launch_bounds__(kLossThreads) void edge_capacity_kernel(const long long* ml, int n_l, const long long* mp, int n_p,
+                                                                      int batch, long long* out) {
+  __shared__ long long cap_s[kLossThreads];
+  __shared__ int ok_s[kLossThreads];
+  const int t = threadIdx.x;
+  int ok = 1;
+  for (int i = t; i + 1 < n_l; i += kLossThreads) ok &= ml[i + 1] >= ml[i];
+  for (int i = t; i + 1 < n_p; i += kLossThreads) ok &= mp[i + 1] >= mp[i];
+  if (t == 0) {
+    if (n_l > 0) ok &= ml[0] >= 0 && ml[n_l - 1] < batch;
+    if (n_p > 0) ok &= mp[0] >= 0 && mp[n_p - 1] < batch;
+  }
+  long long cap = 0;
+  for (int b = t; b < batch; b += kLossThreads) {
+    const long long nl = lower_bound_i64(ml, n_l, b + 1) - lower_bound_i64(ml, n_l, b);
+    const long long np = lower_bound_i64(mp, n_p, b + 1) - lower_bound_i64(mp, n_p, b);
+    const long long n = nl + np;
+    cap += (nl * n + 31) / 32 * 32 + (np * n + 31) / 32 * 32;
+  }
+  cap_s[t] = cap; ok_s[t] = ok;
+  __syncthreads();
+  for (int o = kLossThreads / 2; o > 0; o >>= 1) {
+    if (t < o) { cap_s[t] += cap_s[t + o]; ok_s[t] &= ok_s[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) { out[0] = ok_s[0]; out[1] = cap_s[0]; }
+}
+
 __global__ __launch_bounds__(kLossThreads) void loss_cond_pre_kernel(
     LossCfg c, const float* lig_x, const float* lig_h, const long long* lig_mask, const float* poc_x, const float* poc_h,
     const long long* poc_mask, const float* eps, const float* t_int, const float* gamma_table, const float* logpn_table,

@@ -130,6 +130,18 @@ def edge_capacity(mask_lig, mask_pocket, batch, check_sorted=True):
     kernels locate a sample's rows by binary search, so the masks must be sorted
     ascending with ids in [0, batch) (the reference's scatter ops would accept any
     order; here it is an error, raised before anything is launched)."""
+    if mask_lig.is_cuda and check_sorted and mask_lig.dtype == torch.int64 and mask_pocket.dtype == torch.int64:
+        # one launch + the one host sync (csrc/loss_head.h edge_capacity_kernel); the torch expressions below are ~ 25 launches
+        lib = _lib.load()
+        ml, mp = mask_lig.contiguous(), mask_pocket.contiguous()
+        out = torch.empty(2, dtype=torch.int64, device=ml.device)
+        _lib.check(lib.dsbdd_edge_capacity(torch.cuda.current_stream(ml.device).cuda_stream, ml.data_ptr(), ml.numel(),
+                                           mp.data_ptr(), mp.numel(), int(batch), out.data_ptr()), "dsbdd_edge_capacity")
+        ok_h, cap_h = out.tolist()
+        if not ok_h:
+            raise ValueError("batch masks must be sorted ascending with ids in [0, batch): the HIP kernels "
+                             "locate a sample's rows by binary search")
+        return int(cap_h)
     ok = torch.ones((), dtype=torch.bool, device=mask_lig.device)
     if check_sorted:
         for m in (mask_lig, mask_pocket):

@@ -65,19 +65,27 @@ class TrainGraph:
                                          self.poc_off.data_ptr(), self.deg.data_ptr(), self.row_ptr.data_ptr(),
                                          erow.data_ptr(), ecol.data_ptr(), ed0.data_ptr(), cap, status.data_ptr()),
                    "dsbdd_build_edges")
-        rp = self.row_ptr[[N, n_l]].tolist()          # one host sync per training forward
-        E = int(rp[0])
-        self.E, self.e_lig = E, int(rp[1])
+        # one host sync per training forward: the edge count and the edge prefix of the ligand rows
+        rp = self.row_ptr[n_l::N - n_l].tolist() if N > n_l else [int(self.row_ptr[N].item())] * 2
+        E = int(rp[-1])
+        self.E, self.e_lig = E, int(rp[0])
         self.erow, self.ecol, self.ed0 = erow[:max(E, 1)], ecol[:max(E, 1)], ed0[:max(E, 1)]
         self.n_lig, self.N, self.batch = n_l, N, batch
         self.rev = torch.empty(max(E, 1), **i32)
-        self.cnt = torch.bincount(self.node_batch.long(), minlength=batch).clamp(min=1).to(torch.float32)
+        self._cnt = None
         self.c = _lib.TrainGraph(erow=self.erow.data_ptr(), ecol=self.ecol.data_ptr(), ed0=self.ed0.data_ptr(),
                                  row_ptr=self.row_ptr.data_ptr(), deg=self.deg.data_ptr(), rev=self.rev.data_ptr(),
                                  node_batch=self.node_batch.data_ptr(), lig_off=self.lig_off.data_ptr(),
                                  poc_off=self.poc_off.data_ptr(), n_lig=n_l, n_nodes=N, n_edges=E, batch=batch)
         _lib.check(lib.dsbdd_train_edge_rev(_stream(dev), C.byref(self.c), self.rev.data_ptr()), "dsbdd_train_edge_rev")
         self._scratch = {}
+
+    @property
+    def cnt(self):
+        """nodes per sample (>= 1), for the per-stage Functions' mean backward; the network path does not need it"""
+        if self._cnt is None:
+            self._cnt = torch.bincount(self.node_batch.long(), minlength=self.batch).clamp(min=1).to(torch.float32)
+        return self._cnt
 
     def scratch(self, H):
         if H not in self._scratch:

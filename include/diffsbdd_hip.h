@@ -522,6 +522,12 @@ typedef struct {
   float norm_value_x, norm_value_h, norm_bias_h;
   int32_t n1_tab, n2_tab;
 } dsbdd_loss_cfg;
+/* Upper bound on the edge list dsbdd_build_edges writes for these (sorted) batch masks, and their validity, in one launch:
+ * out[0] = 1 when both masks are sorted ascending with ids in [0, batch), out[1] = sum over the samples of the complete
+ * graph's edges (dynamics.py:170-172) with every (sample, node set) segment rounded up to 32.  The host reads both words
+ * (diffsbdd_amd/engine.py edge_capacity). */
+int dsbdd_edge_capacity(void* stream, const int64_t* lig_mask, int64_t n_lig, const int64_t* pocket_mask, int64_t n_pocket,
+                        int64_t batch, int64_t* out);
 int dsbdd_loss_rows(void);
 int dsbdd_loss_out_rows(void);
 int dsbdd_loss_cond_pre(void* stream, const dsbdd_loss_cfg* cfg, const float* lig_x, const float* lig_h, const int64_t* lig_mask,

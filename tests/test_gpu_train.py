@@ -571,3 +571,20 @@ def test_loss_terms_on_hip_launches_agree_with_the_torch_terms(workload, vnode):
     for k, g in res["torch"]["grads"].items():
         scale = max(g.abs().max().item(), 1e-6)
         assert (res["hip"]["grads"][k] - g).abs().max().item() <= 2e-5 * scale, (k, (res["hip"]["grads"][k] - g).abs().max().item(), scale)
+
+
+def test_edge_capacity_kernel_equals_the_torch_expressions():
+    """engine.edge_capacity on GPU masks is one launch (csrc/loss_head.h edge_capacity_kernel) + the one host sync; it must
+    return what the torch expressions return for the same masks (they still serve CPU tensors) and reject what they reject."""
+    from diffsbdd_amd.engine import edge_capacity
+    g = torch.Generator().manual_seed(0)
+    for batch in (1, 3, 16, 300):
+        nl = torch.randint(0, 40, (batch,), generator=g)
+        npk = torch.randint(0, 400, (batch,), generator=g)
+        ml = torch.repeat_interleave(torch.arange(batch), nl)
+        mp = torch.repeat_interleave(torch.arange(batch), npk)
+        assert edge_capacity(ml.to(dev()), mp.to(dev()), batch) == edge_capacity(ml, mp, batch)
+    ml = torch.tensor([0, 0, 1, 1, 2]); mp = torch.tensor([0, 1, 1, 2, 2, 2])
+    for bad_l, bad_p, b in ((ml.flip(0), mp, 3), (ml, mp.flip(0), 3), (ml, mp, 2), (ml - 1, mp, 3)):
+        with pytest.raises(ValueError, match="sorted"):
+            edge_capacity(bad_l.to(dev()), bad_p.to(dev()), b)
