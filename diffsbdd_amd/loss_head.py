@@ -79,7 +79,10 @@ def conditional_forward(ddpm, ligand, pocket, return_info=False):
     pm = pocket['mask'].to(device=dev, dtype=torch.int64).contiguous()
     B = ligand['size'].size(0)
     a, r = lh.shape[1], ph.shape[1]
-    tab = ddpm.size_distribution._table(0, dev) if ddpm.size_distribution is not None else None
+    # log p(n_lig | n_pocket) as a device table when the size distribution is the package's DistributionNodes; any other
+    # object keeps its own log_prob_n1_given_n2 call below
+    table_of = getattr(ddpm.size_distribution, "_table", None)
+    tab = table_of(0, dev) if table_of is not None else None
     cfg = _lib.LossCfg(batch=B, n_lig=lx.shape[0], n_pocket=px.shape[0], atom_nf=a, residue_nf=r, timesteps=ddpm.T,
                        remove_com=int(bool(ddpm._remove_com)), vnode_idx=-1 if ddpm.vnode_idx is None else int(ddpm.vnode_idx),
                        norm_value_x=float(ddpm.norm_values[0]), norm_value_h=float(ddpm.norm_values[1]),
@@ -103,7 +106,7 @@ def conditional_forward(ddpm, ligand, pocket, return_info=False):
     (t, _g_t, _g_s, _al, _si, snr_w, neg_log_c, kl_prior, l0_h, log_pN, delta_log_px, _tz) = ps.unbind(0)
     net, _ = ddpm.dynamics(z_t, xh_pocket, t.unsqueeze(1), lm, pm)
     error_t, l0_x, xh_hat, info_x, info_h = _Post.apply(net, cfg, eps, z_t, lh, lm, ps)
-    if ddpm.size_distribution is None:
+    if tab is None:
         log_pN = ddpm.log_pN(ligand['size'], pocket['size'])
     zero = torch.tensor(0.0)
     terms = (delta_log_px, error_t, zero, snr_w, l0_x, zero.clone(), l0_h, neg_log_c, kl_prior, log_pN, t_int.squeeze(), xh_hat)

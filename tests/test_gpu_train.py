@@ -514,7 +514,7 @@ def test_kept_z2_backward_agrees_with_the_recompute_backward(arch, n_lig, n_poc)
 
 
 @pytest.mark.parametrize("workload,vnode", [("crossdock_fullatom_cond", None), ("crossdock_ca_cond", None),
-                                            ("crossdock_fullatom_cond", 3)])
+                                            ("crossdock_fullatom_cond", 3), ("crossdock_ca_cond", "simple")])
 def test_loss_terms_on_hip_launches_agree_with_the_torch_terms(workload, vnode):
     """Round 6: in training mode the twelve loss terms of ConditionalDDPM.forward (conditional_model.py:202-330) are
     evaluated by csrc/loss_head.h -- one launch before the network call, one after, one in backward -- instead of ~ 250
@@ -529,6 +529,10 @@ def test_loss_terms_on_hip_launches_agree_with_the_torch_terms(workload, vnode):
     B = 6
     model, cfg, dd = build(workload, dev())
     model.train(True)
+    if vnode == "simple":      # SimpleConditionalDDPM (conditional_model.py:702-746): no COM projection, dof = 3 n
+        from diffsbdd_amd.conditional_model import SimpleConditionalDDPM
+        model.__class__ = SimpleConditionalDDPM
+        vnode = None
     model.vnode_idx = vnode
     rng = np.random.default_rng(3)
     t_fix = torch.tensor(rng.integers(0, dd["timesteps"] + 1, size=(B, 1)), dtype=torch.float32)

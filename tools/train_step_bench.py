@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--paths", default="net,functions,torch",
                     help="DSBDD_TRAIN values: net (one launch sequence per direction, round 6), functions (= hip: the per-stage autograd "
                          "Functions of rounds 4 - 5), torch (round 3's eager path)")
+    ap.add_argument("--fused-adam", action="store_true",
+                    help="AdamW(fused=True): torch's single multi-tensor kernel instead of the foreach implementation the reference's "
+                         "configure_optimizers call gets by default (a caller-side option, reported separately)")
     ap.add_argument("--bare", action="store_true",
                     help="free-running loop only: dynamics forward + a one-kernel loss + backward + optimiser, inputs prepared "
                          "beforehand -- the step without the reference's loss glue (what the ~340 small torch launches cost)")
@@ -64,7 +67,8 @@ def main():
         os.environ["DSBDD_TRAIN"] = path
         model, cfg, dd = build(a.workload, dev)
         model.train(True)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, amsgrad=True, weight_decay=1e-12)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, amsgrad=True, weight_decay=1e-12,
+                                **({"fused": True} if a.fused_adam else {}))
         tf = tb = to = 0.0
         n_nodes = n_edges = 0
         for it in range(a.warmup + a.steps):
