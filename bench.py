@@ -351,16 +351,16 @@ def secondary_workloads(device, n_lig_atoms, steps=3, emulated_legs=True):
     return out
 
 
-def training_leg(device, n_lig_atoms, steps=10, warmup=3):
+def training_leg(device, n_lig_atoms, steps=10, warmup=3, workload="crossdock_fullatom_cond", B=16):
     """SURVEY.md 8f-3, so that the driver's record holds it: the reference's training step (lightning_modules.py:337-363:
-    `ddpm(ligand, pocket)` -> l2 objective -> `backward()` -> AdamW(amsgrad), :183-185) on crossdock_fullatom_cond at the
-    reference's batch size (configs/crossdock_fullatom_cond.yml:13: 16), forward AND backward on the HIP kernels
-    (diffsbdd_amd/train_hip.py over csrc/train.h), free-running (no synchronisation inside a step), batches resident.
+    `ddpm(ligand, pocket)` -> l2 objective -> `backward()` -> AdamW(amsgrad), :183-185) at the reference's batch size
+    (configs/crossdock_fullatom_cond.yml:13: 16; crossdock_ca_cond.yml:13: 96), loss terms, forward AND backward on the HIP
+    kernels (diffsbdd_amd/loss_head.py, train_net.py over csrc/loss_head.h, train_net.h, train.h), free-running (no
+    synchronisation inside a step beyond the radius graph's edge count), batches resident.
     Roofline: forward + input-gradient + weight-gradient FLOPs of what the step evaluates (every row in every stage;
-    coordinate MLPs on the ligand-row edges) against the fp32 matrix peak; the recomputation the kernels choose instead of
-    storing [E][H] activations is stated separately and NOT counted."""
-    arch, key, _ = WORKLOADS["crossdock_fullatom_cond"]
-    B = 16
+    coordinate MLPs on the ligand-row edges) against the fp32 matrix peak.  (Since round 6 the forward pass keeps the edge
+    MLPs' second-layer pre-activations; the recompute FLOPs stated separately are only spent with DSBDD_TRAIN_STORE_Z2=0.)"""
+    arch, key, _ = WORKLOADS[workload]
     cfg, dd, model = build_model(arch, device)
     model.train(True)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, amsgrad=True, weight_decay=1e-12)
@@ -398,14 +398,14 @@ def training_leg(device, n_lig_atoms, steps=10, warmup=3):
     tfl = flops / dt / 1e12
     del model, opt
     torch.cuda.empty_cache()
-    return {"workload": "training step: crossdock_fullatom_cond", "pockets": "same", "batch": B, "value": B / dt, "unit": "complexes/s",
+    return {"workload": "training step: " + workload, "pockets": "same", "batch": B, "value": B / dt, "unit": "complexes/s",
             "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32", "nodes": N, "edges": E,
             "edges_coordinate_stage": E_u, "optimizer": "AdamW(amsgrad)", "call": "ddpm(ligand, pocket) -> l2 terms -> "
-            "backward() -> opt.step() (lightning_modules.py:337-363,183-185), EGNN forward and backward on HIP kernels",
+            "backward() -> opt.step() (lightning_modules.py:337-363,183-185), loss terms, EGNN forward and backward on HIP kernels",
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tfl / FP32_MATRIX_PEAK_TFLOPS, "algorithmic_flops_per_step": flops,
                          "counted": "forward + dgrad + wgrad of every Linear (3 x 2 x forward MAC)",
-                         "recompute_flops_per_step_not_counted": recompute}}
+                         "recompute_flops_per_step_not_counted_only_with_DSBDD_TRAIN_STORE_Z2_0": recompute}}
 
 
 def self_launch(n, attempts=3):
@@ -762,11 +762,12 @@ def main():
         if world == 1 and not args.no_other_workloads and args.workload == "crossdock_fullatom_cond" and \
                 args.pockets == "same" and args.timesteps is None and args.batch is None:
             other_workloads = secondary_workloads(device, args.n_lig, steps=args.secondary_steps, emulated_legs=not args.no_emulated_leg)
-            try:
-                other_workloads.append(training_leg(device, args.n_lig))
-            except Exception as exc:      # the training leg must not cost the benchmark line
-                other_workloads.append({"workload": "training step: crossdock_fullatom_cond", "pockets": "same", "value": None,
-                                        "error": repr(exc)[:300]})
+            for wl_, b_ in (("crossdock_fullatom_cond", 16), ("crossdock_ca_cond", 96)):
+                try:
+                    other_workloads.append(training_leg(device, args.n_lig, workload=wl_, B=b_))
+                except Exception as exc:      # the training legs must not cost the benchmark line
+                    other_workloads.append({"workload": "training step: " + wl_, "pockets": "same", "value": None,
+                                            "error": repr(exc)[:300]})
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not joint:
             cpu = cpu_baseline(arch, key, args.cpu_batch or B, args.n_lig, n_calls, steps=args.cpu_steps,
@@ -834,6 +835,9 @@ def main():
                     summ[k_]["emulated"] = r3(w_["emulated"].get("value"))
         if train_w is not None and train_w.get("value") is not None:
             summ["train"] = {"ms": r3(train_w["ms_per_step"]), "frac": r3(train_w["roofline"]["frac"])}
+        train_ca = wl("training step: crossdock_ca_cond")
+        if train_ca is not None and train_ca.get("value") is not None:
+            summ["train_ca96"] = {"ms": r3(train_ca["ms_per_step"]), "frac": r3(train_ca["roofline"]["frac"])}
         line["summary"] = summ
         assert len(json.dumps(summ)) < 1200
         print(json.dumps(line), flush=True)
