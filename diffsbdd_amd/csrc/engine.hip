@@ -1867,6 +1867,8 @@ struct TrainSide {
   hipStream_t wg = nullptr, co = nullptr;
   int mask = 0;                  // SIDE_* : what runs beside the main chain
   int device = -1;               // the device the streams live on (a module moved to another GPU gets new ones)
+  hipEvent_t w2_done[2] = {nullptr, nullptr};   // after the last W2 weight gradient queued on `wg` that reads scratch set q
+  bool w2_valid[2] = {false, false};
   std::vector<hipEvent_t> ev;
   size_t next = 0;
   // everything queued on `to` after this call starts after everything queued on `from` before it
@@ -1881,26 +1883,37 @@ struct TrainSide {
     if (r == hipSuccess) r = hipStreamCreateWithFlags(&co, hipStreamNonBlocking);
     ev.resize(32);
     for (size_t i = 0; r == hipSuccess && i < ev.size(); ++i) r = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    for (int q = 0; r == hipSuccess && q < 2; ++q) r = hipEventCreateWithFlags(&w2_done[q], hipEventDisableTiming);
+    w2_valid[0] = w2_valid[1] = false;
     return r;
   }
   void destroy() {
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     ev.clear();
+    for (int q = 0; q < 2; ++q) { if (w2_done[q]) (void)hipEventDestroy(w2_done[q]); w2_done[q] = nullptr; w2_valid[q] = false; }
     if (wg) (void)hipStreamDestroy(wg);
     if (co) (void)hipStreamDestroy(co);
     wg = co = nullptr;
   }
 };
 
-// the backward of ONE edge MLP: kernel A -> weight gradient -> kernel B -> node gathers; returns the per-edge gradient
-// w.r.t. the current squared distance in ts.gd.  `sd` (optional): the weight gradient goes to sd->wg; unless `linked`,
-// the chain first waits for that stream (the previous weight gradient reads ts.dz2 / ts.a1 / ts.wg, which kernel A and
-// this weight gradient overwrite).
+// the backward of ONE edge MLP: kernel A / E -> weight gradient -> kernel B -> node gathers; returns the per-edge gradient
+// w.r.t. the current squared distance in ts.gd.  `sd` (optional) -- what waits for what:
+//   * kernel A / E overwrites ts.dz2 / ts.a1 of scratch set `set`: it waits for the last W2 weight gradient that read this
+//     set on the side stream (its own event), NOT for the whole side stream -- the node-level weight gradients queued there
+//     keep running beside the memory-bound kernel E (waiting for them cost the main chain 60 - 70 us per stage);
+//   * the message stage's W2 gradient stays on this stream and is preceded by a FULL join of the side stream: it streams
+//     373 MB and runs 1.6 x longer with anything beside it, and the join is the one point per block that covers the
+//     caller's hazards (dsbdd_train_net_backward: dout, dz / xcat, d_pq / d_pq4 are overwritten after it only);
+//   * a coordinate stage's W2 gradient goes to the side stream and records the set's event.
 static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph* g, const dsbdd_train_mlp* m, const float* x,
                         int64_t E, TrainEdgeArgs a, const dsbdd_train_mlp_grad* out, const TrainScratch& ts,
-                        TrainSide* sd = nullptr, bool linked = false, const float* z2 = nullptr) {
+                        TrainSide* sd = nullptr, bool linked = false, const float* z2 = nullptr, int set = 0) {
   const int grid = train_grid(E);
-  if (sd && !linked) HIP_TRY(sd->link(sd->wg, s));
+  const bool side_w = sd && (sd->mask & (mode == MODE_GCL ? SIDE_GCL_WG : SIDE_COORD_WG));
+  const bool late_join = sd && mode == MODE_GCL && !side_w;      // the full join sits in front of the W2 gradient instead
+  if (sd && !linked && !late_join) { HIP_TRY(sd->link(sd->wg, s)); HIP_TRY(sd->link(sd->co, s)); }
+  if (sd && sd->w2_valid[set]) HIP_TRY(hipStreamWaitEvent(s, sd->w2_done[set], 0));
   const int slots = grid;                  // one partial-vector slot per workgroup
   a.erow = g->erow; a.ecol = g->ecol; a.ed0 = g->ed0; a.E = (int)E; a.x = x; a.n_lig = (int)g->n_lig;
   a.n_nodes = (int)g->n_nodes; a.P = m->P; a.Q = m->Q; a.ldpq = m->ldpq; a.wd = m->wd; a.wd0 = m->wd0; a.table = m->tab;
@@ -1911,9 +1924,10 @@ static int mlp_backward(hipStream_t s, int H, int mode, const dsbdd_train_graph*
   if (z2) HIP_TRY(launch_bwd_e(H, s, mode, a, z2, grid));     // the forward pass kept z2: no H x H layer here
   else HIP_TRY(launch_bwd_a(H, s, mode, a, grid));
   // dW2[f][i] = sum_e dz2[e][f] a1[e][i]
-  const bool side_w = sd && (sd->mask & (mode == MODE_GCL ? SIDE_GCL_WG : SIDE_COORD_WG));
   if (side_w) HIP_TRY(sd->link(s, sd->wg));
+  if (late_join) { HIP_TRY(sd->link(sd->wg, s)); HIP_TRY(sd->link(sd->co, s)); }
   { const int rc = wgrad_impl(side_w ? sd->wg : s, ts.dz2, H, ts.a1, H, E, H, H, out->d_W2, ts.wg, ts.wg_floats); if (rc != DSBDD_OK) return rc; }
+  if (side_w) { HIP_TRY(hipEventRecord(sd->w2_done[set], sd->wg)); sd->w2_valid[set] = true; }
   // B: dz1, partial first-layer vectors, per-edge distance gradients
   a.Bmat = m->W2; a.dz_in = ts.dz2; a.dz_out = ts.dz1; a.part = ts.partB;
   HIP_TRY(launch_bwd_b(H, s, a, grid));
@@ -2081,7 +2095,6 @@ static int coord_backward_impl(void* stream, int32_t H, const dsbdd_train_graph*
   // order q = 0, 1 on this stream
   const bool two = sd && (sd->mask & SIDE_CO) && n_mlp == 2 && scratch_bytes >= 2 * ts.bytes;
   const TrainScratch ts1 = two ? carve_train(static_cast<char*>(scratch) + ts.bytes, H, g->n_nodes, g->n_edges) : ts;
-  if (sd) HIP_TRY(sd->link(sd->wg, s));
   if (two) HIP_TRY(sd->link(s, sd->co));
   for (int q = 0; q < n_mlp; ++q) {
     TrainEdgeArgs a{};
@@ -2092,7 +2105,8 @@ static int coord_backward_impl(void* stream, int32_t H, const dsbdd_train_graph*
     dsbdd_train_mlp mq = m[q];
     mq.head = m[0].head;                      // the output layer is shared by both MLPs (egnn_new.py:78,85,91)
     hipStream_t sq = two && q == 1 ? sd->co : s;
-    { const int rc = mlp_backward(sq, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, tq, sd, true, z2 ? z2 + (size_t)q * z2_stride : nullptr);
+    { const int rc = mlp_backward(sq, H, MODE_COORD, g, &mq, x, e_upd, a, out + q, tq, sd, true, z2 ? z2 + (size_t)q * z2_stride : nullptr,
+                                  two && q == 1 ? 1 : 0);
       if (rc != DSBDD_OK) return rc; }
     if (sq != s) HIP_TRY(sd->link(sq, s));
     hipLaunchKernelGGL(edge_to_node3_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, s, (const float*)tq.gd,

@@ -620,6 +620,11 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
   TrainSide* sd = net->side_mask ? &net->side : nullptr;
   hipStream_t sw = sd && (sd->mask & SIDE_NODE_WG) ? sd->wg : s;      // the stream of the block loop's weight gradients (w.wg / w.colscr are its scratch there)
   auto fork_w = [&]() -> int { if (sw != s) HIP_TRY(sd->link(s, sd->wg)); return DSBDD_OK; };
+  // the bias gradients (ordered column sums, w.colscr) of the sublayers go to the OTHER side stream, idle outside the
+  // coordinate stages: the weight-gradient chain of a sublayer (3 GEMMs + their reductions + 2 two-stage column sums) was
+  // longer than the main chain's node work beside it, and the main chain waited for it in front of the W2 gradient
+  hipStream_t sb = sw != s ? sd->co : s;
+  auto fork_b = [&]() -> int { if (sb != s) HIP_TRY(sd->link(s, sd->co)); return DSBDD_OK; };
   const float* const* P = params;
   float* const* G = grads;
   const int H = d.H, a = d.a, r = d.r, J = d.J, JP = d.JP, N = (int)d.N, nl_ = (int)d.n_l, np_ = (int)d.n_p, M = d.M;
@@ -742,12 +747,13 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       const float* hin = w.h[gi];
       float* dout = w.d_h[cur];
       // node MLP backward
-      // (weight gradients on the side stream; the main stream meets it again before the next edge kernel A -- which is
-      //  before anything these launches read is overwritten: dout by the message stage's tn_lin, dz / xcat / d_pq by the
-      //  next sublayer)
+      // (weight gradients on the side stream; the main stream joins it in front of the message stage's W2 gradient
+      //  (mlp_backward) -- which is before anything these launches read is overwritten: dout by the message stage's last
+      //  tn_lin, dz / xcat by the next sublayer, d_pq / d_pq4 by the node gathers that follow the join)
       { int rc = fork_w(); if (rc) return rc; }
       { int rc = tn_wgrad(sw, dout, H, w.act[gi], H, N, H, H, G[base + 6], w); if (rc) return rc; }
-      { int rc = tn_colsum(sw, dout, H, N, H, G[base + 7], w); if (rc) return rc; }
+      { int rc = fork_b(); if (rc) return rc; }
+      { int rc = tn_colsum(sb, dout, H, N, H, G[base + 7], w); if (rc) return rc; }
       { int rc = tn_lin(s, dout, H, H, nullptr, 0, 0, P[base + 6], H, nullptr, nullptr, 0, w.da, H, N, H); if (rc) return rc; }
       hipLaunchKernelGGL(tn_silu_bwd_kernel, dim3(tn_blocks((size_t)N * H)), dim3(256), 0, s, (const float*)w.da, (const float*)w.z[gi], w.dz, (size_t)N * H);
       HIP_TRY(hipGetLastError());
@@ -755,7 +761,8 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       HIP_TRY(hipGetLastError());
       { int rc = fork_w(); if (rc) return rc; }
       { int rc = tn_wgrad(sw, w.dz, H, w.xcat, 2 * H, N, H, 2 * H, G[base + 4], w); if (rc) return rc; }
-      { int rc = tn_colsum(sw, w.dz, H, N, H, G[base + 5], w); if (rc) return rc; }
+      { int rc = fork_b(); if (rc) return rc; }
+      { int rc = tn_colsum(sb, w.dz, H, N, H, G[base + 5], w); if (rc) return rc; }
       // d_hin = dz W1[:, :H] + d_out (residual);  d_agg = dz W1[:, H:]
       { int rc = tn_lin(s, w.dz, H, H, nullptr, 0, 0, P[base + 4], 2 * H, nullptr, dout, H, w.d_h[cur ^ 1], H, N, H); if (rc) return rc; }
       { int rc = tn_lin(s, w.dz, H, H, nullptr, 0, 0, P[base + 4] + H, 2 * H, nullptr, nullptr, 0, w.d_agg, H, N, H); if (rc) return rc; }
@@ -785,7 +792,7 @@ int dsbdd_train_net_backward(dsbdd_train_net* net, void* stream, const dsbdd_tra
       }
     }
   }
-  if (sd) HIP_TRY(sd->link(sd->wg, s));      // every weight gradient of the blocks is complete from here on
+  if (sd) { HIP_TRY(sd->link(sd->wg, s)); HIP_TRY(sd->link(sd->co, s)); }      // every weight / bias gradient of the blocks is complete from here on
   // embedding
   { int rc = tn_wgrad(s, w.d_h[cur], H, w.h0, JP, N, H, d.D, G[ix.emb], w); if (rc) return rc; }
   { int rc = tn_colsum(s, w.d_h[cur], H, N, H, G[ix.emb + 1], w); if (rc) return rc; }
